@@ -1,0 +1,676 @@
+// C-ABI of libcondmdi_hip.so (include/condmdi.h): engine handle, weight packing, the MDM
+// trans_enc forward / dX-backward schedule of kernel launches, and the sampling loop.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/condmdi.h"
+#include "kernels.hpp"
+
+using namespace cmdi;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(expr)                                                                      \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess)                                                             \
+            return fail(CMDI_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));   \
+    } while (0)
+
+struct LayerW {
+    float *in_w = nullptr, *in_b = nullptr, *out_w = nullptr, *out_b = nullptr;
+    float *l1_w = nullptr, *l1_b = nullptr, *l2_w = nullptr, *l2_b = nullptr;
+    float *n1_g = nullptr, *n1_b = nullptr, *n2_g = nullptr, *n2_b = nullptr;
+    // transposed copies for the dX backward GEMMs (want_grad only)
+    float *in_wT = nullptr, *out_wT = nullptr, *l1_wT = nullptr, *l2_wT = nullptr;
+};
+struct LayerStash {
+    float *qkv = nullptr, *attn = nullptr, *row_stats = nullptr;
+    float *pre1 = nullptr, *stats1 = nullptr, *aux = nullptr, *pre2 = nullptr, *stats2 = nullptr;
+};
+
+}  // namespace
+
+struct cmdi_engine {
+    cmdi_model_desc desc{};
+    int L = 0, d = 0, f = 0, H = 0, C = 0, Cpad = 0, Tmax = 0, Bmax = 0, clip_dim = 512;
+    std::vector<void*> allocs;
+    int64_t bytes = 0;
+
+    // weights
+    float *w_in = nullptr, *b_in = nullptr, *w_in_pad = nullptr, *w_inT = nullptr;
+    float *pe = nullptr;
+    float *t1_w = nullptr, *t1_b = nullptr, *t2_w = nullptr, *t2_b = nullptr;
+    float *txt_w = nullptr, *txt_b = nullptr;
+    float *w_out = nullptr, *b_out = nullptr, *w_outT_pad = nullptr;
+    std::vector<LayerW> layers;
+    float* time_table = nullptr;
+    int n_time_rows = 0;
+    bool finalized = false;
+
+    // schedule (host)
+    bool have_schedule = false;
+    int n_steps = 0, mean_type = 0;
+    std::vector<float> c1, c2, sigma, sqrt_ab, sqrt_1mab, sra, srm1a, ab, ab_prev;
+    std::vector<int64_t> tmap;
+
+    // condition
+    bool have_cond = false;
+    int B = 0, T = 0, cfg = 0;
+    int imputate = 0, stop_imp = 0, recon = 0, stop_rec = 0;
+    bool have_mask = false, have_text = false;
+    std::vector<float> recon_w;
+    float *text_term = nullptr, *text_scale = nullptr, *inpaint = nullptr, *enc_text = nullptr;
+    uint8_t* mask = nullptr;
+
+    // workspace
+    float *tokA = nullptr, *tokB = nullptr, *bufH = nullptr, *qkv = nullptr, *attn = nullptr,
+          *ffn = nullptr, *out_raw = nullptr;
+    std::vector<LayerStash> stash;
+    bool stash_valid = false;
+    float *dA = nullptr, *dB = nullptr, *dH = nullptr, *dqkv = nullptr, *dffn = nullptr,
+          *drowdot = nullptr, *gout = nullptr, *gx = nullptr;
+    int gemm_tile = 0;
+};
+
+namespace {
+
+int dalloc(cmdi_engine* e, void** p, size_t nbytes) {
+    if (nbytes == 0) nbytes = 16;
+    hipError_t err = hipMalloc(p, nbytes);
+    if (err != hipSuccess)
+        return fail(CMDI_E_NOMEM, std::string("hipMalloc(") + std::to_string(nbytes) +
+                                      "): " + hipGetErrorString(err));
+    e->allocs.push_back(*p);
+    e->bytes += (int64_t)nbytes;
+    return CMDI_OK;
+}
+template <class Tp>
+int falloc(cmdi_engine* e, Tp** p, size_t count) {
+    return dalloc(e, reinterpret_cast<void**>(p), count * sizeof(Tp));
+}
+#define ALLOC(ptr, count)                       \
+    do {                                        \
+        int _rc = falloc(e, &(ptr), (count));   \
+        if (_rc != CMDI_OK) return _rc;         \
+    } while (0)
+
+GemmParams gp(const float* A, const float* W, const float* bias, float* C, int M, int N, int K,
+              int lda, int ldw, int ldc) {
+    GemmParams p{};
+    p.A = A; p.W = W; p.bias = bias; p.C = C;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc;
+    p.out_scale = 1.0f;
+    return p;
+}
+
+// ---- forward pass of MDM trans_enc (model/mdm.py:239-306) over n_seq = B or 2B sequences --------
+int mdm_forward(cmdi_engine* e, const float* x, const int64_t* t_dev, int64_t t_scalar,
+                float* out_buf, bool keep, hipStream_t s) {
+    const int B = e->B, T = e->T, S = T + 1, d = e->d, f = e->f, C = e->C;
+    const int n_seq = e->cfg ? 2 * B : B;
+    const int M = n_seq * S;
+    const int tile = e->gemm_tile;
+
+    HIPCHK(launch_token0(e->tokA, e->time_table, e->have_text ? e->text_term : nullptr, e->pe, t_dev,
+                         t_scalar, n_seq, B, S, d, e->n_time_rows, s));
+    {   // InputProcess + sequence_pos_encoder for the frame tokens (mdm.py:271,279-280)
+        GemmParams p = gp(x, e->w_in_pad, e->b_in, e->tokA, B * T, d, e->Cpad, 0, e->Cpad, d);
+        p.pe = e->pe; p.T = T; p.S = S; p.Cf = C; p.Bdup = e->cfg ? B : 0;
+        HIPCHK(launch_gemm(GK_INPROJ, p, 0, s));
+    }
+    for (int l = 0; l < e->L; ++l) {
+        const LayerW& w = e->layers[l];
+        float* qkv = keep ? e->stash[l].qkv : e->qkv;
+        float* attn = keep ? e->stash[l].attn : e->attn;
+        float* pre1 = keep ? e->stash[l].pre1 : e->tokB;
+        float* pre2 = keep ? e->stash[l].pre2 : e->tokB;
+        // self-attention block: x = norm1(x + out_proj(MHA(x)))
+        HIPCHK(launch_gemm(GK_PLAIN, gp(e->tokA, w.in_w, w.in_b, qkv, M, 3 * d, d, d, d, 3 * d), tile, s));
+        HIPCHK(launch_attention_fwd(qkv, attn, keep ? e->stash[l].row_stats : nullptr, n_seq, S, e->H, s));
+        {
+            GemmParams p = gp(attn, w.out_w, w.out_b, pre1, M, d, d, d, d, d);
+            p.R = e->tokA;
+            HIPCHK(launch_gemm(GK_RESID, p, tile, s));
+        }
+        HIPCHK(launch_layernorm(pre1, w.n1_g, w.n1_b, e->bufH, keep ? e->stash[l].stats1 : nullptr, M, d, s));
+        // feed-forward block: x = norm2(x + linear2(gelu(linear1(x))))
+        {
+            GemmParams p = gp(e->bufH, w.l1_w, w.l1_b, e->ffn, M, f, d, d, d, f);
+            p.aux = keep ? e->stash[l].aux : nullptr;
+            HIPCHK(launch_gemm(GK_GELU, p, tile, s));
+        }
+        {
+            GemmParams p = gp(e->ffn, w.l2_w, w.l2_b, pre2, M, d, f, f, f, d);
+            p.R = e->bufH;
+            HIPCHK(launch_gemm(GK_RESID, p, tile, s));
+        }
+        HIPCHK(launch_layernorm(pre2, w.n2_g, w.n2_b, e->tokA, keep ? e->stash[l].stats2 : nullptr, M, d, s));
+    }
+    {   // OutputProcess on tokens 1..T, stored straight into [n_seq, C, 1, T] (mdm.py:284,304,412-422)
+        GemmParams p = gp(e->w_out, e->tokA, e->b_out, out_buf, C, n_seq * T, d, d, d, 0);
+        p.T = T; p.S = S; p.Cf = C;
+        HIPCHK(launch_gemm(GK_OUTPROJ, p, 0, s));
+    }
+    e->stash_valid = keep;
+    return CMDI_OK;
+}
+
+// ---- dX backward: gx[n_seq,C,T] = (d out / d x)ᵀ · gout[n_seq,C,T], per sequence ---------------
+int mdm_backward(cmdi_engine* e, const float* gout, float* gx, hipStream_t s) {
+    const int B = e->B, T = e->T, S = T + 1, d = e->d, f = e->f, C = e->C;
+    const int n_seq = e->cfg ? 2 * B : B;
+    const int M = n_seq * S;
+    const int tile = e->gemm_tile;
+    if (!e->stash_valid) return fail(CMDI_E_STATE, "cmdi_mdm_vjp: no stashed forward pass");
+
+    // output projection: d tok[b*S+1+t][k] = sum_c gout[b][c][t] W_out[c][k]; token 0 rows get 0
+    HIPCHK(hipMemsetAsync(e->dA, 0, (size_t)M * d * sizeof(float), s));
+    {
+        GemmParams p = gp(gout, e->w_outT_pad, nullptr, e->dA, n_seq * T, d, e->Cpad, 0, e->Cpad, d);
+        p.T = T; p.S = S; p.Cf = C;
+        HIPCHK(launch_gemm(GK_OUTPROJ_BWD, p, 0, s));
+    }
+    for (int l = e->L - 1; l >= 0; --l) {
+        const LayerW& w = e->layers[l];
+        const LayerStash& st = e->stash[l];
+        // norm2
+        HIPCHK(launch_layernorm_bwd(st.pre2, st.stats2, w.n2_g, e->dA, e->dB, M, d, s));  // dB = d pre2
+        // linear2 + GELU: dffn = (dB · W2) * gelu'(aux)
+        {
+            GemmParams p = gp(e->dB, w.l2_wT, nullptr, e->dffn, M, f, d, d, d, f);
+            p.aux = st.aux;
+            HIPCHK(launch_gemm(GK_GELUGRAD, p, tile, s));
+        }
+        // linear1 + residual: dH = dffn · W1 + dB
+        {
+            GemmParams p = gp(e->dffn, w.l1_wT, nullptr, e->dH, M, d, f, f, f, d);
+            p.R = e->dB;
+            HIPCHK(launch_gemm(GK_ACCUM, p, tile, s));
+        }
+        // norm1
+        HIPCHK(launch_layernorm_bwd(st.pre1, st.stats1, w.n1_g, e->dH, e->dB, M, d, s));  // dB = d pre1
+        // out_proj: d attn = dB · Wo   (no bias, no residual) -> reuse dH as d attn
+        HIPCHK(launch_gemm(GK_PLAIN, gp(e->dB, w.out_wT, nullptr, e->dH, M, d, d, d, d, d), tile, s));
+        // attention core
+        HIPCHK(launch_attention_bwd(st.qkv, st.attn, st.row_stats, e->dH, e->dqkv, e->drowdot, n_seq, S,
+                                    e->H, s));
+        // in_proj + residual: dA = dqkv · Wqkv + dB
+        {
+            GemmParams p = gp(e->dqkv, w.in_wT, nullptr, e->dA, M, d, 3 * d, 3 * d, 3 * d, d);
+            p.R = e->dB;
+            HIPCHK(launch_gemm(GK_ACCUM, p, tile, s));
+        }
+    }
+    {   // input projection: gx[b][c][t] = sum_n dA[b*S+1+t][n] W_in[n][c]
+        GemmParams p = gp(e->w_inT, e->dA, nullptr, gx, C, n_seq * T, d, d, d, 0);
+        p.T = T; p.S = S; p.Cf = C;
+        HIPCHK(launch_gemm(GK_OUTPROJ, p, 0, s));
+    }
+    return CMDI_OK;
+}
+
+int check_ready(cmdi_engine* e, bool need_schedule, bool need_model = true) {
+    if (!e) return fail(CMDI_E_INVALID, "null handle");
+    if (need_model && e->L == 0) return fail(CMDI_E_STATE, "sampler-only engine has no denoiser");
+    if (!e->finalized) return fail(CMDI_E_STATE, "weights not finalized (cmdi_finalize_weights)");
+    if (!e->have_cond) return fail(CMDI_E_STATE, "condition not set (cmdi_set_condition)");
+    if (need_schedule && !e->have_schedule) return fail(CMDI_E_STATE, "schedule not set (cmdi_set_schedule)");
+    return CMDI_OK;
+}
+
+int build_coef(cmdi_engine* e, int sampler, int step, float eta, bool impute, bool recon,
+               StepCoef* k) {
+    if (step < 0 || step >= e->n_steps) return fail(CMDI_E_INVALID, "step out of range");
+    std::memset(k, 0, sizeof(*k));
+    k->mean_eps = e->mean_type == CMDI_MEAN_EPSILON;
+    k->impute = impute;
+    k->recon = recon;
+    k->sra = e->sra[step];
+    k->srm1a = e->srm1a[step];
+    const float nz = step != 0 ? 1.0f : 0.0f;
+    if (sampler == CMDI_SAMPLER_DDPM) {
+        k->ddim = 0;
+        k->c1 = e->c1[step];
+        k->c2 = e->c2[step];
+        k->sig_nz = nz * e->sigma[step];
+    } else {
+        // ddim_sample (gaussian_diffusion.py:1339-1351), every operation in fp32 like the tensors
+        // produced by _extract_into_tensor(...).float()
+        k->ddim = 1;
+        const float ab = e->ab[step], abp = e->ab_prev[step];
+        const volatile float r1 = sqrtf((1.0f - abp) / (1.0f - ab));
+        const volatile float r2 = sqrtf(1.0f - ab / abp);
+        const volatile float sig = (eta * r1) * r2;
+        k->sqrt_abp = sqrtf(abp);
+        const volatile float sig2 = sig * sig;
+        const volatile float inner = (1.0f - abp) - sig2;
+        k->dir = sqrtf(inner);
+        k->sig_nz = nz * sig;
+    }
+    if (recon) {
+        if ((int)e->recon_w.size() != e->n_steps)
+            return fail(CMDI_E_STATE, "reconstruction guidance needs recon_w[n_steps]");
+        const volatile float ws = e->recon_w[step] * e->sqrt_ab[step];
+        k->gcoef = ws / 2.0f;
+    }
+    return CMDI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* cmdi_last_error(void) { return g_err.c_str(); }
+const char* cmdi_version(void) { return "condmdi-hip 0.1 (gfx950, fp32 MFMA)"; }
+
+int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
+    if (!desc || !out) return fail(CMDI_E_INVALID, "null argument");
+    if (desc->n_feats < 1 || desc->max_batch < 1 || desc->max_frames < 1)
+        return fail(CMDI_E_INVALID, "bad model geometry");
+    if (desc->n_layers == 0) {
+        // sampler-only engine: schedule + condition + cmdi_sampler_update / q_sample / randn, for
+        // denoisers that are not the native MDM
+        cmdi_engine* e = new cmdi_engine();
+        e->desc = *desc;
+        e->desc.text_cond = 0;
+        e->desc.want_grad = 0;
+        e->C = desc->n_feats; e->Tmax = desc->max_frames; e->Bmax = desc->max_batch;
+        *out = e;
+        ALLOC(e->text_scale, e->Bmax);
+        ALLOC(e->inpaint, (size_t)e->Bmax * e->C * e->Tmax);
+        int rc = dalloc(e, reinterpret_cast<void**>(&e->mask), (size_t)e->Bmax * e->C * e->Tmax);
+        if (rc != CMDI_OK) return rc;
+        e->finalized = true;
+        return CMDI_OK;
+    }
+    if (desc->n_heads <= 0 || desc->d_model != desc->n_heads * 128)
+        return fail(CMDI_E_INVALID, "d_model / n_heads must be 128");
+    if (desc->d_model % 256 != 0 || desc->d_model > 1024)
+        return fail(CMDI_E_INVALID, "d_model must be 256, 512, 768 or 1024");
+    if (desc->d_ff % 128 != 0) return fail(CMDI_E_INVALID, "d_ff must be a multiple of 128");
+    if (desc->max_frames > 223) return fail(CMDI_E_INVALID, "max_frames must be in [1, 223]");
+    if (desc->n_layers < 1 || desc->pe_rows < desc->max_frames + 1)
+        return fail(CMDI_E_INVALID, "bad model geometry");
+    cmdi_engine* e = new cmdi_engine();
+    e->desc = *desc;
+    e->L = desc->n_layers; e->d = desc->d_model; e->f = desc->d_ff; e->H = desc->n_heads;
+    e->C = desc->n_feats; e->Cpad = (desc->n_feats + 31) / 32 * 32;
+    e->Tmax = desc->max_frames; e->Bmax = desc->max_batch;
+    const char* tile_env = std::getenv("CMDI_GEMM_TILE");
+    e->gemm_tile = tile_env ? std::atoi(tile_env) : 0;
+    const int d = e->d, f = e->f, C = e->C;
+    const size_t nseq = 2 * (size_t)e->Bmax, Smax = e->Tmax + 1, Mmax = nseq * Smax;
+    *out = e;  // so that cmdi_destroy can free a half-built engine
+
+    ALLOC(e->w_in, (size_t)d * C); ALLOC(e->b_in, d); ALLOC(e->w_in_pad, (size_t)d * e->Cpad);
+    ALLOC(e->pe, (size_t)desc->pe_rows * d);
+    ALLOC(e->t1_w, (size_t)d * d); ALLOC(e->t1_b, d); ALLOC(e->t2_w, (size_t)d * d); ALLOC(e->t2_b, d);
+    if (desc->text_cond) { ALLOC(e->txt_w, (size_t)d * e->clip_dim); ALLOC(e->txt_b, d); }
+    ALLOC(e->w_out, (size_t)C * d); ALLOC(e->b_out, C);
+    e->layers.resize(e->L);
+    for (LayerW& w : e->layers) {
+        ALLOC(w.in_w, (size_t)3 * d * d); ALLOC(w.in_b, 3 * d);
+        ALLOC(w.out_w, (size_t)d * d); ALLOC(w.out_b, d);
+        ALLOC(w.l1_w, (size_t)f * d); ALLOC(w.l1_b, f);
+        ALLOC(w.l2_w, (size_t)d * f); ALLOC(w.l2_b, d);
+        ALLOC(w.n1_g, d); ALLOC(w.n1_b, d); ALLOC(w.n2_g, d); ALLOC(w.n2_b, d);
+        if (desc->want_grad) {
+            ALLOC(w.in_wT, (size_t)3 * d * d); ALLOC(w.out_wT, (size_t)d * d);
+            ALLOC(w.l1_wT, (size_t)f * d); ALLOC(w.l2_wT, (size_t)d * f);
+        }
+    }
+    ALLOC(e->text_term, nseq * d); ALLOC(e->text_scale, e->Bmax);
+    ALLOC(e->enc_text, (size_t)e->Bmax * e->clip_dim);
+    ALLOC(e->inpaint, (size_t)e->Bmax * C * e->Tmax);
+    {
+        int rc = dalloc(e, reinterpret_cast<void**>(&e->mask), (size_t)e->Bmax * C * e->Tmax);
+        if (rc != CMDI_OK) return rc;
+    }
+    ALLOC(e->tokA, Mmax * d); ALLOC(e->tokB, Mmax * d); ALLOC(e->bufH, Mmax * d);
+    ALLOC(e->qkv, Mmax * 3 * d); ALLOC(e->attn, Mmax * d); ALLOC(e->ffn, Mmax * f);
+    ALLOC(e->out_raw, nseq * C * e->Tmax);
+    if (desc->want_grad) {
+        ALLOC(e->w_inT, (size_t)C * d); ALLOC(e->w_outT_pad, (size_t)d * e->Cpad);
+        e->stash.resize(e->L);
+        for (LayerStash& st : e->stash) {
+            ALLOC(st.qkv, Mmax * 3 * d); ALLOC(st.attn, Mmax * d);
+            ALLOC(st.row_stats, nseq * e->H * Smax * 2);
+            ALLOC(st.pre1, Mmax * d); ALLOC(st.stats1, Mmax * 2); ALLOC(st.aux, Mmax * f);
+            ALLOC(st.pre2, Mmax * d); ALLOC(st.stats2, Mmax * 2);
+        }
+        ALLOC(e->dA, Mmax * d); ALLOC(e->dB, Mmax * d); ALLOC(e->dH, Mmax * d);
+        ALLOC(e->dqkv, Mmax * 3 * d); ALLOC(e->dffn, Mmax * f);
+        ALLOC(e->drowdot, nseq * e->H * Smax);
+        ALLOC(e->gout, nseq * C * e->Tmax); ALLOC(e->gx, nseq * C * e->Tmax);
+    }
+    return CMDI_OK;
+}
+
+int cmdi_destroy(cmdi_handle h) {
+    if (!h) return CMDI_OK;
+    for (void* p : h->allocs) (void)hipFree(p);
+    delete h;
+    return CMDI_OK;
+}
+
+int64_t cmdi_workspace_bytes(cmdi_handle h) { return h ? h->bytes : 0; }
+
+int cmdi_load_weight(cmdi_handle e, const char* name, const float* d_src, int64_t numel,
+                     cmdi_stream stream) {
+    if (!e || !name || !d_src) return fail(CMDI_E_INVALID, "null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int d = e->d, f = e->f, C = e->C;
+    float* dst = nullptr;
+    int64_t want = -1;
+    const std::string n(name);
+    int l = -1;
+    char rest[96] = {0};
+    if (n == "input_process.poseEmbedding.weight") { dst = e->w_in; want = (int64_t)d * C; }
+    else if (n == "input_process.poseEmbedding.bias") { dst = e->b_in; want = d; }
+    else if (n == "sequence_pos_encoder.pe") { dst = e->pe; want = (int64_t)e->desc.pe_rows * d; }
+    else if (n == "embed_timestep.sequence_pos_encoder.pe") { return CMDI_OK; /* alias of the above */ }
+    else if (n == "embed_timestep.time_embed.0.weight") { dst = e->t1_w; want = (int64_t)d * d; }
+    else if (n == "embed_timestep.time_embed.0.bias") { dst = e->t1_b; want = d; }
+    else if (n == "embed_timestep.time_embed.2.weight") { dst = e->t2_w; want = (int64_t)d * d; }
+    else if (n == "embed_timestep.time_embed.2.bias") { dst = e->t2_b; want = d; }
+    else if (n == "embed_text.weight" && e->txt_w) { dst = e->txt_w; want = (int64_t)d * e->clip_dim; }
+    else if (n == "embed_text.bias" && e->txt_b) { dst = e->txt_b; want = d; }
+    else if (n == "output_process.poseFinal.weight") { dst = e->w_out; want = (int64_t)C * d; }
+    else if (n == "output_process.poseFinal.bias") { dst = e->b_out; want = C; }
+    else if (std::sscanf(name, "seqTransEncoder.layers.%d.%95s", &l, rest) == 2 && l >= 0 && l < e->L) {
+        LayerW& w = e->layers[l];
+        const std::string r(rest);
+        if (r == "self_attn.in_proj_weight") { dst = w.in_w; want = (int64_t)3 * d * d; }
+        else if (r == "self_attn.in_proj_bias") { dst = w.in_b; want = 3 * d; }
+        else if (r == "self_attn.out_proj.weight") { dst = w.out_w; want = (int64_t)d * d; }
+        else if (r == "self_attn.out_proj.bias") { dst = w.out_b; want = d; }
+        else if (r == "linear1.weight") { dst = w.l1_w; want = (int64_t)f * d; }
+        else if (r == "linear1.bias") { dst = w.l1_b; want = f; }
+        else if (r == "linear2.weight") { dst = w.l2_w; want = (int64_t)d * f; }
+        else if (r == "linear2.bias") { dst = w.l2_b; want = d; }
+        else if (r == "norm1.weight") { dst = w.n1_g; want = d; }
+        else if (r == "norm1.bias") { dst = w.n1_b; want = d; }
+        else if (r == "norm2.weight") { dst = w.n2_g; want = d; }
+        else if (r == "norm2.bias") { dst = w.n2_b; want = d; }
+    }
+    if (!dst) return fail(CMDI_E_UNKNOWN_WEIGHT, std::string("unknown weight: ") + name);
+    if (numel != want)
+        return fail(CMDI_E_INVALID, std::string(name) + ": expected " + std::to_string(want) +
+                                        " elements, got " + std::to_string(numel));
+    HIPCHK(hipMemcpyAsync(dst, d_src, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice, s));
+    e->finalized = false;
+    return CMDI_OK;
+}
+
+int cmdi_finalize_weights(cmdi_handle e, int32_t n_time_rows, cmdi_stream stream) {
+    if (!e) return fail(CMDI_E_INVALID, "null handle");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int d = e->d, f = e->f, C = e->C;
+    if (n_time_rows < 1 || n_time_rows > e->desc.pe_rows)
+        return fail(CMDI_E_INVALID, "n_time_rows must be in [1, pe_rows]");
+    HIPCHK(launch_pad_copy(e->w_in_pad, e->w_in, d, C, e->Cpad, s));
+    if (e->desc.want_grad) {
+        HIPCHK(launch_transpose_pad(e->w_inT, e->w_in, d, C, d, s));          // [C][d]
+        HIPCHK(launch_transpose_pad(e->w_outT_pad, e->w_out, C, d, e->Cpad, s));  // [d][Cpad]
+        for (LayerW& w : e->layers) {
+            HIPCHK(launch_transpose_pad(w.in_wT, w.in_w, 3 * d, d, 3 * d, s));  // [d][3d]
+            HIPCHK(launch_transpose_pad(w.out_wT, w.out_w, d, d, d, s));
+            HIPCHK(launch_transpose_pad(w.l1_wT, w.l1_w, f, d, f, s));          // [d][f]
+            HIPCHK(launch_transpose_pad(w.l2_wT, w.l2_w, d, f, d, s));          // [f][d]
+        }
+    }
+    // TimestepEmbedder (mdm.py:351-353) for every original timestep: Linear -> SiLU -> Linear on pe[t]
+    if (!e->time_table || e->n_time_rows < n_time_rows) {
+        int rc = falloc(e, &e->time_table, (size_t)n_time_rows * d);
+        if (rc != CMDI_OK) return rc;
+    }
+    e->n_time_rows = n_time_rows;
+    float* tmp = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&tmp), (size_t)n_time_rows * d * sizeof(float)));
+    hipError_t e1 = launch_gemm(GK_SILU, gp(e->pe, e->t1_w, e->t1_b, tmp, n_time_rows, d, d, d, d, d), 0, s);
+    hipError_t e2 = launch_gemm(GK_PLAIN, gp(tmp, e->t2_w, e->t2_b, e->time_table, n_time_rows, d, d, d, d, d), 4, s);
+    hipError_t e3 = hipStreamSynchronize(s);  // one-time setup: tmp must outlive the kernels
+    (void)hipFree(tmp);
+    HIPCHK(e1); HIPCHK(e2); HIPCHK(e3);
+    e->finalized = true;
+    return CMDI_OK;
+}
+
+int cmdi_set_schedule(cmdi_handle e, const cmdi_schedule* sc) {
+    if (!e || !sc) return fail(CMDI_E_INVALID, "null argument");
+    if (sc->n_steps < 1) return fail(CMDI_E_INVALID, "n_steps < 1");
+    if (!sc->post_coef1 || !sc->post_coef2 || !sc->sigma || !sc->sqrt_ab || !sc->sqrt_1mab ||
+        !sc->sqrt_recip_ab || !sc->sqrt_recipm1_ab || !sc->ab || !sc->ab_prev || !sc->timestep_map)
+        return fail(CMDI_E_INVALID, "schedule table missing");
+    const int n = sc->n_steps;
+    e->n_steps = n;
+    e->mean_type = sc->mean_type;
+    e->c1.assign(sc->post_coef1, sc->post_coef1 + n);
+    e->c2.assign(sc->post_coef2, sc->post_coef2 + n);
+    e->sigma.assign(sc->sigma, sc->sigma + n);
+    e->sqrt_ab.assign(sc->sqrt_ab, sc->sqrt_ab + n);
+    e->sqrt_1mab.assign(sc->sqrt_1mab, sc->sqrt_1mab + n);
+    e->sra.assign(sc->sqrt_recip_ab, sc->sqrt_recip_ab + n);
+    e->srm1a.assign(sc->sqrt_recipm1_ab, sc->sqrt_recipm1_ab + n);
+    e->ab.assign(sc->ab, sc->ab + n);
+    e->ab_prev.assign(sc->ab_prev, sc->ab_prev + n);
+    e->tmap.assign(sc->timestep_map, sc->timestep_map + n);
+    for (int i = 0; i < n; ++i)
+        if (e->tmap[i] < 0) return fail(CMDI_E_INVALID, "negative timestep in timestep_map");
+    e->have_schedule = true;
+    return CMDI_OK;
+}
+
+int cmdi_set_condition(cmdi_handle e, const cmdi_condition* c, cmdi_stream stream) {
+    if (!e || !c) return fail(CMDI_E_INVALID, "null argument");
+    if (!e->finalized) return fail(CMDI_E_STATE, "weights not finalized");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (c->batch < 1 || c->batch > e->Bmax) return fail(CMDI_E_INVALID, "batch exceeds max_batch");
+    if (c->n_frames < 1 || c->n_frames > e->Tmax) return fail(CMDI_E_INVALID, "n_frames exceeds max_frames");
+    if (c->cfg && !c->d_text_scale) return fail(CMDI_E_INVALID, "cfg needs text_scale");
+    if ((c->imputate || c->recon_guidance) && (!c->d_inpaint_mask || !c->d_inpaint_motion))
+        return fail(CMDI_E_INVALID, "imputation / reconstruction guidance need inpainting_mask and inpainted_motion");
+    if (c->recon_guidance && !e->desc.want_grad)
+        return fail(CMDI_E_STATE, "reconstruction guidance needs an engine created with want_grad=1");
+    if (c->recon_guidance && !c->recon_w) return fail(CMDI_E_INVALID, "reconstruction guidance needs recon_w");
+    const int B = c->batch, T = c->n_frames, d = e->d;
+    const size_t n = (size_t)B * e->C * T;
+    e->B = B; e->T = T; e->cfg = c->cfg ? 1 : 0;
+    e->imputate = c->imputate; e->stop_imp = c->stop_imputation_at;
+    e->recon = c->recon_guidance; e->stop_rec = c->stop_recguidance_at;
+    e->have_mask = c->d_inpaint_mask != nullptr;
+    if (c->d_text_scale)
+        HIPCHK(hipMemcpyAsync(e->text_scale, c->d_text_scale, B * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (c->d_inpaint_mask)
+        HIPCHK(hipMemcpyAsync(e->mask, c->d_inpaint_mask, n, hipMemcpyDeviceToDevice, s));
+    if (c->d_inpaint_motion)
+        HIPCHK(hipMemcpyAsync(e->inpaint, c->d_inpaint_motion, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    e->recon_w.clear();
+    if (c->recon_w) {
+        if (!e->have_schedule) return fail(CMDI_E_STATE, "set the schedule before a condition with recon_w");
+        e->recon_w.assign(c->recon_w, c->recon_w + e->n_steps);
+    }
+    // embed_text(mask_cond(enc_text)) (mdm.py:248-251): conditional rows W·c + b, unconditional rows
+    // (force_mask -> zeros) collapse to the bias.
+    e->have_text = e->desc.text_cond != 0;
+    if (e->have_text) {
+        if (c->d_enc_text) {
+            HIPCHK(hipMemcpyAsync(e->enc_text, c->d_enc_text, (size_t)B * e->clip_dim * sizeof(float),
+                                  hipMemcpyDeviceToDevice, s));
+            HIPCHK(launch_gemm(GK_PLAIN, gp(e->enc_text, e->txt_w, e->txt_b, e->text_term, B, d,
+                                            e->clip_dim, e->clip_dim, e->clip_dim, d), 4, s));
+        } else {
+            HIPCHK(launch_fill_rows(e->text_term, e->txt_b, B, d, s));
+        }
+        if (e->cfg) HIPCHK(launch_fill_rows(e->text_term + (size_t)B * d, e->txt_b, B, d, s));
+    }
+    e->have_cond = true;
+    e->stash_valid = false;
+    return CMDI_OK;
+}
+
+int cmdi_mdm_forward(cmdi_handle e, const float* d_x, const int64_t* d_t, float* d_out,
+                     float* d_out_uncond, cmdi_stream stream) {
+    int rc = check_ready(e, false);
+    if (rc != CMDI_OK) return rc;
+    if (!d_x || !d_t || !d_out) return fail(CMDI_E_INVALID, "null tensor");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t n = (size_t)e->B * e->C * e->T;
+    const bool keep = e->desc.want_grad != 0;
+    if (!e->cfg) {
+        if (d_out_uncond) return fail(CMDI_E_INVALID, "d_out_uncond needs a cfg condition");
+        return mdm_forward(e, d_x, d_t, 0, d_out, keep, s);
+    }
+    rc = mdm_forward(e, d_x, d_t, 0, e->out_raw, keep, s);
+    if (rc != CMDI_OK) return rc;
+    if (d_out_uncond) {
+        HIPCHK(hipMemcpyAsync(d_out, e->out_raw, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(d_out_uncond, e->out_raw + n, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    } else {
+        HIPCHK(launch_cfg_combine(e->out_raw, e->out_raw + n, e->text_scale, d_out, e->B,
+                                  (int64_t)e->C * e->T, s));
+    }
+    return CMDI_OK;
+}
+
+int cmdi_mdm_vjp(cmdi_handle e, const float* d_gout, float* d_gx, cmdi_stream stream) {
+    int rc = check_ready(e, false);
+    if (rc != CMDI_OK) return rc;
+    if (!e->desc.want_grad) return fail(CMDI_E_STATE, "engine created without want_grad");
+    if (!d_gout || !d_gx) return fail(CMDI_E_INVALID, "null tensor");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t per = (int64_t)e->C * e->T;
+    const size_t n = (size_t)e->B * per;
+    if (!e->cfg) return mdm_backward(e, d_gout, d_gx, s);
+    // hat = out_u + s*(out_c - out_u)  =>  d out_c = s*g, d out_u = g - s*g; x feeds both passes
+    HIPCHK(launch_cfg_split(d_gout, e->text_scale, e->gout, e->gout + n, e->B, per, s));
+    rc = mdm_backward(e, e->gout, e->gx, s);
+    if (rc != CMDI_OK) return rc;
+    HIPCHK(launch_add2(d_gx, e->gx, e->gx + n, (int64_t)n, s));
+    return CMDI_OK;
+}
+
+int cmdi_sampler_update(cmdi_handle e, int32_t sampler, int32_t step, float eta,
+                        const float* d_model_out, const float* d_recon_grad, float* d_x,
+                        float* d_pred_xstart, const float* d_noise, uint64_t seed,
+                        int64_t first_sample, cmdi_stream stream) {
+    int rc = check_ready(e, true, false);
+    if (rc != CMDI_OK) return rc;
+    if (!d_model_out || !d_x) return fail(CMDI_E_INVALID, "null tensor");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool impute = e->imputate && step >= e->stop_imp;
+    const bool recon = e->recon && step >= e->stop_rec && d_recon_grad != nullptr;
+    if (e->mean_type == CMDI_MEAN_EPSILON && (impute || recon))
+        return fail(CMDI_E_INVALID, "This feature supports only X_start pred for now!");
+    StepCoef k;
+    rc = build_coef(e, sampler, step, eta, impute, recon, &k);
+    if (rc != CMDI_OK) return rc;
+    SamplerIO io{};
+    io.x = d_x; io.out_c = d_model_out; io.out_u = nullptr; io.text_scale = nullptr;
+    io.mask = e->mask; io.inpaint = e->inpaint; io.grad_c = d_recon_grad; io.grad_u = nullptr;
+    io.noise = d_noise; io.pred_xstart = d_pred_xstart;
+    HIPCHK(launch_sampler_step(io, k, e->B, (int64_t)e->C * e->T, seed, first_sample, step, s));
+    return CMDI_OK;
+}
+
+int cmdi_step(cmdi_handle e, int32_t sampler, int32_t step, float eta, float* d_x,
+              float* d_pred_xstart, const float* d_noise, uint64_t seed, int64_t first_sample,
+              cmdi_stream stream) {
+    int rc = check_ready(e, true);
+    if (rc != CMDI_OK) return rc;
+    if (!d_x) return fail(CMDI_E_INVALID, "null tensor");
+    if (step < 0 || step >= e->n_steps) return fail(CMDI_E_INVALID, "step out of range");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t per = (int64_t)e->C * e->T;
+    const size_t n = (size_t)e->B * per;
+    const bool impute = e->imputate && step >= e->stop_imp;
+    const bool recon = e->recon && step >= e->stop_rec;
+    if (e->mean_type == CMDI_MEAN_EPSILON && (impute || recon))
+        return fail(CMDI_E_INVALID, "This feature supports only X_start pred for now!");
+    if (e->tmap[step] >= e->n_time_rows)
+        return fail(CMDI_E_STATE, "timestep_map exceeds the finalized time-embedding table");
+
+    rc = mdm_forward(e, d_x, nullptr, e->tmap[step], e->out_raw, recon, s);
+    if (rc != CMDI_OK) return rc;
+    const float* out_c = e->out_raw;
+    const float* out_u = e->cfg ? e->out_raw + n : nullptr;
+    const float *grad_c = nullptr, *grad_u = nullptr;
+    if (recon) {
+        HIPCHK(launch_recon_gout(out_c, out_u, e->text_scale, e->mask, e->inpaint, e->gout,
+                                 e->gout + n, e->B, per, s));
+        rc = mdm_backward(e, e->gout, e->gx, s);
+        if (rc != CMDI_OK) return rc;
+        grad_c = e->gx;
+        grad_u = e->cfg ? e->gx + n : nullptr;
+    }
+    StepCoef k;
+    rc = build_coef(e, sampler, step, eta, impute, recon, &k);
+    if (rc != CMDI_OK) return rc;
+    SamplerIO io{};
+    io.x = d_x; io.out_c = out_c; io.out_u = out_u; io.text_scale = e->text_scale;
+    io.mask = e->mask; io.inpaint = e->inpaint; io.grad_c = grad_c; io.grad_u = grad_u;
+    io.noise = d_noise; io.pred_xstart = d_pred_xstart;
+    HIPCHK(launch_sampler_step(io, k, e->B, per, seed, first_sample, step, s));
+    return CMDI_OK;
+}
+
+int cmdi_sample_loop(cmdi_handle e, int32_t sampler, int32_t first_step, int32_t last_step,
+                     float eta, float* d_x, const float* d_noise_stream, uint64_t seed,
+                     int64_t first_sample, cmdi_stream stream) {
+    int rc = check_ready(e, true);
+    if (rc != CMDI_OK) return rc;
+    if (first_step < last_step || last_step < 0 || first_step >= e->n_steps)
+        return fail(CMDI_E_INVALID, "need n_steps > first_step >= last_step >= 0");
+    const size_t n = (size_t)e->B * e->C * e->T;
+    for (int step = first_step, i = 0; step >= last_step; --step, ++i) {
+        const float* nz = d_noise_stream ? d_noise_stream + (size_t)i * n : nullptr;
+        rc = cmdi_step(e, sampler, step, eta, d_x, nullptr, nz, seed, first_sample, stream);
+        if (rc != CMDI_OK) return rc;
+    }
+    return CMDI_OK;
+}
+
+int cmdi_q_sample(cmdi_handle e, int32_t step, const float* d_x0, const float* d_noise, float* d_out,
+                  int64_t numel, cmdi_stream stream) {
+    if (!e || !e->have_schedule) return fail(CMDI_E_STATE, "schedule not set");
+    if (step < 0 || step >= e->n_steps) return fail(CMDI_E_INVALID, "step out of range");
+    HIPCHK(launch_q_sample(d_x0, d_noise, d_out, e->sqrt_ab[step], e->sqrt_1mab[step], numel,
+                           static_cast<hipStream_t>(stream)));
+    return CMDI_OK;
+}
+
+int cmdi_randn(cmdi_handle, float* d_out, int32_t batch, int64_t per_sample, uint64_t seed,
+               int64_t first_sample, int32_t step, cmdi_stream stream) {
+    if (!d_out || batch < 1 || per_sample < 1) return fail(CMDI_E_INVALID, "bad argument");
+    HIPCHK(launch_randn(d_out, batch, per_sample, seed, first_sample, step,
+                        static_cast<hipStream_t>(stream)));
+    return CMDI_OK;
+}
+
+int cmdi_gemm_nt(const float* d_a, const float* d_w, const float* d_bias, float* d_c, int32_t m,
+                 int32_t n, int32_t k, int32_t tile, cmdi_stream stream) {
+    if (!d_a || !d_w || !d_c) return fail(CMDI_E_INVALID, "null tensor");
+    if (k % 32 != 0 || n % 32 != 0) return fail(CMDI_E_INVALID, "K and N must be multiples of 32");
+    if (tile < 0 || tile > 5) return fail(CMDI_E_INVALID, "tile must be in [0, 5]");
+    HIPCHK(launch_gemm(GK_PLAIN, gp(d_a, d_w, d_bias, d_c, m, n, k, k, k, n), tile,
+                       static_cast<hipStream_t>(stream)));
+    return CMDI_OK;
+}
+
+void cmdi_philox4x32_10(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]) {
+    philox4x32_10_host(counter, key, out);
+}
+
+}  // extern "C"

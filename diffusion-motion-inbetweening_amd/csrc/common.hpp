@@ -1,0 +1,51 @@
+// Shared device helpers for the CondMDI gfx950 engine (fp32 everywhere, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cmdi {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWave = 64;
+
+// Row r (0..15) of a 32x32 MFMA C/D fragment held by lane `lane`:
+// col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+__device__ __forceinline__ int mfma32_row(int r, int lane) {
+    return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+}
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) {
+    // F.gelu default (exact erf form), torch/nn/functional.py; used by
+    // nn.TransformerEncoderLayer(activation="gelu") at model/mdm.py:107-112.
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
+
+// XCD-aware bijective remap of a linear block id (guide T1): blocks that the dispatcher places on
+// the same XCD (id % 8) get a contiguous chunk of the tile space, so tiles sharing an operand
+// panel hit the same private L2.  Speed only; any mapping is correct.
+__device__ __forceinline__ int xcd_remap(int id, int nblocks) {
+    const int q = nblocks >> 3, r = nblocks & 7;
+    const int xcd = id & 7, idx = id >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+}  // namespace cmdi

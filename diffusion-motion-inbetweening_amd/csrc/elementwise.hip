@@ -1,0 +1,204 @@
+// HBM-bound row kernels of the MDM denoiser: LayerNorm (post-norm, eps 1e-5, biased variance —
+// nn.TransformerEncoderLayer.norm1/norm2 built at model/mdm.py:107-114), its backward, and the
+// conditioning-token assembly of MDM.forward (model/mdm.py:245-251,279-280).
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace cmdi {
+
+// One wave per row; a lane owns NV float4 at columns lane*4 + v*256 -> every wave-instruction is a
+// contiguous 1 KiB access.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta,
+                                                        float* __restrict__ y,
+                                                        float* __restrict__ stats, int rows) {
+    constexpr int D = NV * 256;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * D;
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = *reinterpret_cast<const float4*>(xr + i * 256 + lane * 4);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+        q += (a * a + b * b) + (c * c + d * d);
+    }
+    const float var = wave_sum(q) * (1.0f / D);
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    if (stats && lane == 0) {
+        stats[2 * row] = mean;
+        stats[2 * row + 1] = rstd;
+    }
+    float* yr = y + (size_t)row * D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float4 g = *reinterpret_cast<const float4*>(gamma + i * 256 + lane * 4);
+        const float4 bb = *reinterpret_cast<const float4*>(beta + i * 256 + lane * 4);
+        float4 o;
+        o.x = (v[i].x - mean) * rstd * g.x + bb.x;
+        o.y = (v[i].y - mean) * rstd * g.y + bb.y;
+        o.z = (v[i].z - mean) * rstd * g.z + bb.z;
+        o.w = (v[i].w - mean) * rstd * g.w + bb.w;
+        *reinterpret_cast<float4*>(yr + i * 256 + lane * 4) = o;
+    }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = gamma * dy,  xhat = (x - mean) * rstd
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ stats,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ dy,
+                                                            float* __restrict__ dx, int rows) {
+    constexpr int D = NV * 256;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    const float* xr = x + (size_t)row * D;
+    const float* dyr = dy + (size_t)row * D;
+    float4 xh[NV], g[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float4 xv = *reinterpret_cast<const float4*>(xr + i * 256 + lane * 4);
+        const float4 dv = *reinterpret_cast<const float4*>(dyr + i * 256 + lane * 4);
+        const float4 gm = *reinterpret_cast<const float4*>(gamma + i * 256 + lane * 4);
+        xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd,
+                            (xv.w - mean) * rstd);
+        g[i] = make_float4(dv.x * gm.x, dv.y * gm.y, dv.z * gm.z, dv.w * gm.w);
+        s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+        s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+    }
+    const float m1 = wave_sum(s1) * (1.0f / D);
+    const float m2 = wave_sum(s2) * (1.0f / D);
+    float* dxr = dx + (size_t)row * D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float4 o;
+        o.x = rstd * (g[i].x - m1 - xh[i].x * m2);
+        o.y = rstd * (g[i].y - m1 - xh[i].y * m2);
+        o.z = rstd * (g[i].z - m1 - xh[i].z * m2);
+        o.w = rstd * (g[i].w - m1 - xh[i].w * m2);
+        *reinterpret_cast<float4*>(dxr + i * 256 + lane * 4) = o;
+    }
+}
+
+hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, float* y,
+                            float* stats, int rows, int d, hipStream_t stream) {
+    const dim3 grid((rows + 3) / 4), block(256);
+    switch (d) {
+        case 256: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, stream, x, gamma, beta, y, stats, rows); break;
+        case 512: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, stream, x, gamma, beta, y, stats, rows); break;
+        case 768: hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, stream, x, gamma, beta, y, stats, rows); break;
+        case 1024: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, stream, x, gamma, beta, y, stats, rows); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_layernorm_bwd(const float* x, const float* stats, const float* gamma,
+                                const float* dy, float* dx, int rows, int d, hipStream_t stream) {
+    const dim3 grid((rows + 3) / 4), block(256);
+    switch (d) {
+        case 256: hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, block, 0, stream, x, stats, gamma, dy, dx, rows); break;
+        case 512: hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, block, 0, stream, x, stats, gamma, dy, dx, rows); break;
+        case 768: hipLaunchKernelGGL(layernorm_bwd_kernel<3>, grid, block, 0, stream, x, stats, gamma, dy, dx, rows); break;
+        case 1024: hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, block, 0, stream, x, stats, gamma, dy, dx, rows); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// tok[b*S][:] = (time_table[t_b] + text_term[b]) + pe[0]   — emb = embed_timestep(t); emb +=
+// embed_text(mask_cond(enc_text)); xseq = cat(emb, x) + pe[:S]   (model/mdm.py:245-251,279-280,334)
+__global__ void token0_kernel(float* __restrict__ tok, const float* __restrict__ time_table,
+                              const float* __restrict__ text_term, const float* __restrict__ pe,
+                              const int64_t* __restrict__ t_dev, int64_t t_scalar, int n_per_pass,
+                              int S, int d, int n_time_rows) {
+    const int b = blockIdx.x;  // sequence index in [0, n_seq); timesteps repeat per CFG pass
+    int64_t t = t_dev ? t_dev[b % n_per_pass] : t_scalar;
+    if (t < 0) t = 0;
+    if (t >= n_time_rows) t = n_time_rows - 1;
+    for (int n = threadIdx.x; n < d; n += blockDim.x) {
+        float e = time_table[(size_t)t * d + n];
+        if (text_term) e += text_term[(size_t)b * d + n];
+        tok[(size_t)b * S * d + n] = e + pe[n];
+    }
+}
+
+hipError_t launch_token0(float* tok, const float* time_table, const float* text_term,
+                         const float* pe, const int64_t* t_dev, int64_t t_scalar, int n_seq,
+                         int n_per_pass, int S, int d, int n_time_rows, hipStream_t stream) {
+    // n_seq = B (single pass) or 2B (CFG: conditional rows then unconditional rows); t_dev, when
+    // given, holds n_per_pass = B entries shared by both passes.
+    hipLaunchKernelGGL(token0_kernel, dim3(n_seq), dim3(256), 0, stream, tok, time_table, text_term,
+                       pe, t_dev, t_scalar, n_per_pass, S, d, n_time_rows);
+    return hipGetLastError();
+}
+
+__global__ void fill_rows_kernel(float* __restrict__ dst, const float* __restrict__ row, int rows,
+                                 int d) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (int64_t)rows * d) dst[i] = row[i % d];
+}
+hipError_t launch_fill_rows(float* dst, const float* row, int rows, int d, hipStream_t stream) {
+    const int64_t n = (int64_t)rows * d;
+    hipLaunchKernelGGL(fill_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, dst, row, rows, d);
+    return hipGetLastError();
+}
+
+__global__ void add2_kernel(float* __restrict__ dst, const float* __restrict__ a,
+                            const float* __restrict__ b, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = a[i] + b[i];
+}
+hipError_t launch_add2(float* dst, const float* a, const float* b, int64_t n, hipStream_t stream) {
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(add2_kernel, dim3(blocks), dim3(256), 0, stream, dst, a, b, n);
+    return hipGetLastError();
+}
+
+__global__ void pad_copy_kernel(float* __restrict__ dst, const float* __restrict__ src, int rows,
+                                int cols, int ldd) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)rows * ldd) return;
+    const int r = (int)(i / ldd), c = (int)(i % ldd);
+    dst[i] = c < cols ? src[(size_t)r * cols + c] : 0.f;
+}
+hipError_t launch_pad_copy(float* dst, const float* src, int rows, int cols, int ldd,
+                           hipStream_t stream) {
+    const int64_t n = (int64_t)rows * ldd;
+    hipLaunchKernelGGL(pad_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dst,
+                       src, rows, cols, ldd);
+    return hipGetLastError();
+}
+
+__global__ void transpose_pad_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                     int rows, int cols, int ldd) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)cols * ldd) return;
+    const int c = (int)(i / ldd), r = (int)(i % ldd);
+    dst[i] = r < rows ? src[(size_t)r * cols + c] : 0.f;
+}
+hipError_t launch_transpose_pad(float* dst, const float* src, int rows, int cols, int ldd,
+                                hipStream_t stream) {
+    const int64_t n = (int64_t)cols * ldd;
+    hipLaunchKernelGGL(transpose_pad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                       dst, src, rows, cols, ldd);
+    return hipGetLastError();
+}
+
+}  // namespace cmdi

@@ -1,0 +1,41 @@
+// Operand / epilogue descriptors of the fp32 NT GEMM family (host + device).
+#pragma once
+#include <stddef.h>
+
+namespace cmdi {
+
+// How a logical operand row maps to memory.
+enum RowMode {
+    ROWS_PLAIN = 0,   // row r at ptr + r*ld, K contiguous
+    ROWS_TOK = 1,     // logical row (b,t) -> token row b*S + 1 + t   (drops the conditioning token)
+    ROWS_MOTION = 2,  // logical row (b,t), element k=c at x[b][c][t] (motion tensor, T contiguous)
+};
+
+enum EpiMode {
+    EPI_PLAIN = 0,     // C = v + bias[n]
+    EPI_GELU = 1,      // aux = v + bias (optional stash); C = gelu_erf(v + bias)
+    EPI_SILU = 2,      // C = silu(v + bias)
+    EPI_RESID = 3,     // C = (v + bias[n]) + R[m][n]
+    EPI_INPROJ = 4,    // m=(b,t): tok[b*S+1+t][n] = v + bias[n] + pe[1+t][n]  (and the uncond copy)
+    EPI_MOTION = 5,    // m=c (feature), n=(b,t): out[b][c][t] = v + bias[m]   (transposed store)
+    EPI_TOKOUT = 6,    // m=(b,t): C[b*S+1+t][n] = v            (backward of the output projection)
+    EPI_GELUGRAD = 7,  // C = v * gelu'(aux[m][n])              (backward through linear1's GELU)
+    EPI_ACCUM = 8,     // C = v + R[m][n] (no bias)              (gradient accumulation)
+};
+
+struct GemmParams {
+    const float* A;
+    const float* W;
+    const float* bias;
+    float* C;
+    const float* R;
+    float* aux;
+    const float* pe;
+    int M, N, K;        // logical sizes (K a multiple of BK after padding)
+    int lda, ldw, ldc;  // leading dimensions of PLAIN/TOK operands and of C
+    int T, S, Cf;       // frames, tokens per sequence (T+1), motion features (263)
+    int Bdup;           // EPI_INPROJ: B if an unconditional copy is also written, else 0
+    float out_scale;    // EPI_MOTION: multiplies v (1 for the forward pass)
+};
+
+}  // namespace cmdi

@@ -1,0 +1,94 @@
+// Host-side launchers of the gfx950 kernels (one translation unit per kernel family).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gemm_params.hpp"
+
+namespace cmdi {
+
+// ---- gemm_f32.hip -------------------------------------------------------------------------
+enum GemmKind {
+    GK_PLAIN = 0,      // A plain, W plain, C = v + bias
+    GK_GELU,           // ... C = gelu(v + bias), optional pre-activation stash in aux
+    GK_SILU,
+    GK_RESID,          // C = v + bias + R
+    GK_ACCUM,          // C = v + R
+    GK_GELUGRAD,       // C = v * gelu'(aux)
+    GK_INPROJ,         // A = motion tensor (transposed read), EPI_INPROJ
+    GK_OUTPROJ,        // A = W_out rows (features), W = token rows, EPI_MOTION (transposed store)
+    GK_OUTPROJ_BWD,    // A = d_out motion tensor, W = W_outᵀ, EPI_TOKOUT
+};
+// tile: 0 auto, 1 = 128x128, 2 = 64x128, 3 = 128x64, 4 = 64x64, 5 = 256x128 (8 waves)
+hipError_t launch_gemm(GemmKind kind, const GemmParams& p, int tile, hipStream_t stream);
+int gemm_auto_tile(int M, int N);
+
+// ---- attention_f32.hip ----------------------------------------------------------------------
+hipError_t launch_attention_fwd(const float* qkv, float* out, float* p_stash, int n_seq, int S,
+                                int H, hipStream_t stream);
+// ---- attention_bwd_f32.hip ------------------------------------------------------------------
+// d_qkv[M,3d] from d_out[M,d]; P is recomputed from the forward's row statistics; d_rowdot is a
+// [n_seq*H*S] scratch (D = rowsum(dO*O)) written by the dQ kernel and read by the dK/dV kernel.
+hipError_t launch_attention_bwd(const float* qkv, const float* o_fwd, const float* row_stats,
+                                const float* d_out, float* d_qkv, float* d_rowdot, int n_seq, int S,
+                                int H, hipStream_t stream);
+
+// ---- elementwise.hip ------------------------------------------------------------------------
+hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, float* y,
+                            float* stats /* [rows][2] mean,rstd or null */, int rows, int d,
+                            hipStream_t stream);
+// dx = LN backward of dy (optionally + extra residual gradient dres added to the result)
+hipError_t launch_layernorm_bwd(const float* x, const float* stats, const float* gamma,
+                                const float* dy, float* dx, int rows, int d, hipStream_t stream);
+// tok[b*S + 0][:] = time_table[t_b] + text_term[b] + pe[0]
+hipError_t launch_token0(float* tok, const float* time_table, const float* text_term,
+                         const float* pe, const int64_t* t_dev, int64_t t_scalar, int n_seq,
+                         int n_per_pass, int S, int d, int n_time_rows, hipStream_t stream);
+// text_term[b'] rows: conditional rows get proj[b] (already W·c+b), unconditional rows get bias
+hipError_t launch_fill_rows(float* dst, const float* row, int rows, int d, hipStream_t stream);
+hipError_t launch_add2(float* dst, const float* a, const float* b, int64_t n, hipStream_t stream);
+// dst[r][c] = c < cols ? src[r][c] : 0   (dst row stride ldd >= cols)
+hipError_t launch_pad_copy(float* dst, const float* src, int rows, int cols, int ldd,
+                           hipStream_t stream);
+// dst[c][r] = r < rows ? src[r][c] : 0 for r < ldd  (src [rows][cols] -> dst [cols][ldd])
+hipError_t launch_transpose_pad(float* dst, const float* src, int rows, int cols, int ldd,
+                                hipStream_t stream);
+
+// ---- sampler.hip ----------------------------------------------------------------------------
+struct StepCoef {
+    float c1, c2;          // posterior_mean_coef1/2[i]
+    float sig_nz;          // [i != 0] * sigma
+    float sra, srm1a;      // sqrt_recip_alphas_cumprod[i], sqrt_recipm1_alphas_cumprod[i]
+    float sqrt_abp, dir;   // DDIM: sqrt(ab_prev), sqrt(1 - ab_prev - sigma^2)
+    float gcoef;           // reconstruction guidance: (w_r * sqrt_ab) / 2
+    int ddim, mean_eps, impute, recon;
+};
+struct SamplerIO {
+    float* x;                 // in: x_t, out: x_{t-1}
+    const float* out_c;       // conditional (or only) model output
+    const float* out_u;       // unconditional output or null
+    const float* text_scale;  // [B] or null
+    const uint8_t* mask;      // inpainting mask or null
+    const float* inpaint;     // inpainted motion or null
+    const float* grad_c;      // reconstruction-guidance gradient halves (null if none)
+    const float* grad_u;
+    const float* noise;       // injected draw or null (engine RNG)
+    float* pred_xstart;       // optional
+};
+hipError_t launch_sampler_step(const SamplerIO& io, const StepCoef& k, int batch, int64_t per_sample,
+                               uint64_t seed, int64_t first_sample, int step, hipStream_t stream);
+// gout_c = s*g, gout_u = (1-s)*g with g = 2*(hat - inpaint)*mask, hat = CFG(out_c, out_u)
+hipError_t launch_recon_gout(const float* out_c, const float* out_u, const float* text_scale,
+                             const uint8_t* mask, const float* inpaint, float* gout_c, float* gout_u,
+                             int batch, int64_t per_sample, hipStream_t stream);
+hipError_t launch_cfg_combine(const float* out_c, const float* out_u, const float* text_scale,
+                              float* out, int batch, int64_t per_sample, hipStream_t stream);
+hipError_t launch_cfg_split(const float* g, const float* text_scale, float* gc, float* gu, int batch,
+                            int64_t per_sample, hipStream_t stream);
+hipError_t launch_q_sample(const float* x0, const float* noise, float* out, float a, float b,
+                           int64_t n, hipStream_t stream);
+hipError_t launch_randn(float* out, int batch, int64_t per_sample, uint64_t seed,
+                        int64_t first_sample, int step, hipStream_t stream);
+void philox4x32_10_host(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+}  // namespace cmdi

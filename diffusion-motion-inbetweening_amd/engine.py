@@ -1,0 +1,270 @@
+"""Python handle on the native engine (libcondmdi_hip.so).
+
+`Engine` owns one ``cmdi_handle``: the packed weights of an MDM ``trans_enc`` denoiser, the
+respaced diffusion schedule and the per-call conditioning, all resident in HBM.  Tensors cross the
+boundary as raw device pointers on torch's current HIP stream; no call synchronises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+
+def _as_f32_ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _require_device_f32(t: torch.Tensor, name: str, device) -> torch.Tensor:
+    if t.device != device:
+        t = t.to(device)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class Engine:
+    """One native engine bound to one HIP device."""
+
+    def __init__(self, *, n_layers: int, d_model: int, d_ff: int, n_heads: int, n_feats: int,
+                 max_frames: int, max_batch: int, pe_rows: int = 5000, text_cond: bool = False,
+                 want_grad: bool = False, device="cuda"):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise N.NativeError(
+                "the CondMDI engine runs on a HIP device only (there is no CPU path); got "
+                f"device={self.device}")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.lib = N.load()
+        self.desc = N.ModelDesc(n_layers, d_model, d_ff, n_heads, n_feats, max_frames, max_batch,
+                                pe_rows, int(text_cond), int(want_grad))
+        self.n_feats, self.max_frames, self.max_batch = n_feats, max_frames, max_batch
+        self.want_grad = bool(want_grad)
+        self.text_cond = bool(text_cond)
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            N.check(self.lib.cmdi_create(C.byref(self.desc), C.byref(self._h)))
+        self.n_steps = 0
+        self.batch = 0
+        self.n_frames = 0
+        self.cfg = False
+        self._schedule_key = None
+        self._keep = []  # host arrays that must outlive a native call
+
+    # -- lifetime -------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            try:
+                torch.cuda.synchronize(self.device)
+            except Exception:
+                pass
+            self.lib.cmdi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def stream(self) -> int:
+        return N.current_stream(self.device)
+
+    def workspace_bytes(self) -> int:
+        return int(self.lib.cmdi_workspace_bytes(self._h))
+
+    # -- weights --------------------------------------------------------------------------------
+    def load_state_dict(self, state_dict, n_time_rows: int = 1000):
+        """Ingest the reference's MDM state dict (SURVEY.md §5.4 key names)."""
+        with torch.cuda.device(self.device):
+            for name, t in state_dict.items():
+                if name.startswith("clip_model."):
+                    continue
+                t = _require_device_f32(t.detach(), name, self.device)
+                N.check(self.lib.cmdi_load_weight(self._h, name.encode(), N.ptr(t), t.numel(),
+                                                  self.stream))
+            N.check(self.lib.cmdi_finalize_weights(self._h, int(n_time_rows), self.stream))
+
+    # -- schedule -------------------------------------------------------------------------------
+    def set_schedule(self, tables: dict, key=None):
+        """`tables`: fp32 numpy arrays named like include/condmdi.h's cmdi_schedule fields."""
+        if key is not None and key == self._schedule_key:
+            return
+        n = int(tables["n_steps"])
+        arrs = {}
+        for name in ("post_coef1", "post_coef2", "sigma", "sqrt_ab", "sqrt_1mab", "sqrt_recip_ab",
+                     "sqrt_recipm1_ab", "ab", "ab_prev"):
+            a = np.ascontiguousarray(tables[name], dtype=np.float32)
+            assert a.shape == (n,), (name, a.shape)
+            arrs[name] = a
+        tmap = np.ascontiguousarray(tables["timestep_map"], dtype=np.int64)
+        assert tmap.shape == (n,)
+        sc = N.Schedule(n, int(tables["mean_type"]), *[_as_f32_ptr(arrs[k]) for k in (
+            "post_coef1", "post_coef2", "sigma", "sqrt_ab", "sqrt_1mab", "sqrt_recip_ab",
+            "sqrt_recipm1_ab", "ab", "ab_prev")], tmap.ctypes.data_as(C.POINTER(C.c_int64)))
+        N.check(self.lib.cmdi_set_schedule(self._h, C.byref(sc)))
+        self.n_steps = n
+        self._schedule_key = key
+
+    # -- condition ------------------------------------------------------------------------------
+    def set_condition(self, *, batch: int, n_frames: int, cfg: bool = False,
+                      enc_text: Optional[torch.Tensor] = None,
+                      text_scale: Optional[torch.Tensor] = None,
+                      inpaint_mask: Optional[torch.Tensor] = None,
+                      inpaint_motion: Optional[torch.Tensor] = None,
+                      imputate: bool = False, stop_imputation_at: int = 0,
+                      recon_guidance: bool = False, stop_recguidance_at: int = 0,
+                      recon_w: Optional[np.ndarray] = None):
+        dev = self.device
+        keep = []
+        if enc_text is not None:
+            enc_text = _require_device_f32(enc_text, "enc_text", dev)
+            assert enc_text.shape == (batch, 512), enc_text.shape
+            keep.append(enc_text)
+        if text_scale is not None:
+            text_scale = _require_device_f32(torch.as_tensor(text_scale).reshape(-1), "text_scale", dev)
+            assert text_scale.numel() == batch
+            keep.append(text_scale)
+        if inpaint_mask is not None:
+            inpaint_mask = inpaint_mask.to(dev).to(torch.uint8).contiguous()
+            assert inpaint_mask.numel() == batch * self.n_feats * n_frames, inpaint_mask.shape
+            keep.append(inpaint_mask)
+        if inpaint_motion is not None:
+            inpaint_motion = _require_device_f32(inpaint_motion, "inpaint_motion", dev)
+            assert inpaint_motion.numel() == batch * self.n_feats * n_frames
+            keep.append(inpaint_motion)
+        rw = None
+        if recon_w is not None:
+            rw = np.ascontiguousarray(recon_w, dtype=np.float32)
+            assert rw.shape == (self.n_steps,), (rw.shape, self.n_steps)
+        cond = N.Condition(batch, n_frames, int(cfg), N.ptr(enc_text), N.ptr(text_scale),
+                           N.ptr(inpaint_mask), N.ptr(inpaint_motion), int(imputate),
+                           int(stop_imputation_at), int(recon_guidance), int(stop_recguidance_at),
+                           _as_f32_ptr(rw) if rw is not None else None)
+        with torch.cuda.device(dev):
+            N.check(self.lib.cmdi_set_condition(self._h, C.byref(cond), self.stream))
+        self.batch, self.n_frames, self.cfg = batch, n_frames, bool(cfg)
+        self._keep = keep  # inputs are copied on the stream: keep them alive until it drains
+
+    # -- denoiser -------------------------------------------------------------------------------
+    def _check_x(self, x: torch.Tensor):
+        if x.device != self.device or x.dtype != torch.float32 or not x.is_contiguous():
+            raise ValueError("x must be a contiguous fp32 tensor on the engine's device")
+        if x.numel() != self.batch * self.n_feats * self.n_frames:
+            raise ValueError(f"x has {x.numel()} elements, condition was set for "
+                             f"[{self.batch},{self.n_feats},1,{self.n_frames}]")
+
+    def mdm_forward(self, x: torch.Tensor, t: torch.Tensor, split: bool = False):
+        """Denoiser output for x [B,J,1,T] at ORIGINAL timesteps t [B] (int64)."""
+        self._check_x(x)
+        t = t.to(device=self.device, dtype=torch.int64).contiguous()
+        assert t.numel() == self.batch
+        out = torch.empty_like(x)
+        out_u = torch.empty_like(x) if split else None
+        with torch.cuda.device(self.device):
+            N.check(self.lib.cmdi_mdm_forward(self._h, N.ptr(x), N.ptr(t), N.ptr(out), N.ptr(out_u),
+                                              self.stream))
+        return (out, out_u) if split else out
+
+    def mdm_vjp(self, gout: torch.Tensor) -> torch.Tensor:
+        self._check_x(gout)
+        gx = torch.empty_like(gout)
+        with torch.cuda.device(self.device):
+            N.check(self.lib.cmdi_mdm_vjp(self._h, N.ptr(gout), N.ptr(gx), self.stream))
+        return gx
+
+    # -- sampler --------------------------------------------------------------------------------
+    def step(self, x: torch.Tensor, step: int, *, sampler: int = N.CMDI_SAMPLER_DDPM,
+             eta: float = 0.0, noise: Optional[torch.Tensor] = None,
+             pred_xstart: Optional[torch.Tensor] = None, seed: int = 0, first_sample: int = 0):
+        """In place: x_t -> x_{t-1} at respaced index `step`."""
+        self._check_x(x)
+        if noise is not None:
+            self._check_x(noise)
+        if pred_xstart is not None:
+            self._check_x(pred_xstart)
+        with torch.cuda.device(self.device):
+            N.check(self.lib.cmdi_step(self._h, sampler, int(step), float(eta), N.ptr(x),
+                                       N.ptr(pred_xstart), N.ptr(noise), int(seed) & (2**64 - 1),
+                                       int(first_sample), self.stream))
+        return x
+
+    def sample_loop(self, x: torch.Tensor, first_step: int, last_step: int = 0, *,
+                    sampler: int = N.CMDI_SAMPLER_DDPM, eta: float = 0.0,
+                    noise_stream: Optional[torch.Tensor] = None, seed: int = 0,
+                    first_sample: int = 0):
+        self._check_x(x)
+        if noise_stream is not None:
+            n_draws = first_step - last_step + 1
+            if (noise_stream.device != self.device or noise_stream.dtype != torch.float32
+                    or not noise_stream.is_contiguous() or noise_stream.numel() != n_draws * x.numel()):
+                raise ValueError("noise_stream must be contiguous fp32 [n_draws, *x.shape] on device")
+        with torch.cuda.device(self.device):
+            N.check(self.lib.cmdi_sample_loop(self._h, sampler, int(first_step), int(last_step),
+                                              float(eta), N.ptr(x), N.ptr(noise_stream),
+                                              int(seed) & (2**64 - 1), int(first_sample), self.stream))
+        return x
+
+    def sampler_update(self, x: torch.Tensor, model_out: torch.Tensor, step: int, *,
+                       sampler: int = N.CMDI_SAMPLER_DDPM, eta: float = 0.0,
+                       recon_grad: Optional[torch.Tensor] = None,
+                       noise: Optional[torch.Tensor] = None,
+                       pred_xstart: Optional[torch.Tensor] = None, seed: int = 0,
+                       first_sample: int = 0):
+        self._check_x(x)
+        self._check_x(model_out)
+        with torch.cuda.device(self.device):
+            N.check(self.lib.cmdi_sampler_update(
+                self._h, sampler, int(step), float(eta), N.ptr(model_out), N.ptr(recon_grad),
+                N.ptr(x), N.ptr(pred_xstart), N.ptr(noise), int(seed) & (2**64 - 1),
+                int(first_sample), self.stream))
+        return x
+
+    def q_sample(self, x0: torch.Tensor, noise: torch.Tensor, step: int) -> torch.Tensor:
+        out = torch.empty_like(x0)
+        with torch.cuda.device(self.device):
+            N.check(self.lib.cmdi_q_sample(self._h, int(step), N.ptr(x0.contiguous()),
+                                           N.ptr(noise.contiguous()), N.ptr(out), x0.numel(),
+                                           self.stream))
+        return out
+
+    def randn(self, shape, *, seed: int, first_sample: int = 0, step: int = -1) -> torch.Tensor:
+        out = torch.empty(tuple(shape), dtype=torch.float32, device=self.device)
+        batch = int(shape[0])
+        per = out.numel() // batch
+        with torch.cuda.device(self.device):
+            N.check(self.lib.cmdi_randn(self._h, N.ptr(out), batch, per, int(seed) & (2**64 - 1),
+                                        int(first_sample), int(step), self.stream))
+        return out
+
+
+def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
+            tile: int = 0) -> torch.Tensor:
+    """C = A[M,K] · W[N,K]ᵀ (+ bias) through the engine's fp32 MFMA GEMM (test / bench hook)."""
+    lib = N.load()
+    assert a.is_cuda and w.is_cuda and a.dtype == torch.float32 and w.dtype == torch.float32
+    a, w = a.contiguous(), w.contiguous()
+    m, k = a.shape
+    n = w.shape[0]
+    assert w.shape[1] == k
+    c = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        N.check(lib.cmdi_gemm_nt(N.ptr(a), N.ptr(w), N.ptr(bias), N.ptr(c), m, n, k, int(tile),
+                                 N.current_stream(a.device)))
+    return c
+
+
+def philox4x32_10(counter, key):
+    """Host Philox4x32-10 block (known-answer tests)."""
+    lib = N.load()
+    c = (C.c_uint32 * 4)(*[int(v) & 0xFFFFFFFF for v in counter])
+    k = (C.c_uint32 * 2)(*[int(v) & 0xFFFFFFFF for v in key])
+    o = (C.c_uint32 * 4)()
+    lib.cmdi_philox4x32_10(c, k, o)
+    return [int(v) for v in o]

@@ -1,0 +1,188 @@
+/*
+ * condmdi.h — C-ABI of libcondmdi_hip.so, the MI355X (gfx950) engine for the CondMDI
+ * diffusion-sampling hot path.
+ *
+ * The reference (setarehc/diffusion-motion-inbetweening) has no FFI: its hot path sits behind a
+ * Python API.  This header is what a binding of that API to native code needs; every entry point
+ * names the reference interface it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - every pointer named d_* is a DEVICE pointer (HIP), everything else is a host pointer;
+ *   - all floating point is IEEE fp32, timesteps are int64, masks are uint8 (0/1);
+ *   - motion tensors use the reference layout [B, J, 1, T] with T contiguous (J*1 = n_feats);
+ *   - every call returns 0 on success or a negative CMDI_E_* code; cmdi_last_error() gives text;
+ *   - calls only ENQUEUE work on `stream` (a hipStream_t); they never synchronise and never throw;
+ *   - the caller owns every buffer it passes; the library owns only its workspace and its private
+ *     copies of weights / schedule / condition tensors (copied at the set_* / load_* call).
+ */
+#ifndef CONDMDI_H
+#define CONDMDI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cmdi_engine* cmdi_handle;
+typedef void* cmdi_stream; /* hipStream_t */
+
+enum {
+    CMDI_OK = 0,
+    CMDI_E_INVALID = -1,   /* bad argument / unsupported dimension           */
+    CMDI_E_STATE = -2,     /* call order violated (weights/schedule missing) */
+    CMDI_E_HIP = -3,       /* a HIP runtime call failed                      */
+    CMDI_E_NOMEM = -4,     /* workspace allocation failed                    */
+    CMDI_E_UNKNOWN_WEIGHT = -5
+};
+
+/* Model geometry.  Replaces the keyword arguments of MDM.__init__ (model/mdm.py:11-36) that the
+ * trans_enc / hml_vec path reads, as produced by get_model_args (utils/model_util.py:40-119). */
+typedef struct {
+    int32_t n_layers;    /* num_layers   (8)                                   */
+    int32_t d_model;     /* latent_dim   (512; must be a multiple of 128)      */
+    int32_t d_ff;        /* ff_size      (1024; multiple of 128)               */
+    int32_t n_heads;     /* num_heads    (4); d_model / n_heads must be 128    */
+    int32_t n_feats;     /* njoints*nfeats (263)                               */
+    int32_t max_frames;  /* largest T this engine will see (<= 223)            */
+    int32_t max_batch;   /* largest B (samples, before the CFG doubling)       */
+    int32_t pe_rows;     /* rows of sequence_pos_encoder.pe (5000)             */
+    int32_t text_cond;   /* 1 if cond_mode contains 'text' (embed_text exists) */
+    int32_t want_grad;   /* 1: allocate the activation stash for cmdi_mdm_vjp  */
+} cmdi_model_desc;
+
+/* Model-output → x0 conventions (diffusion/gaussian_diffusion.py:74-95). */
+enum { CMDI_MEAN_START_X = 0, CMDI_MEAN_EPSILON = 1 };
+enum { CMDI_SAMPLER_DDPM = 0, CMDI_SAMPLER_DDIM = 1 };
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+
+/* Replaces MDM(**get_model_args(args, data)) for arch='trans_enc' (utils/model_util.py:26-37,
+ * model/mdm.py:105-114,136-165): allocates weight storage and the activation workspace. */
+int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out);
+int cmdi_destroy(cmdi_handle h);
+const char* cmdi_last_error(void);
+const char* cmdi_version(void);
+
+/* Replaces load_model_wo_clip / nn.Module.load_state_dict (utils/model_util.py:19-23,168-182).
+ * `name` is the reference state-dict key, e.g.
+ * "seqTransEncoder.layers.3.self_attn.in_proj_weight"; `d_src` is a contiguous fp32 DEVICE tensor
+ * of `numel` elements in the reference's own layout.  Copies on `stream`. */
+int cmdi_load_weight(cmdi_handle h, const char* name, const float* d_src, int64_t numel,
+                     cmdi_stream stream);
+/* Call once after all weights: packs padded/transposed copies and precomputes
+ * TimestepEmbedder.forward (model/mdm.py:351-353) for every original timestep < n_time_rows. */
+int cmdi_finalize_weights(cmdi_handle h, int32_t n_time_rows, cmdi_stream stream);
+
+/* ---- schedule -------------------------------------------------------------------------------
+ * Replaces the float64 tables of GaussianDiffusion.__init__ (diffusion/gaussian_diffusion.py:
+ * 184-217) after SpacedDiffusion's respacing (diffusion/respace.py:74-91) and the per-step
+ * _extract_into_tensor(...).float() casts (:2215-2229).  All arrays have n_steps entries, already
+ * cast to fp32 by the host; timestep_map is respace.py:78-88's list (respaced index → original t).
+ */
+typedef struct {
+    int32_t n_steps;
+    int32_t mean_type;               /* CMDI_MEAN_*                                          */
+    const float* post_coef1;         /* posterior_mean_coef1                                 */
+    const float* post_coef2;         /* posterior_mean_coef2                                 */
+    const float* sigma;              /* exp(0.5 * model_log_variance) for the model_var_type */
+    const float* sqrt_ab;            /* sqrt_alphas_cumprod                                  */
+    const float* sqrt_1mab;          /* sqrt_one_minus_alphas_cumprod                        */
+    const float* sqrt_recip_ab;      /* sqrt_recip_alphas_cumprod                            */
+    const float* sqrt_recipm1_ab;    /* sqrt_recipm1_alphas_cumprod                          */
+    const float* ab;                 /* alphas_cumprod                                       */
+    const float* ab_prev;            /* alphas_cumprod_prev                                  */
+    const int64_t* timestep_map;     /* respaced i → original t                              */
+} cmdi_schedule;
+int cmdi_set_schedule(cmdi_handle h, const cmdi_schedule* s);
+
+/* ---- per-call conditioning ------------------------------------------------------------------
+ * Replaces model_kwargs['y'] as read on the path: text embedding (the output of
+ * MDM.encode_text, model/mdm.py:211-237, [B,512]) and text_scale for ClassifierFreeSampleModel
+ * (model/cfg_sampler.py:25-35); inpainting_mask & y['mask'] and inpainted_motion for imputation /
+ * reconstruction guidance (diffusion/gaussian_diffusion.py:405-435); the host-evaluated gates of
+ * utils/editing_util.py:325-346 and the per-step w_r = grad_ws[i] * reconstruction_weight
+ * (:418-420, editing_util.py:299-322). */
+typedef struct {
+    int32_t batch;                   /* B                                                      */
+    int32_t n_frames;                /* T                                                      */
+    int32_t cfg;                     /* 1: ClassifierFreeSampleModel semantics (2 passes)      */
+    const float* d_enc_text;         /* [B, clip_dim=512] or NULL (no_cond / all-uncond)       */
+    const float* d_text_scale;       /* [B] or NULL (required when cfg=1)                      */
+    const uint8_t* d_inpaint_mask;   /* [B,J,1,T] already AND-ed with y['mask'], or NULL       */
+    const float* d_inpaint_motion;   /* [B,J,1,T] or NULL                                      */
+    int32_t imputate;                /* y['imputate']                                          */
+    int32_t stop_imputation_at;      /* y['stop_imputation_at'] (respaced index)               */
+    int32_t recon_guidance;          /* y['reconstruction_guidance']                           */
+    int32_t stop_recguidance_at;     /* y['stop_recguidance_at']                               */
+    const float* recon_w;            /* HOST [n_steps]: grad_ws[i]*reconstruction_weight, or NULL */
+} cmdi_condition;
+int cmdi_set_condition(cmdi_handle h, const cmdi_condition* c, cmdi_stream stream);
+
+/* ---- denoiser -------------------------------------------------------------------------------
+ * Replaces MDM.forward (model/mdm.py:239-306), and ClassifierFreeSampleModel.forward
+ * (model/cfg_sampler.py:25-35) when the condition was set with cfg=1.
+ * d_x [B,J,1,T]; d_t int64[B] ORIGINAL timesteps (after _WrappedModel, respace.py:128-133);
+ * d_out [B,J,1,T].  If d_out_uncond != NULL (cfg only) the two raw passes are returned instead of
+ * the guided combination: d_out = conditional, d_out_uncond = unconditional. */
+int cmdi_mdm_forward(cmdi_handle h, const float* d_x, const int64_t* d_t, float* d_out,
+                     float* d_out_uncond, cmdi_stream stream);
+
+/* Vector-Jacobian product of the (CFG-combined) denoiser output w.r.t. d_x, evaluated at the
+ * inputs of the LAST cmdi_mdm_forward on this handle (needs want_grad=1).  Replaces
+ * torch.autograd.grad(loss, z) in the reconstruction-guidance block
+ * (diffusion/gaussian_diffusion.py:411-416).  d_gout, d_gx: [B,J,1,T]. */
+int cmdi_mdm_vjp(cmdi_handle h, const float* d_gout, float* d_gx, cmdi_stream stream);
+
+/* ---- sampler --------------------------------------------------------------------------------
+ * One denoising step at respaced index `step`: p_sample (diffusion/gaussian_diffusion.py:656-713)
+ * or ddim_sample (:1300-1416) including p_mean_variance's imputation / reconstruction-guidance
+ * branches (:405-445).  d_x is x_t on entry and x_{t-1} on exit.  d_noise [B,J,1,T] is the draw
+ * th.randn_like(x) of :696; if NULL the engine draws it itself (Philox4x32-10 keyed by
+ * (seed, first_sample + b, step, element), independent of how the batch is sharded).
+ * d_pred_xstart (optional) receives out["pred_xstart"]. */
+int cmdi_step(cmdi_handle h, int32_t sampler, int32_t step, float eta, float* d_x,
+              float* d_pred_xstart, const float* d_noise, uint64_t seed, int64_t first_sample,
+              cmdi_stream stream);
+
+/* The loop of p_sample_loop_progressive / ddim_sample_loop_progressive
+ * (diffusion/gaussian_diffusion.py:1270-1297,1564-1587): for step = first_step .. last_step
+ * (descending, inclusive) call cmdi_step.  d_noise_stream, if not NULL, holds one [B,J,1,T] draw
+ * per step in loop order (the injected-noise parity mode of SURVEY.md §8c). */
+int cmdi_sample_loop(cmdi_handle h, int32_t sampler, int32_t first_step, int32_t last_step,
+                     float eta, float* d_x, const float* d_noise_stream, uint64_t seed,
+                     int64_t first_sample, cmdi_stream stream);
+
+/* Sampler arithmetic alone, for denoisers that are not the native MDM (any callable model):
+ * given the model output (already CFG-combined) apply imputation, the x0/eps conversion and the
+ * posterior / DDIM update.  Same semantics as cmdi_step minus the model call; the
+ * reconstruction-guidance gradient, if any, is passed in d_recon_grad (already masked). */
+int cmdi_sampler_update(cmdi_handle h, int32_t sampler, int32_t step, float eta,
+                        const float* d_model_out, const float* d_recon_grad, float* d_x,
+                        float* d_pred_xstart, const float* d_noise, uint64_t seed,
+                        int64_t first_sample, cmdi_stream stream);
+
+/* q_sample (diffusion/gaussian_diffusion.py:311-328): d_out = sqrt_ab[step]*x0 + sqrt_1mab[step]*noise. */
+int cmdi_q_sample(cmdi_handle h, int32_t step, const float* d_x0, const float* d_noise,
+                  float* d_out, int64_t numel, cmdi_stream stream);
+
+/* Standard-normal fill with the engine's counter-based generator (same keying as cmdi_step with
+ * step = -1); used for x_T when the caller passes noise=None (gaussian_diffusion.py:1248). */
+int cmdi_randn(cmdi_handle h, float* d_out, int32_t batch, int64_t per_sample, uint64_t seed,
+               int64_t first_sample, int32_t step, cmdi_stream stream);
+
+/* ---- introspection for tests / bench --------------------------------------------------------- */
+/* Raw NT GEMM used by every projection: C[M,N] = A[M,K] · W[N,K]^T (+bias[N]); fp32 MFMA.
+ * tile selects the block shape (0 = default heuristic).  K % 32 == 0, N % 32 == 0. */
+int cmdi_gemm_nt(const float* d_a, const float* d_w, const float* d_bias, float* d_c, int32_t m,
+                 int32_t n, int32_t k, int32_t tile, cmdi_stream stream);
+/* Philox4x32-10 raw block (host, for known-answer tests): out[4] = philox(counter[4], key[2]). */
+void cmdi_philox4x32_10(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]);
+/* Bytes of device memory held by the handle. */
+int64_t cmdi_workspace_bytes(cmdi_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CONDMDI_H */

@@ -1,0 +1,91 @@
+"""Seeded synthetic inputs shared by the golden-fixture generator and the tests.
+
+Every input is a pure function of the case dict (numpy PCG64), following the measurement plan of
+SURVEY.md §8d: x ~ N(0,1) (HumanML3D vectors are z-scored before the sampler), ragged lengths,
+fake CLIP embeddings ~ N(0,1), text_scale 2.5, keyframes = get_keyframes_mask('benchmark_sparse',
+trans_length, 'pos_rot_vel') (reference utils/editing_util.py:85-91 — every feature of every
+trans_length-th frame below the sequence length).
+"""
+from __future__ import annotations
+
+import zlib
+
+import numpy as np
+
+N_FEATS = 263
+DUMP_STEPS = (0, 4, 9)  # loop counters whose pred_xstart is stored for 10-step chains
+
+CASES = {
+    # single denoiser evaluations
+    "fwd_uncond": dict(kind="fwd", text=False, weight_seed=11, B=2, T=60, t=[999, 37], seed=101),
+    "fwd_text": dict(kind="fwd", text=True, weight_seed=12, B=2, T=196, t=[500, 3], seed=102,
+                     text_scale=[2.5, 0.0]),
+    "vjp_text_cfg": dict(kind="vjp", text=True, cfg=True, weight_seed=13, B=2, T=60, t=[333, 333],
+                         seed=103, text_scale=[2.5, 1.0]),
+    # 10-step chains (respacing [10] -> original t = 0,111,...,999), injected noise
+    "chain_uncond_ddpm": dict(kind="chain", text=False, cfg=False, weight_seed=14, B=2, T=60,
+                              respacing=[10], sampler="ddpm", seed=104),
+    "chain_edit_recon": dict(kind="chain", text=True, cfg=True, weight_seed=15, B=2, T=60,
+                             respacing=[10], sampler="ddpm", seed=105, text_scale=[2.5, 2.5],
+                             edit=True, trans_length=5, imputate=True, stop_imputation_at=1,
+                             recon=True, recon_weight=20.0, grad_schedule=None,
+                             stop_recguidance_at=0, lengths=[60, 45]),
+    "chain_impute_only": dict(kind="chain", text=True, cfg=True, weight_seed=16, B=2, T=60,
+                              respacing=[10], sampler="ddpm", seed=106, text_scale=[2.5, 0.0],
+                              edit=True, trans_length=5, imputate=True, stop_imputation_at=3,
+                              recon=False, recon_weight=0.0, grad_schedule=None,
+                              stop_recguidance_at=0, lengths=[52, 60]),
+    "chain_ddim_eta0": dict(kind="chain", text=True, cfg=True, weight_seed=17, B=2, T=60,
+                            respacing="ddim10", sampler="ddim", eta=0.0, seed=107,
+                            text_scale=[2.5, 2.5]),
+    "chain_ddim_eta05": dict(kind="chain", text=True, cfg=True, weight_seed=17, B=2, T=60,
+                             respacing="ddim10", sampler="ddim", eta=0.5, seed=108,
+                             text_scale=[2.5, 2.5]),
+    "chain_skip_init": dict(kind="chain", text=False, cfg=False, weight_seed=14, B=2, T=60,
+                            respacing=[10], sampler="ddpm", seed=109, skip=4, init_image=True),
+}
+# loop counters stored per chain (shorter for the skip case: 6 steps)
+CHAIN_DUMPS = {name: tuple(s for s in DUMP_STEPS if s < 10 - c.get("skip", 0))
+               for name, c in CASES.items() if c["kind"] == "chain"}
+
+
+def sparse_keyframe_mask(lengths, n_frames, trans_length, n_feats=N_FEATS):
+    m = np.zeros((len(lengths), n_feats, 1, n_frames), dtype=bool)
+    for b, length in enumerate(lengths):
+        m[b, :, :, np.arange(0, int(length), trans_length)] = True
+    return m
+
+
+def make_inputs(case: dict) -> dict:
+    rng = np.random.default_rng(case["seed"])
+    B, T = case["B"], case["T"]
+    shape = (B, N_FEATS, 1, T)
+    out = {}
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    if case["kind"] in ("fwd", "vjp"):
+        out["x"] = f32(rng.standard_normal(shape))
+        out["t"] = np.asarray(case["t"], dtype=np.int64)
+        if case["kind"] == "vjp":
+            out["gout"] = f32(rng.standard_normal(shape))
+    else:
+        n_steps = 10 - case.get("skip", 0)
+        out["x_T"] = f32(rng.standard_normal(shape))
+        out["noise"] = f32(rng.standard_normal((n_steps,) + shape))
+        lengths = np.asarray(case.get("lengths", [T] * B), dtype=np.int64)
+        out["lengths"] = lengths
+        out["len_mask"] = (np.arange(T)[None, :] < lengths[:, None]).reshape(B, 1, 1, T)
+        if case.get("edit"):
+            out["x0"] = f32(rng.standard_normal(shape))
+            out["inpaint_mask"] = sparse_keyframe_mask(lengths, T, case["trans_length"])
+        if case.get("init_image"):
+            out["init_image"] = f32(rng.standard_normal(shape))
+    if case["text"]:
+        out["enc_text"] = f32(rng.standard_normal((B, 512)))
+        out["text_scale"] = f32(case.get("text_scale", [2.5] * B))
+    return out
+
+
+def fingerprint(inputs: dict) -> np.ndarray:
+    """CRC32 of every input array, in key order (detects a drifted input generator)."""
+    return np.asarray([zlib.crc32(np.ascontiguousarray(inputs[k]).tobytes()) for k in sorted(inputs)],
+                      dtype=np.int64)

@@ -1,0 +1,150 @@
+"""Pin the numpy oracle against the golden vectors produced by the REAL reference
+(tests/golden/make_golden.py).  CPU only.
+
+Tolerances (fp32, stated per SURVEY.md §8c): one denoiser evaluation max-abs <= 2e-5 /
+rel-L2 <= 5e-6 (numpy BLAS vs torch CPU kernels differ only in summation order); sampler
+arithmetic given identical model output: bit-exact; 10-step chains: rel-L2 <= 2e-5.
+"""
+import numpy as np
+import pytest
+
+from conftest import check_fingerprint, load_golden, max_abs, rel_l2
+from oracle import diffusion_oracle as do
+from oracle import weights
+from oracle.mdm_oracle import MDMOracle
+
+SCHED_ATTRS = {
+    "betas": "betas", "alphas_cumprod": "ab", "alphas_cumprod_prev": "ab_prev",
+    "sqrt_alphas_cumprod": "sqrt_ab", "sqrt_one_minus_alphas_cumprod": "sqrt_1mab",
+    "sqrt_recip_alphas_cumprod": "sqrt_recip_ab", "sqrt_recipm1_alphas_cumprod": "sqrt_recipm1_ab",
+    "posterior_variance": "post_var", "posterior_log_variance_clipped": "post_logvar_clipped",
+    "posterior_mean_coef1": "coef1", "posterior_mean_coef2": "coef2",
+}
+SCHEDULES = {"cos1000": ("cosine", None), "lin1000": ("linear", None),
+             "cos_ddim100": ("cosine", "ddim100"), "cos_10": ("cosine", [10]),
+             "cos_ddim10": ("cosine", "ddim10")}
+
+
+def oracle_schedule(tag):
+    name, resp = SCHEDULES[tag]
+    # the reference ALWAYS goes through SpacedDiffusion (utils/model_util.py:138-141), which
+    # recomputes betas from alpha-bar ratios even when every step is kept
+    use = do.space_timesteps(1000, resp if resp is not None else [1000])
+    return do.Schedule(do.named_betas(name, 1000), use)
+
+
+@pytest.mark.parametrize("tag", list(SCHEDULES))
+def test_schedule_tables_bit_exact(tag):
+    g = load_golden("schedules")
+    sch = oracle_schedule(tag)
+    assert list(g[f"{tag}.timestep_map"]) == list(sch.timestep_map)
+    for ref_name, mine in SCHED_ATTRS.items():
+        assert np.array_equal(g[f"{tag}.{ref_name}"], getattr(sch, mine)), (tag, ref_name)
+
+
+def test_schedule_known_answers():
+    """float64 KATs recorded in SURVEY.md §8c (cosine, T = 1000)."""
+    s = oracle_schedule("cos1000")
+    assert s.betas[0] == pytest.approx(4.128422482197e-05, rel=1e-12)
+    assert s.ab[500] == pytest.approx(4.922851724488e-01, rel=1e-12)
+    assert s.coef1[1] == pytest.approx(5.277814093345e-01, rel=1e-12)
+    assert s.coef2[500] == pytest.approx(9.953562794552e-01, rel=1e-12)
+    assert s.betas[999] == 0.999 and s.betas[998] == pytest.approx(7.499993929011e-01, rel=1e-12)
+    assert s.post_logvar_clipped[0] == pytest.approx(-1.073408253247e+01, rel=1e-12)
+    d = oracle_schedule("cos_ddim100")
+    assert d.timestep_map == list(range(0, 1000, 10))
+    assert d.betas[50] == pytest.approx(3.068714485471e-02, rel=1e-11)
+    assert oracle_schedule("cos_10").timestep_map == [0, 111, 222, 333, 444, 555, 666, 777, 888, 999]
+
+
+@pytest.mark.parametrize("name", [None, 'first-half', 'last-half', 'exponential', 'sigmoid', 'half-sigmoid'])
+def test_gradient_schedules(name):
+    assert np.array_equal(load_golden("schedules")[f"grad_ws.{name}"], do.gradient_schedule(name, 1000))
+
+
+def test_forward_uncond(cases):
+    case = cases.CASES["fwd_uncond"]
+    inp = cases.make_inputs(case)
+    check_fingerprint(cases, "fwd_uncond", inp)
+    m = MDMOracle(weights.make_state_dict(case["weight_seed"], text=False))
+    out = m.forward(inp["x"], inp["t"])
+    ref = load_golden("fwd_uncond")["out"]
+    assert max_abs(out, ref) <= 2e-5 and rel_l2(out, ref) <= 5e-6
+
+
+def test_forward_text_and_cfg(cases):
+    case = cases.CASES["fwd_text"]
+    inp = cases.make_inputs(case)
+    check_fingerprint(cases, "fwd_text", inp)
+    m = MDMOracle(weights.make_state_dict(case["weight_seed"], text=True))
+    g = load_golden("fwd_text")
+    cfg, oc, ou = m.forward_cfg(inp["x"], inp["t"], inp["enc_text"], inp["text_scale"])
+    for mine, key in ((oc, "out_cond"), (ou, "out_uncond"), (cfg, "out_cfg")):
+        assert max_abs(mine, g[key]) <= 5e-5 and rel_l2(mine, g[key]) <= 5e-6, key
+    # CFG combine itself is bit-exact given the reference's two passes
+    s = inp["text_scale"].reshape(-1, 1, 1, 1)
+    assert np.array_equal(g["out_uncond"] + (s * (g["out_cond"] - g["out_uncond"])), g["out_cfg"])
+
+
+def test_vjp_matches_autograd(cases):
+    case = cases.CASES["vjp_text_cfg"]
+    inp = cases.make_inputs(case)
+    check_fingerprint(cases, "vjp_text_cfg", inp)
+    m = MDMOracle(weights.make_state_dict(case["weight_seed"], text=True))
+    g = load_golden("vjp_text_cfg")
+    gx = m.vjp_cfg(inp["x"], inp["t"], inp["gout"], inp["enc_text"], inp["text_scale"])
+    assert rel_l2(gx, g["gx"]) <= 1e-5 and max_abs(gx, g["gx"]) <= 1e-4 * np.abs(g["gx"]).max()
+
+
+def run_chain(cases, name):
+    case = cases.CASES[name]
+    inp = cases.make_inputs(case)
+    check_fingerprint(cases, name, inp)
+    m = MDMOracle(weights.make_state_dict(case["weight_seed"], text=case["text"]))
+    resp = case["respacing"]
+    sch = do.Schedule(do.named_betas("cosine", 1000), do.space_timesteps(1000, resp))
+    x = inp["x_T"]
+    first = sch.n - 1 - case.get("skip", 0)
+    if "init_image" in inp:
+        x = do.q_sample(sch, first, inp["init_image"], x)
+    kw = {}
+    if case.get("edit"):
+        mask = inp["inpaint_mask"] & inp["len_mask"]
+        kw = dict(mask=mask, inpaint=inp["x0"], imputate=case["imputate"],
+                  stop_imputation_at=case["stop_imputation_at"], recon_guidance=case["recon"],
+                  stop_recguidance_at=case["stop_recguidance_at"], recon_weight=case["recon_weight"],
+                  grad_schedule=case["grad_schedule"])
+    final, preds = do.sample_loop(
+        sch, m, x, inp["noise"], sampler=case["sampler"], eta=case.get("eta", 0.0),
+        enc_text=inp.get("enc_text"), text_scale=inp.get("text_scale"), cfg=case["cfg"],
+        first_step=first, collect=True, **kw)
+    return final, preds, load_golden(name)
+
+
+@pytest.mark.parametrize("name", ["chain_uncond_ddpm", "chain_edit_recon", "chain_impute_only",
+                                  "chain_ddim_eta0", "chain_ddim_eta05", "chain_skip_init"])
+def test_chain(cases, name):
+    final, preds, g = run_chain(cases, name)
+    assert rel_l2(final, g["final"]) <= 2e-5, rel_l2(final, g["final"])
+    for k, step in enumerate(cases.CHAIN_DUMPS[name]):
+        assert rel_l2(preds[step], g["pred_xstart"][k]) <= 2e-5, (step, rel_l2(preds[step], g["pred_xstart"][k]))
+
+
+def test_philox_known_answers():
+    """Random123 kat_vectors for philox4x32 with 10 rounds."""
+    kat = [
+        ([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+        ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+        ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]),
+    ]
+    for ctr, key, want in kat:
+        assert list(do.philox4x32_10(ctr, key)) == want
+
+
+def test_engine_randn_is_standard_normal():
+    z = do.engine_randn(4, 263 * 196, seed=1234)
+    assert abs(float(z.mean())) < 0.01 and abs(float(z.std()) - 1.0) < 0.01
+    # keyed by global sample index: a shard reproduces its slice of the full batch
+    part = do.engine_randn(2, 263 * 196, seed=1234, first_sample=2)
+    assert np.array_equal(part, z[2:])
