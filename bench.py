@@ -1,0 +1,224 @@
+"""Throughput of the CondMDI sampling hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4] [--no-cpu]
+
+Workload (BASELINE.json configs[1], "c2"): HumanML3D shape B=32 x 263 feats x 196 frames per GPU,
+1000-step DDPM chain, text-conditioned classifier-free guidance (2 denoiser passes per step),
+random-init MDM trans_enc (8 layers, d=512, ff=1024, 4 heads), synthetic z-scored inputs, fp32.
+One "step" = one denoising step x_t -> x_{t-1} of the whole per-GPU batch (both CFG passes, the
+sampler update and the per-step Philox noise); the K timed steps are the LAST K steps of the chain
+entered at step K-1 (t = K-1 .. 0), bracketed by barrier + torch.cuda.synchronize on both sides;
+the maximum over ranks is the time.  value = N * K / time (weak scaling: every rank runs its own
+B=32 slice; no collective inside the loop, one RCCL all-gather of the samples afterwards).
+
+Prints ONE JSON line on rank 0 (see the task contract) with two extra objects:
+  roofline      the dominant kernel = the self-attention in_proj GEMM (fp32 MFMA), timed with HIP
+                events on its own stream inside a second, instrumented pass over the same K steps
+  cpu_baseline  the numpy oracle (a port of the reference's CPU path) on the host cores, a bounded
+                sample of the same workload (1 warm-up + a few full CFG steps at B=32)
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+from pathlib import Path
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+PKG = "diffusion-motion-inbetweening_amd"
+sub = lambda n: importlib.import_module(f"{PKG}.{n}")
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+N_FEATS, T_FRAMES = 263, 196
+CONFIGS = {
+    # name: (batch per GPU, respacing, sampler, cfg, edit)
+    "c2": dict(B=32, respacing=[1000], sampler="ddpm", cfg=True, edit=False,
+               desc="HumanML3D 196x263, 1000-step DDPM, B=32/GPU, text CFG"),
+    "c3": dict(B=32, respacing=[1000], sampler="ddpm", cfg=True, edit=True,
+               desc="benchmark_sparse imputation + reconstruction guidance, 1000-step DDPM, B=32/GPU, CFG"),
+    "c4": dict(B=256, respacing="ddim100", sampler="ddim", cfg=True, edit=False,
+               desc="DDIM-100 respaced, B=256/GPU, text CFG"),
+}
+
+
+def flops_per_sample_eval(T=T_FRAMES, J=N_FEATS, d=512, f=1024, L=8):
+    S = T + 1
+    layer = 2 * S * d * 3 * d + 4 * S * S * d + 2 * S * d * d + 4 * S * d * f
+    return 2 * T * J * d + L * layer + 2 * T * d * J + 4 * d * d + 2 * 512 * d
+
+
+def build_model(cfg_on, dev, seed=0):
+    from oracle import weights  # synthetic weights recipe only (no oracle compute)
+    mu = sub("utils.model_util")
+    model, _ = mu.create_model_and_diffusion(SimpleNamespace(dataset="humanml"), None)
+    sd = weights.make_state_dict(seed, text=True)
+    mu.load_model_wo_clip(model, weights.to_torch(sd))
+    model.to(dev).eval()
+    return model, sd
+
+
+def cpu_baseline(sd, B, n_steps=3):
+    """numpy port of the reference CPU path: full CFG denoising steps at the bench shape."""
+    from oracle import diffusion_oracle as do
+    from oracle.mdm_oracle import MDMOracle
+    rng = np.random.default_rng(1)
+    m = MDMOracle(sd)
+    sch = do.Schedule(do.named_betas("cosine", 1000), do.space_timesteps(1000, [1000]))
+    x = rng.standard_normal((B, N_FEATS, 1, T_FRAMES)).astype(np.float32)
+    enc = rng.standard_normal((B, 512)).astype(np.float32)
+    scale = np.full((B,), 2.5, dtype=np.float32)
+    nz = rng.standard_normal((n_steps + 1,) + x.shape).astype(np.float32)
+
+    def one(i, k):
+        t = np.full((B,), i, dtype=np.int64)
+        hat, _, _ = m.forward_cfg(x, t, enc, scale)
+        return do.step_update(sch, i, x, hat, nz[k])[0]
+
+    one(999, 0)  # warm-up
+    t0 = time.perf_counter()
+    for k in range(n_steps):
+        one(998 - k, k + 1)
+    dt = time.perf_counter() - t0
+    cores = os.cpu_count() or 1
+    return {"value": n_steps / dt, "unit": "denoising steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n_steps} full CFG DDPM steps at B={B}x{T_FRAMES}x{N_FEATS} after 1 warm-up "
+                      f"(oracle/ numpy fp32, BLAS threads = host cores)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path exists)"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        dist.init_process_group("nccl", init_method="env://", device_id=dev)
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+
+    B, K, W = cfg["B"], args.steps, args.warmup
+    gd, rs, du = sub("diffusion.gaussian_diffusion"), sub("diffusion.respace"), sub("utils.dist_util")
+    N = sub("_native")
+    model, sd = build_model(cfg["cfg"], dev)
+    diffusion = rs.SpacedDiffusion(rs.space_timesteps(1000, cfg["respacing"]),
+                                   gd.DiffusionConfig(betas=gd.get_named_beta_schedule("cosine", 1000)))
+    n_chain = diffusion.num_timesteps
+    assert K + W <= n_chain, f"steps + warmup must be <= {n_chain}"
+    eng = model.engine(dev, max_batch=B, max_frames=T_FRAMES, want_grad=cfg["edit"])
+    eng.set_schedule(diffusion.engine_tables(), key="bench")
+
+    # synthetic per-rank inputs keyed by GLOBAL sample index (rank r owns samples [r*B, (r+1)*B))
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    enc = torch.randn(B, 512, generator=g).to(dev)
+    scale = torch.full((B,), 2.5, device=dev)
+    cond = dict(batch=B, n_frames=T_FRAMES, cfg=cfg["cfg"], enc_text=enc, text_scale=scale)
+    if cfg["edit"]:
+        x0 = torch.randn(B, N_FEATS, 1, T_FRAMES, generator=g).to(dev)
+        mask = torch.zeros(B, N_FEATS, 1, T_FRAMES, dtype=torch.bool)
+        mask[..., ::5] = True  # benchmark_sparse, trans_length=5, all features (pos_rot_vel)
+        cond.update(inpaint_mask=mask.to(dev), inpaint_motion=x0, imputate=True, stop_imputation_at=1,
+                    recon_guidance=True, stop_recguidance_at=0,
+                    recon_w=np.full((n_chain,), 20.0, dtype=np.float32))
+    eng.set_condition(**cond)
+    sampler = N.CMDI_SAMPLER_DDIM if cfg["sampler"] == "ddim" else N.CMDI_SAMPLER_DDPM
+    seed, first = 20260925, rank * B
+    x = eng.randn((B, N_FEATS, 1, T_FRAMES), seed=seed, first_sample=first)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # warm-up: W steps from the top of the chain (untimed)
+    if W > 0:
+        eng.sample_loop(x, n_chain - 1, n_chain - W, sampler=sampler, seed=seed, first_sample=first)
+    barrier()
+    t0 = time.perf_counter()
+    eng.sample_loop(x, K - 1, 0, sampler=sampler, seed=seed, first_sample=first)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    assert torch.isfinite(x).all(), "non-finite samples"
+
+    # the path's only collective: reassemble the generated sequences (outside the timed steps)
+    t1 = time.perf_counter()
+    full = du.all_gather_batch(x, world * B)
+    torch.cuda.synchronize(dev)
+    gather_ms = (time.perf_counter() - t1) * 1e3
+    assert full.shape[0] == world * B
+
+    steps_per_s = world * K / elapsed
+    passes = 2 if cfg["cfg"] else 1
+    flop_step = B * passes * flops_per_sample_eval() * (30.68 / 14.706 if cfg["edit"] else 1.0)
+    out = {
+        "metric": "diffusion denoising steps/sec", "value": steps_per_s, "unit": "steps/s",
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic (random-init MDM weights, z-scored N(0,1) motions, fake CLIP embeddings)",
+        "config": {"workload": cfg["desc"], "batch_per_gpu": B, "global_batch": world * B,
+                   "n_frames": T_FRAMES, "n_feats": N_FEATS, "chain_steps": n_chain,
+                   "parallelism": f"batch-sharded x{world}"},
+        "motions_per_sec": world * B / (n_chain * elapsed / K),
+        "step_tflops": flop_step / (elapsed / K) / 1e12,
+        "step_frac_of_fp32_mfma_peak": flop_step / (elapsed / K) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+        "allgather_ms": gather_ms,
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # instrumented second pass over the same K steps: HIP events around every in_proj GEMM
+        eng.profile_enable(True)
+        eng.sample_loop(x, K - 1, 0, sampler=sampler, seed=seed, first_sample=first)
+        torch.cuda.synchronize(dev)
+        ms, launches, (m, n, k) = eng.profile_read()
+        eng.profile_enable(False)
+        avg_s = ms / max(launches, 1) * 1e-3
+        flop_launch = 2.0 * m * n * k
+        traffic = None
+        pmc = REPO / "profiles" / "pmc_inproj_gemm.json"
+        if pmc.exists():
+            traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
+        out["roofline"] = {
+            "kernel": f"gemm_nt_kernel (self_attn.in_proj, M={m} N={n} K={k}, fp32 MFMA 32x32x2)",
+            "bound": "mfma", "achieved": flop_launch / avg_s / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": flop_launch / avg_s / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+            "traffic": traffic, "launches": launches, "avg_launch_us": avg_s * 1e6,
+            "flops_per_launch": flop_launch,
+        }
+    if world > 1:
+        dist.barrier()
+    if rank == 0 and world == 1 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(sd, B)
+        out["gpu_over_cpu"] = steps_per_s / out["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -69,6 +69,9 @@ SIGNATURES = {
     "cmdi_gemm_nt": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP]),
     "cmdi_philox4x32_10": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "cmdi_workspace_bytes": (_I64, [_VP]),
+    "cmdi_profile_enable": (C.c_int, [_VP, _I32]),
+    "cmdi_profile_read": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(_I64), C.POINTER(_I32),
+                                    C.POINTER(_I32), C.POINTER(_I32)]),
 }
 
 _lib = None

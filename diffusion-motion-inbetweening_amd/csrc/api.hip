@@ -82,6 +82,12 @@ struct cmdi_engine {
     float *dA = nullptr, *dB = nullptr, *dH = nullptr, *dqkv = nullptr, *dffn = nullptr,
           *drowdot = nullptr, *gout = nullptr, *gx = nullptr;
     int gemm_tile = 0;
+
+    // optional live timing of the in_proj GEMM (bench.py roofline leg)
+    bool profile = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    int prof_m = 0, prof_n = 0, prof_k = 0;
 };
 
 namespace {
@@ -137,7 +143,22 @@ int mdm_forward(cmdi_engine* e, const float* x, const int64_t* t_dev, int64_t t_
         float* pre1 = keep ? e->stash[l].pre1 : e->tokB;
         float* pre2 = keep ? e->stash[l].pre2 : e->tokB;
         // self-attention block: x = norm1(x + out_proj(MHA(x)))
+        if (e->profile) {
+            if (e->ev_used + 2 > e->ev_pool.size()) {
+                hipEvent_t a, b;
+                HIPCHK(hipEventCreate(&a));
+                HIPCHK(hipEventCreate(&b));
+                e->ev_pool.push_back(a);
+                e->ev_pool.push_back(b);
+            }
+            HIPCHK(hipEventRecord(e->ev_pool[e->ev_used], s));
+        }
         HIPCHK(launch_gemm(GK_PLAIN, gp(e->tokA, w.in_w, w.in_b, qkv, M, 3 * d, d, d, d, 3 * d), tile, s));
+        if (e->profile) {
+            HIPCHK(hipEventRecord(e->ev_pool[e->ev_used + 1], s));
+            e->ev_used += 2;
+            e->prof_m = M; e->prof_n = 3 * d; e->prof_k = d;
+        }
         HIPCHK(launch_attention_fwd(qkv, attn, keep ? e->stash[l].row_stats : nullptr, n_seq, S, e->H, s));
         {
             GemmParams p = gp(attn, w.out_w, w.out_b, pre1, M, d, d, d, d, d);
@@ -358,8 +379,35 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
     return CMDI_OK;
 }
 
+int cmdi_profile_enable(cmdi_handle e, int32_t on) {
+    if (!e) return fail(CMDI_E_INVALID, "null handle");
+    e->profile = on != 0;
+    e->ev_used = 0;
+    return CMDI_OK;
+}
+
+int cmdi_profile_read(cmdi_handle e, double* total_ms, int64_t* launches, int32_t* m, int32_t* n,
+                      int32_t* k) {
+    if (!e || !total_ms || !launches) return fail(CMDI_E_INVALID, "null argument");
+    double sum = 0.0;
+    for (size_t i = 0; i + 1 < e->ev_used; i += 2) {
+        HIPCHK(hipEventSynchronize(e->ev_pool[i + 1]));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e->ev_pool[i], e->ev_pool[i + 1]));
+        sum += ms;
+    }
+    *total_ms = sum;
+    *launches = (int64_t)(e->ev_used / 2);
+    if (m) *m = e->prof_m;
+    if (n) *n = e->prof_n;
+    if (k) *k = e->prof_k;
+    e->ev_used = 0;
+    return CMDI_OK;
+}
+
 int cmdi_destroy(cmdi_handle h) {
     if (!h) return CMDI_OK;
+    for (hipEvent_t ev : h->ev_pool) (void)hipEventDestroy(ev);
     for (void* p : h->allocs) (void)hipFree(p);
     delete h;
     return CMDI_OK;
@@ -482,7 +530,7 @@ int cmdi_set_condition(cmdi_handle e, const cmdi_condition* c, cmdi_stream strea
     if (c->cfg && !c->d_text_scale) return fail(CMDI_E_INVALID, "cfg needs text_scale");
     if ((c->imputate || c->recon_guidance) && (!c->d_inpaint_mask || !c->d_inpaint_motion))
         return fail(CMDI_E_INVALID, "imputation / reconstruction guidance need inpainting_mask and inpainted_motion");
-    if (c->recon_guidance && !e->desc.want_grad)
+    if (c->recon_guidance && e->L > 0 && !e->desc.want_grad)
         return fail(CMDI_E_STATE, "reconstruction guidance needs an engine created with want_grad=1");
     if (c->recon_guidance && !c->recon_w) return fail(CMDI_E_INVALID, "reconstruction guidance needs recon_w");
     const int B = c->batch, T = c->n_frames, d = e->d;

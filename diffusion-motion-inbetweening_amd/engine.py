@@ -79,6 +79,17 @@ class Engine:
     def workspace_bytes(self) -> int:
         return int(self.lib.cmdi_workspace_bytes(self._h))
 
+    def profile_enable(self, on: bool):
+        N.check(self.lib.cmdi_profile_enable(self._h, int(on)))
+
+    def profile_read(self):
+        """(total_ms, launches, (M, N, K)) of the in_proj GEMM launches recorded since enable."""
+        ms, cnt = C.c_double(), C.c_int64()
+        m, n, k = C.c_int32(), C.c_int32(), C.c_int32()
+        N.check(self.lib.cmdi_profile_read(self._h, C.byref(ms), C.byref(cnt), C.byref(m),
+                                           C.byref(n), C.byref(k)))
+        return ms.value, cnt.value, (m.value, n.value, k.value)
+
     # -- weights --------------------------------------------------------------------------------
     def load_state_dict(self, state_dict, n_time_rows: int = 1000):
         """Ingest the reference's MDM state dict (SURVEY.md §5.4 key names)."""

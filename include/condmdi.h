@@ -179,6 +179,13 @@ int cmdi_gemm_nt(const float* d_a, const float* d_w, const float* d_bias, float*
                  int32_t n, int32_t k, int32_t tile, cmdi_stream stream);
 /* Philox4x32-10 raw block (host, for known-answer tests): out[4] = philox(counter[4], key[2]). */
 void cmdi_philox4x32_10(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]);
+/* Live timing of the dominant kernel (the self-attention in_proj GEMM, one launch per layer):
+ * while enabled, every such launch is bracketed by a pair of HIP events on its own stream.
+ * cmdi_profile_read waits for the recorded events and returns their summed duration and count,
+ * then clears them.  Used by bench.py's roofline leg; off by default (no events, no overhead). */
+int cmdi_profile_enable(cmdi_handle h, int32_t on);
+int cmdi_profile_read(cmdi_handle h, double* total_ms, int64_t* launches, int32_t* m, int32_t* n,
+                      int32_t* k);
 /* Bytes of device memory held by the handle. */
 int64_t cmdi_workspace_bytes(cmdi_handle h);
 
