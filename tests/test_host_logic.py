@@ -1,0 +1,163 @@
+"""CPU-only tests of the host side: the C-ABI library loads and exports every symbol the header
+declares, schedule tables of the product's GaussianDiffusion/SpacedDiffusion equal the reference's
+golden tables bit-for-bit, respacing / guidance schedules / keyframe masks / conditioning hand-off,
+and the failure mode on a machine without a GPU (loud error, never a CPU fallback)."""
+import ctypes
+import re
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, load_golden, sub
+
+SCHED_ATTRS = ["betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod",
+               "sqrt_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod",
+               "sqrt_recipm1_alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped",
+               "posterior_mean_coef1", "posterior_mean_coef2"]
+SCHEDULES = {"cos1000": ("cosine", [1000]), "lin1000": ("linear", [1000]),
+             "cos_ddim100": ("cosine", "ddim100"), "cos_10": ("cosine", [10]),
+             "cos_ddim10": ("cosine", "ddim10")}
+
+
+def make_diffusion(name, resp):
+    gd, rs = sub("diffusion.gaussian_diffusion"), sub("diffusion.respace")
+    return rs.SpacedDiffusion(rs.space_timesteps(1000, resp),
+                              gd.DiffusionConfig(betas=gd.get_named_beta_schedule(name, 1000)))
+
+
+def test_library_exports_every_header_symbol(condmdi):
+    header = (REPO / "include" / "condmdi.h").read_text()
+    declared = set(re.findall(r"\b(cmdi_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 18
+    lib = condmdi._native.load()
+    raw = ctypes.CDLL(str(condmdi._native.LIB_PATH))
+    for name in sorted(declared):
+        assert hasattr(raw, name), f"{name} declared in include/condmdi.h but not exported"
+    assert declared == set(condmdi._native.SIGNATURES), \
+        declared.symmetric_difference(condmdi._native.SIGNATURES)
+    assert b"gfx950" in lib.cmdi_version()
+
+
+def test_host_philox_entry_point_known_answers():
+    philox = sub("engine").philox4x32_10
+    assert philox([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+@pytest.mark.parametrize("tag", list(SCHEDULES))
+def test_product_schedule_tables_match_reference(tag):
+    g = load_golden("schedules")
+    d = make_diffusion(*SCHEDULES[tag])
+    assert list(g[f"{tag}.timestep_map"]) == list(d.timestep_map)
+    for attr in SCHED_ATTRS:
+        assert np.array_equal(g[f"{tag}.{attr}"], getattr(d, attr)), (tag, attr)
+    t = d.engine_tables()
+    assert t["n_steps"] == d.num_timesteps and t["sigma"].dtype == np.float32
+    assert np.array_equal(t["post_coef1"], g[f"{tag}.posterior_mean_coef1"].astype(np.float32))
+    assert np.array_equal(
+        t["sigma"], np.exp(np.float32(0.5) * g[f"{tag}.posterior_log_variance_clipped"].astype(np.float32)))
+
+
+def test_space_timesteps_edge_cases():
+    st = sub("diffusion.respace").space_timesteps
+    assert st(1000, "ddim100") == set(range(0, 1000, 10))
+    assert st(1000, [10]) == {0, 111, 222, 333, 444, 555, 666, 777, 888, 999}
+    assert st(300, [10, 15, 20]) == st(300, "10,15,20") and len(st(300, "10,15,20")) == 45
+    assert st(10, [1]) == {0}
+    with pytest.raises(ValueError):
+        st(1000, "ddim999")    # no integer stride gives exactly 999 steps
+    with pytest.raises(ValueError):
+        st(10, [20])           # section smaller than the requested count
+
+
+@pytest.mark.parametrize("name", [None, 'first-half', 'last-half', 'exponential', 'sigmoid', 'half-sigmoid'])
+def test_gradient_schedule(name):
+    eu = sub("utils.editing_util")
+    assert np.array_equal(load_golden("schedules")[f"grad_ws.{name}"],
+                          eu.get_gradient_schedule(name, num_diffusion_steps=1000))
+    with pytest.raises(NotImplementedError):
+        eu.get_gradient_schedule("nope")
+
+
+def test_joint_to_full_mask_and_gates(cases):
+    eu = sub("utils.editing_util")
+    jm = torch.zeros(2, 22, 1, 8, dtype=torch.bool)
+    jm[0, :, :, ::5] = True
+    full = eu.joint_to_full_mask(jm, mode='pos_rot_vel')
+    assert full.shape == (2, 263, 1, 8)
+    assert np.array_equal(full.numpy()[:1], cases.sparse_keyframe_mask([8], 8, 5))
+    assert not full[1].any()
+    pos_only = eu.joint_to_full_mask(jm, mode='pos')
+    assert int(pos_only[0, :, 0, 0].sum()) == 3 + 21 * 3 + 4     # root xyz-ish + ric + contacts
+    y = dict(imputate=True, stop_imputation_at=3, inpainting_mask=1, inpainted_motion=1,
+             reconstruction_guidance=False)
+    assert eu.requires_imputation({'y': y}, torch.tensor([3, 3]))
+    assert not eu.requires_imputation({'y': y}, torch.tensor([2, 2]))
+    assert not eu.requires_reconstruction_guidance({'y': y}, torch.tensor([999]))
+    assert not eu.requires_imputation({'y': {}}, 5)
+
+
+def test_model_factory_state_dict_names_match_reference():
+    """create_model_and_diffusion keeps the reference's parameter names / shapes."""
+    from oracle import weights
+    mu = sub("utils.model_util")
+    model, diffusion = mu.create_model_and_diffusion(SimpleNamespace(dataset="humanml"), None)
+    assert diffusion.num_timesteps == 1000 and type(diffusion).__name__ == "SpacedDiffusion"
+    want = weights.make_state_dict(0, text=True)
+    have = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert have == {k: tuple(v.shape) for k, v in want.items()}
+    assert sum(p.numel() for p in model.parameters()) == 17_880_327
+    mu.load_model_wo_clip(model, weights.to_torch(want))
+    assert model.cond_mode == 'text' and model.keyframe_conditioned is False
+    cfg = sub("model.cfg_sampler").ClassifierFreeSampleModel(model)
+    assert cfg.njoints == 263 and cfg.nfeats == 1 and cfg.data_rep == 'hml_vec'
+    assert model.rot2xyz(x=torch.ones(1), mask=None, pose_rep='xyz') is not None
+    unc, d2 = mu.create_model_and_diffusion(SimpleNamespace(dataset="humanml", unconstrained=True,
+                                                            use_ddim=True), None)
+    assert unc.cond_mode == 'no_cond' and d2.num_timesteps == 100
+    with pytest.raises(AssertionError):
+        sub("model.cfg_sampler").ClassifierFreeSampleModel(SimpleNamespace(cond_mask_prob=0.0))
+    with pytest.raises(NotImplementedError):
+        mu.create_model_and_diffusion(SimpleNamespace(dataset="humanml", arch="unet"), None)
+
+
+def test_no_cpu_fallback():
+    """Without a HIP device every product entry point fails loudly."""
+    if torch.cuda.is_available():
+        pytest.skip("has a GPU")
+    N = sub("_native")
+    mu = sub("utils.model_util")
+    model, diffusion = mu.create_model_and_diffusion(
+        SimpleNamespace(dataset="humanml", unconstrained=True, layers=1), None)
+    model.eval()
+    x = torch.zeros(1, 263, 1, 8)
+    with pytest.raises(N.NativeError):
+        model(x, torch.zeros(1, dtype=torch.long), y={})
+    with pytest.raises(N.NativeError):
+        diffusion.p_sample_loop(model, (1, 263, 1, 8), model_kwargs={'y': {}})
+    with pytest.raises(N.NativeError):
+        sub("engine").Engine(n_layers=0, d_model=0, d_ff=0, n_heads=0, n_feats=263, max_frames=8,
+                             max_batch=1, device="cpu")
+    with pytest.raises(KeyError):
+        diffusion.p_sample_loop(model, (1, 263, 1, 8), model_kwargs={})
+
+
+def test_compat_aliases_resolve_reference_import_names():
+    import subprocess
+    import sys
+    code = (
+        "import importlib, sys; sys.path.insert(0, %r);"
+        "c = importlib.import_module('diffusion-motion-inbetweening_amd.compat');"
+        "c.install_reference_aliases();"
+        "from utils.model_util import create_model_and_diffusion, load_saved_model;"
+        "from model.cfg_sampler import ClassifierFreeSampleModel;"
+        "from diffusion.respace import SpacedDiffusion, space_timesteps;"
+        "from diffusion.gaussian_diffusion import ModelMeanType, DiffusionConfig;"
+        "from utils.fixseed import fixseed; from utils import dist_util;"
+        "print(SpacedDiffusion.__module__)" % str(REPO))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip().endswith("diffusion.respace")
