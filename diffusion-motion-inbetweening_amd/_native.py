@@ -66,7 +66,8 @@ SIGNATURES = {
     "cmdi_sampler_update": (C.c_int, [_VP, _I32, _I32, _F, _VP, _VP, _VP, _VP, _VP, _U64, _I64, _VP]),
     "cmdi_q_sample": (C.c_int, [_VP, _I32, _VP, _VP, _VP, _I64, _VP]),
     "cmdi_randn": (C.c_int, [_VP, _VP, _I32, _I64, _U64, _I64, _I32, _VP]),
-    "cmdi_gemm_nt": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP]),
+    "cmdi_gemm_nt": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _VP]),
+    "cmdi_attention_fwd": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _VP]),
     "cmdi_philox4x32_10": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "cmdi_workspace_bytes": (_I64, [_VP]),
     "cmdi_profile_enable": (C.c_int, [_VP, _I32]),

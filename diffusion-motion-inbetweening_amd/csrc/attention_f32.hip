@@ -1,185 +1,223 @@
 // Self-attention of one TransformerEncoderLayer (torch MultiheadAttention called from
 // model/mdm.py:284 via nn.TransformerEncoder; math in SURVEY.md Appendix A.2):
 //   P = softmax_row(Q_h K_hᵀ / sqrt(128)) over all S = T+1 tokens (no mask), A = concat_h(P V_h)
-// fp32 on v_mfma_f32_32x32x2_f32, d_head = 128, S <= 224.
+// fp32 on v_mfma_f32_16x16x4_f32, d_head = 128, S <= 224.
 //
-// Work split: grid = (B'·H, ceil(S/128)); 4 waves per block, each wave owns 32 queries.  All S
-// keys fit one pass, so the softmax is the plain two-pass form (no online rescale):
-//   phase 1: Sᵀ tile = K_tile · Qᵀ (swapped operands, so a lane's 16 accumulators of each tile are
-//            16 KEYS of ONE query -> the row max / row sum are in-lane plus one lane^32 exchange);
-//   phase 2: p = exp(s - max) / sum, kept in the same registers;
-//   phase 3: O += P · V_tile with P's accumulator registers used directly as the MFMA A operand
-//            (A[i=query][k=hi] is exactly what lane (query, hi) holds in register r).
-// K / V tiles (32 keys x 128 dims) are staged through double-buffered LDS by all 4 waves.
+// Work split: grid = (B'·H, ceil(ceil(S/16)/8)); 8 waves per block, each wave owns 16 queries (S =
+// 197 -> 13 query blocks, 13 key sub-tiles: 5 % padding instead of the 29 % a 32-row MFMA costs).
+// K / V stream through LDS in 32-key stages (LDS-DMA, double buffered); per 16-key sub-tile a wave
+// computes
+//   Sᵀ = K_sub · Qᵀ      operands swapped, so a lane's accumulators are 4 KEYS of ONE query:
+//                        row max / sum are in-lane + two lane-xor exchanges (lanes l, l^16, l^32)
+//   online softmax       running max m and partial sum l per query = per lane (scalars)
+//   Oᵀ += V_subᵀ · Pᵀ    Pᵀ's accumulator registers ARE the MFMA B operand (B[k=g][n=q] is what
+//                        lane (q, g) holds in register r), V comes from LDS as the A operand; Oᵀ
+//                        keeps queries on lanes, so the online rescale is a lane-wise multiply.
 #include "common.hpp"
 #include "kernels.hpp"
 
 namespace cmdi {
 
-constexpr int DH = 128;          // head dim
-constexpr int KT = 32;           // keys per tile
-constexpr int KLD = DH + 4;      // LDS row stride (floats): 528 B = 33 slots of 16 B (odd) -> the
-                                 // 16 rows of a ds_read_b128 lane group hit 16 distinct slots
-constexpr int MAX_KT = 7;        // up to 224 keys
+namespace {
+constexpr int DH = 128;     // head dim
+constexpr int STG = 32;     // keys per LDS stage
+constexpr int NWAVE = 8;
 
-__device__ __forceinline__ void stage_tile(float* lds, const float* __restrict__ src, int row_ld,
-                                           int key0, int S, int tid) {
-    // 32 keys x 128 dims = 1024 float4, 4 per thread; rows past S are zero-filled
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int idx = tid + i * 256;
-        const int r = idx >> 5, c4 = idx & 31;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (key0 + r < S) v = *reinterpret_cast<const float4*>(src + (size_t)(key0 + r) * row_ld + c4 * 4);
-        *reinterpret_cast<float4*>(&lds[r * KLD + c4 * 4]) = v;
-    }
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4v mfma16(float a, float b, f32x4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// One 32-key x 128-dim tile of K and one of V per stage, by LDS-DMA (global_load_lds_dwordx4).  A
+// wave-instruction fills 1 KiB = 2 rows and the image is lane-linear, so bank conflicts are
+// removed differently for the two tiles:
+//   K (read as ds_read_b128, 16 key rows x one 16-B chunk per lane group): XOR swizzle on the
+//     SOURCE address — chunk c of row r lands at chunk position c ^ (r & 15);
+//   V (read as ds_read_b32, rows k and k+4 per 32-lane group, 16 consecutive dims each): the row
+//     PAIRS are placed 1024 + 32 B apart, which shifts row k+4 by 16 banks against row k and keeps
+//     every address linear in the dim (immediate offsets, no per-read address arithmetic).
+// Rows past S re-read row S-1 (their scores are masked, their P is exactly 0; values stay finite).
+constexpr int VPAIR = 264;                  // floats between consecutive V row pairs (1056 B)
+constexpr int KTILE = STG * DH;             // 4096 floats
+constexpr int VTILE = (STG / 2) * VPAIR;    // 4224 floats
+constexpr int STAGE_FLOATS = KTILE + VTILE;
+
+__device__ __forceinline__ void stage_kv(float* kbuf, float* vbuf, const float* __restrict__ kbase,
+                                         const float* __restrict__ vbase, int row_ld, int key0, int S,
+                                         int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int g = (i & 1) * NWAVE + wave;       // 0..15: pair of rows inside the tile
+        const int r = g * 2 + (lane >> 5);
+        const int c = i < 2 ? ((lane & 31) ^ (r & 15)) : (lane & 31);
+        int key = key0 + r;
+        key = key < S ? key : S - 1;
+        const float* gp = (i < 2 ? kbase : vbase) + (size_t)key * row_ld + c * 4;
+        float* dst = i < 2 ? kbuf + g * 256 : vbuf + g * VPAIR;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+}
+}  // namespace
+
 template <bool STASH>
-__global__ __launch_bounds__(256) void attention_fwd_kernel(const float* __restrict__ qkv,
+__global__ __launch_bounds__(512, 4) void attention_fwd_kernel(const float* __restrict__ qkv,
                                                             float* __restrict__ out,
                                                             float* __restrict__ row_stats, int S,
                                                             int H, float scale) {
-    __shared__ __attribute__((aligned(16))) float kv[2][KT * KLD];
+    extern __shared__ __attribute__((aligned(16))) float kv[];  // [buffer][K tile | V tile]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, hi = lane >> 5;
+    const int l15 = lane & 15, g = lane >> 4;
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
     const int d_model = H * DH, ld = 3 * d_model;
-    const int q0 = blockIdx.y * 128 + wave * 32;
+    const int q0 = (blockIdx.y * NWAVE + wave) * 16;
     const bool active = q0 < S;  // wave-uniform
-    const int nkt = (S + KT - 1) / KT;
+    const int nstage = (S + STG - 1) / STG;
 
     const float* qbase = qkv + (size_t)b * S * ld + h * DH;
     const float* kbase = qbase + d_model;
     const float* vbase = qbase + 2 * d_model;
 
-    // Q fragment as MFMA B operand: lane (query=l31, hi) holds Q[q][c*8 + 4*hi + j], pre-scaled.
-    float4 qf[16];
-    {
-        const int q = q0 + l31;
-        const bool ok = active && q < S;
+    // Q as MFMA B operand: lane (query = l15, g) holds Q[q][16c + 4g + j], j = 0..3 — MFMA number
+    // 4c + j of a sub-tile contracts dims {16c + 4g' + j : g' = 0..3} (a permutation of k, shared
+    // with the K reads below).
+    const int q = q0 + l15;
+    const bool qok = active && q < S;
+    float4 qf[8];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) v = *reinterpret_cast<const float4*>(qbase + (size_t)q * ld + c * 8 + hi * 4);
-            qf[c] = make_float4(v.x * scale, v.y * scale, v.z * scale, v.w * scale);
-        }
+    for (int c = 0; c < 8; ++c) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (qok) v = *reinterpret_cast<const float4*>(qbase + (size_t)q * ld + c * 16 + g * 4);
+        qf[c] = make_float4(v.x * scale, v.y * scale, v.z * scale, v.w * scale);
     }
 
-    // ---- phase 1: scores -------------------------------------------------------------------
-    f32x16 s[MAX_KT];
+    f32x4v o[8];  // Oᵀ: o[db][reg] = O[q][16 db + 4 g + reg]
 #pragma unroll
-    for (int t = 0; t < MAX_KT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+    for (int db = 0; db < 8; ++db) o[db] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
 
-    stage_tile(kv[0], kbase, ld, 0, S, tid);
+    stage_kv(kv, kv + KTILE, kbase, vbase, ld, 0, S, wave, lane);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's DMA pieces have landed
     __syncthreads();
+
+    for (int st = 0; st < nstage; ++st) {
+        const int cur = st & 1;
+        if (st + 1 < nstage)
+            stage_kv(kv + (cur ^ 1) * STAGE_FLOATS, kv + (cur ^ 1) * STAGE_FLOATS + KTILE, kbase, vbase,
+                     ld, (st + 1) * STG, S, wave, lane);
+        if (active) {
+            const float* kt = kv + cur * STAGE_FLOATS;
+            const float* vt = kt + KTILE;
+            const int nsub = (S - st * STG) > 16 ? 2 : 1;  // sub-tiles with at least one valid key
+            // one 16-key sub-tile at a time (not unrolled: keeps the live set near
+            // qf + o + one score fragment, so two blocks = 4 waves per SIMD fit the register file)
+#pragma unroll 1
+            for (int j = 0; j < nsub; ++j) {
+                // ---- scores --------------------------------------------------------------
+                const int krow = j * 16 + l15;  // this lane's key row (A operand row)
+                const float* kr = kt + krow * DH;
+                // two accumulator chains: a dependent 16x16x4 MFMA has 40-cycle latency
+                f32x4v a0 = (f32x4v){0.f, 0.f, 0.f, 0.f}, a1 = a0;
 #pragma unroll
-    for (int t = 0; t < MAX_KT; ++t) {
-        if (t < nkt) {
-            if (t + 1 < nkt) stage_tile(kv[(t + 1) & 1], kbase, ld, (t + 1) * KT, S, tid);
-            if (active) {
-                const float* kb = kv[t & 1] + l31 * KLD + hi * 4;
+                for (int c = 0; c < 8; c += 2) {
+                    const float4 k0 =
+                        *reinterpret_cast<const float4*>(kr + (((4 * c + g) ^ (krow & 15)) << 2));
+                    const float4 k1 =
+                        *reinterpret_cast<const float4*>(kr + (((4 * c + 4 + g) ^ (krow & 15)) << 2));
+                    a0 = mfma16(k0.x, qf[c].x, a0);
+                    a1 = mfma16(k1.x, qf[c + 1].x, a1);
+                    a0 = mfma16(k0.y, qf[c].y, a0);
+                    a1 = mfma16(k1.y, qf[c + 1].y, a1);
+                    a0 = mfma16(k0.z, qf[c].z, a0);
+                    a1 = mfma16(k1.z, qf[c + 1].z, a1);
+                    a0 = mfma16(k0.w, qf[c].w, a0);
+                    a1 = mfma16(k1.w, qf[c + 1].w, a1);
+                }
+                f32x4v s;
 #pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    const float4 a = *reinterpret_cast<const float4*>(kb + c * 8);
-                    s[t] = mfma32(a.x, qf[c].x, s[t]);
-                    s[t] = mfma32(a.y, qf[c].y, s[t]);
-                    s[t] = mfma32(a.z, qf[c].z, s[t]);
-                    s[t] = mfma32(a.w, qf[c].w, s[t]);
+                for (int r = 0; r < 4; ++r) {
+                    const int key = st * STG + j * 16 + 4 * g + r;  // accumulator row = key
+                    s[r] = key < S ? a0[r] + a1[r] : -INFINITY;
+                }
+                // ---- online softmax (per query = per lane column) ------------------------
+                float mloc = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+                const float m_new = fmaxf(m_run, mloc);   // finite: every sub-tile holds a valid key
+                const float alpha = expf(m_run - m_new);  // exp(-inf) = 0 on the first sub-tile
+                float psum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = expf(s[r] - m_new);  // masked keys: exp(-inf) = 0
+                    s[r] = pv;
+                    psum += pv;
+                }
+                l_run = l_run * alpha + psum;  // partial over this lane's keys; summed at the end
+                m_run = m_new;
+#pragma unroll
+                for (int db = 0; db < 8; ++db) {
+                    o[db][0] *= alpha; o[db][1] *= alpha; o[db][2] *= alpha; o[db][3] *= alpha;
+                }
+                // ---- Oᵀ += Vᵀ · Pᵀ -------------------------------------------------------
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // MFMA step r contracts keys {16 j + 4 g' + r : g' = 0..3}
+                    const int vrow = j * 16 + 4 * g + r;
+                    const float* vr = vt + (vrow >> 1) * VPAIR + (vrow & 1) * DH + l15;
+                    const float pb = s[r];
+#pragma unroll
+                    for (int db = 0; db < 8; ++db) o[db] = mfma16(vr[db * 16], pb, o[db]);
                 }
             }
-            __syncthreads();
         }
-    }
-
-    // ---- phase 2: softmax over keys (per query = per lane column) -------------------------
-    float mx = -INFINITY;
-#pragma unroll
-    for (int t = 0; t < MAX_KT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = t * KT + mfma32_row(r, lane);
-            if (key >= S) s[t][r] = -INFINITY;
-            mx = fmaxf(mx, s[t][r]);
-        }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float sum = 0.f;
-#pragma unroll
-    for (int t = 0; t < MAX_KT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float e = expf(s[t][r] - mx);
-            s[t][r] = e;
-            sum += e;
-        }
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
-#pragma unroll
-    for (int t = 0; t < MAX_KT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[t][r] *= inv;
-
-    if constexpr (STASH) {
-        // Row statistics for the backward pass (P is recomputed there): [B'·H][S][2] = (max, 1/sum)
-        const int q = q0 + l31;
-        if (active && q < S && hi == 0) {
-            row_stats[((size_t)bh * S + q) * 2] = mx;
-            row_stats[((size_t)bh * S + q) * 2 + 1] = inv;
-        }
-    }
-
-    // ---- phase 3: O = P · V -----------------------------------------------------------------
-    f32x16 o[4];
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-
-    stage_tile(kv[0], vbase, ld, 0, S, tid);
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < MAX_KT; ++t) {
-        if (t < nkt) {
-            if (t + 1 < nkt) stage_tile(kv[(t + 1) & 1], vbase, ld, (t + 1) * KT, S, tid);
-            if (active) {
-                const float* vb = kv[t & 1] + l31;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    // MFMA step r contracts key (r&3)+8(r>>2) [hi=0 lanes] and that key + 4 [hi=1]
-                    const float* vr = vb + mfma32_row(r, lane) * KLD;
-                    const float a = s[t][r];
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) o[d] = mfma32(a, vr[d * 32], o[d]);
-                }
-            }
-            __syncthreads();
-        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
     }
 
     if (active) {
-        float* ob = out + (size_t)b * S * d_model + h * DH + l31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int q = q0 + mfma32_row(r, lane);
-            if (q < S) {
-#pragma unroll
-                for (int d = 0; d < 4; ++d) ob[(size_t)q * d_model + d * 32] = o[d][r];
+        float lsum = l_run;
+        lsum += __shfl_xor(lsum, 16, 64);
+        lsum += __shfl_xor(lsum, 32, 64);
+        const float inv = 1.0f / lsum;
+        if (qok) {
+            if constexpr (STASH) {
+                // row statistics for the backward pass (P is recomputed there): (max, 1/sum)
+                if (g == 0) {
+                    row_stats[((size_t)bh * S + q) * 2] = m_run;
+                    row_stats[((size_t)bh * S + q) * 2 + 1] = inv;
+                }
             }
+            float* ob = out + ((size_t)b * S + q) * d_model + h * DH + 4 * g;
+#pragma unroll
+            for (int db = 0; db < 8; ++db)
+                *reinterpret_cast<float4*>(ob + db * 16) =
+                    make_float4(o[db][0] * inv, o[db][1] * inv, o[db][2] * inv, o[db][3] * inv);
         }
     }
 }
 
 hipError_t launch_attention_fwd(const float* qkv, float* out, float* row_stats, int n_seq, int S,
                                 int H, hipStream_t stream) {
-    dim3 grid(n_seq * H, (S + 127) / 128);
+    const int qblocks = (S + 15) / 16;
+    dim3 grid(n_seq * H, (qblocks + NWAVE - 1) / NWAVE);
     const float scale = 1.0f / sqrtf((float)DH);
+    constexpr size_t lds = 2ull * STAGE_FLOATS * sizeof(float);  // 66,560 B > the 64 KiB default
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_fwd_kernel<true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_fwd_kernel<false>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e1 != hipSuccess) return e1;
+        if (e2 != hipSuccess) return e2;
+        attr_done = true;
+    }
     if (row_stats)
-        hipLaunchKernelGGL(attention_fwd_kernel<true>, grid, dim3(256), 0, stream, qkv, out, row_stats,
-                           S, H, scale);
+        hipLaunchKernelGGL(attention_fwd_kernel<true>, grid, dim3(64 * NWAVE), lds, stream, qkv, out,
+                           row_stats, S, H, scale);
     else
-        hipLaunchKernelGGL(attention_fwd_kernel<false>, grid, dim3(256), 0, stream, qkv, out,
+        hipLaunchKernelGGL(attention_fwd_kernel<false>, grid, dim3(64 * NWAVE), lds, stream, qkv, out,
                            row_stats, S, H, scale);
     return hipGetLastError();
 }

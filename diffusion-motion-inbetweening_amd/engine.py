@@ -256,19 +256,33 @@ class Engine:
 
 
 def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
-            tile: int = 0) -> torch.Tensor:
-    """C = A[M,K] · W[N,K]ᵀ (+ bias) through the engine's fp32 MFMA GEMM (test / bench hook)."""
+            tile: int = 0, epi: int = 0, resid: Optional[torch.Tensor] = None,
+            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """C = epi(A[M,K] · W[N,K]ᵀ + bias) through the engine's fp32 MFMA GEMM (test / bench hook);
+    epi 0 = bias, 1 = bias + GELU, 3 = bias + residual."""
     lib = N.load()
     assert a.is_cuda and w.is_cuda and a.dtype == torch.float32 and w.dtype == torch.float32
     a, w = a.contiguous(), w.contiguous()
     m, k = a.shape
     n = w.shape[0]
     assert w.shape[1] == k
-    c = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    c = out if out is not None else torch.empty((m, n), dtype=torch.float32, device=a.device)
     with torch.cuda.device(a.device):
-        N.check(lib.cmdi_gemm_nt(N.ptr(a), N.ptr(w), N.ptr(bias), N.ptr(c), m, n, k, int(tile),
-                                 N.current_stream(a.device)))
+        N.check(lib.cmdi_gemm_nt(N.ptr(a), N.ptr(w), N.ptr(bias), N.ptr(resid), N.ptr(c), m, n, k,
+                                 int(epi), int(tile), N.current_stream(a.device)))
     return c
+
+
+def attention_fwd(qkv: torch.Tensor, n_seq: int, seq_len: int, n_heads: int) -> torch.Tensor:
+    """softmax(QKᵀ/sqrt(128))V per (sequence, head) on a packed [n_seq*S, 3*H*128] tensor."""
+    lib = N.load()
+    assert qkv.is_cuda and qkv.dtype == torch.float32 and qkv.is_contiguous()
+    assert qkv.shape == (n_seq * seq_len, 3 * n_heads * 128)
+    out = torch.empty((n_seq * seq_len, n_heads * 128), dtype=torch.float32, device=qkv.device)
+    with torch.cuda.device(qkv.device):
+        N.check(lib.cmdi_attention_fwd(N.ptr(qkv), N.ptr(out), n_seq, seq_len, n_heads,
+                                       N.current_stream(qkv.device)))
+    return out
 
 
 def philox4x32_10(counter, key):

@@ -173,10 +173,15 @@ int cmdi_randn(cmdi_handle h, float* d_out, int32_t batch, int64_t per_sample, u
                int64_t first_sample, int32_t step, cmdi_stream stream);
 
 /* ---- introspection for tests / bench --------------------------------------------------------- */
-/* Raw NT GEMM used by every projection: C[M,N] = A[M,K] · W[N,K]^T (+bias[N]); fp32 MFMA.
- * tile selects the block shape (0 = default heuristic).  K % 32 == 0, N % 32 == 0. */
-int cmdi_gemm_nt(const float* d_a, const float* d_w, const float* d_bias, float* d_c, int32_t m,
-                 int32_t n, int32_t k, int32_t tile, cmdi_stream stream);
+/* Raw NT GEMM used by every projection: C[M,N] = epi(A[M,K] · W[N,K]^T + bias[N]); fp32 MFMA.
+ * epi: 0 = bias, 1 = bias + GELU(erf), 3 = bias + residual d_resid[M,N].  tile selects the block
+ * shape / pipeline variant (0 = the engine's heuristic).  K % 32 == 0, N % 32 == 0. */
+int cmdi_gemm_nt(const float* d_a, const float* d_w, const float* d_bias, const float* d_resid,
+                 float* d_c, int32_t m, int32_t n, int32_t k, int32_t epi, int32_t tile,
+                 cmdi_stream stream);
+/* Self-attention core alone (test / bench hook): d_qkv [n_seq*S, 3*H*128] -> d_out [n_seq*S, H*128]. */
+int cmdi_attention_fwd(const float* d_qkv, float* d_out, int32_t n_seq, int32_t seq_len,
+                       int32_t n_heads, cmdi_stream stream);
 /* Philox4x32-10 raw block (host, for known-answer tests): out[4] = philox(counter[4], key[2]). */
 void cmdi_philox4x32_10(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]);
 /* Live timing of the dominant kernel (the self-attention in_proj GEMM, one launch per layer):

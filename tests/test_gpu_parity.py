@@ -57,7 +57,7 @@ def test_single_hip_runtime_and_native_lib_loaded(condmdi):
 
 
 # ---- GEMM ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 11, 12, 13, 14, 15, 21, 22, 23, 24, 25])
 @pytest.mark.parametrize("shape", [(333, 512, 512), (197 * 4, 1536, 512), (1000, 512, 1024)])
 def test_gemm_nt(tile, shape):
     eng = sub("engine")
@@ -66,9 +66,30 @@ def test_gemm_nt(tile, shape):
     a = torch.randn(m, k, generator=g)
     w = torch.randn(n, k, generator=g) * (torch.arange(n).float()[:, None] % 7 + 1)  # asymmetric
     b = torch.randn(n, generator=g)
+    r = torch.randn(m, n, generator=g)
     ref = (a.double() @ w.double().T + b.double())
     out = eng.gemm_nt(a.to(DEV), w.to(DEV), b.to(DEV), tile=tile).cpu()
     assert rel_l2(out.numpy(), ref.numpy()) <= 2e-6
+    out = eng.gemm_nt(a.to(DEV), w.to(DEV), b.to(DEV), tile=tile, epi=3, resid=r.to(DEV)).cpu()
+    assert rel_l2(out.numpy(), (ref + r.double()).numpy()) <= 2e-6
+    out = eng.gemm_nt(a.to(DEV), w.to(DEV), b.to(DEV), tile=tile, epi=1).cpu()
+    assert rel_l2(out.numpy(), torch.nn.functional.gelu(ref).numpy()) <= 2e-6
+
+
+# ---- attention -----------------------------------------------------------------------------------
+@pytest.mark.parametrize("S", [197, 61, 16, 17, 224, 33])
+def test_attention_core_vs_torch(S):
+    eng = sub("engine")
+    n_seq, H = 3, 4
+    g = torch.Generator().manual_seed(S)
+    qkv = torch.randn(n_seq * S, 3 * H * 128, generator=g)
+    qkv[:, :512] *= 3.0  # sharper softmax; a spiked key forces the online-max rescale late in the row
+    qkv[S - 1, 512:1024] *= 4.0
+    q, k, v = (qkv[:, i * 512:(i + 1) * 512].double().view(n_seq, S, H, 128).transpose(1, 2) for i in range(3))
+    p = torch.softmax(q @ k.transpose(-1, -2) / 128 ** 0.5, dim=-1)
+    ref = (p @ v).transpose(1, 2).reshape(n_seq * S, 512)
+    out = eng.attention_fwd(qkv.to(DEV), n_seq, S, H).cpu()
+    assert rel_l2(out.numpy(), ref.numpy()) <= 2e-6, rel_l2(out.numpy(), ref.numpy())
 
 
 # ---- RNG -------------------------------------------------------------------------------------------
