@@ -38,6 +38,7 @@ PKG = "diffusion-motion-inbetweening_amd"
 sub = lambda n: importlib.import_module(f"{PKG}.{n}")
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+F16_MFMA_PEAK_TFLOPS = 2500.0   # same guide: dense f16/bf16 MFMA (v_mfma_f32_32x32x16_f16)
 N_FEATS, T_FRAMES = 263, 196
 CONFIGS = {
     # name: (batch per GPU, respacing, sampler, cfg, edit)
@@ -118,6 +119,8 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--precision", default=None, choices=["f32", "f16x3"],
+                    help="encoder GEMM arithmetic (include/condmdi.h CMDI_PREC_*); default: the library's")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
 
@@ -142,7 +145,9 @@ def main():
                                    gd.DiffusionConfig(betas=gd.get_named_beta_schedule("cosine", 1000)))
     n_chain = diffusion.num_timesteps
     assert K + W <= n_chain, f"steps + warmup must be <= {n_chain}"
+    model.native_precision = args.precision
     eng = model.engine(dev, max_batch=B, max_frames=T_FRAMES, want_grad=cfg["edit"])
+    split = eng.precision == "f16x3"
     eng.set_schedule(diffusion.engine_tables(), key="bench")
 
     # synthetic per-rank inputs keyed by GLOBAL sample index (rank r owns samples [r*B, (r+1)*B))
@@ -180,6 +185,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     assert torch.isfinite(x).all(), "non-finite samples"
+    eng.check_range()
 
     # the path's only collective: reassemble the generated sequences (outside the timed steps)
     t1 = time.perf_counter()
@@ -194,7 +200,10 @@ def main():
     out = {
         "metric": "diffusion denoising steps/sec", "value": steps_per_s, "unit": "steps/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": ("f32 (products as 3 split-f16 MFMAs on 22-bit operand pairs, fp32 accumulate; same "
+                  "parity tolerances as exact fp32)") if split else "f32",
+        "precision_mode": eng.precision,
         "data": "synthetic (random-init MDM weights, z-scored N(0,1) motions, fake CLIP embeddings)",
         "config": {"workload": cfg["desc"], "batch_per_gpu": B, "global_batch": world * B,
                    "n_frames": T_FRAMES, "n_feats": N_FEATS, "chain_steps": n_chain,
@@ -218,13 +227,27 @@ def main():
         pmc = REPO / "profiles" / "pmc_inproj_gemm.json"
         if pmc.exists():
             traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
-        out["roofline"] = {
-            "kernel": f"gemm_nt_kernel (self_attn.in_proj, M={m} N={n} K={k}, fp32 MFMA 32x32x2)",
-            "bound": "mfma", "achieved": flop_launch / avg_s / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": flop_launch / avg_s / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-            "traffic": traffic, "launches": launches, "avg_launch_us": avg_s * 1e6,
-            "flops_per_launch": flop_launch,
-        }
+        ach = flop_launch / avg_s / 1e12
+        if split:
+            # algorithmic flops = 2MNK of the fp32 product; the kernel executes 3 f16 MFMA products
+            # per algorithmic product, so its ceiling is the dense f16 peak / 3
+            peak = F16_MFMA_PEAK_TFLOPS / 3.0
+            out["roofline"] = {
+                "kernel": f"gemm_h3_kernel (self_attn.in_proj, M={m} N={n} K={k}, 3x v_mfma_f32_32x32x16_f16 "
+                          "per fp32-equivalent product)",
+                "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                "traffic": traffic, "launches": launches, "avg_launch_us": avg_s * 1e6,
+                "flops_per_launch": flop_launch, "executed_f16_tflops": 3.0 * ach,
+                "f16_dense_peak": F16_MFMA_PEAK_TFLOPS, "vs_fp32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS,
+            }
+        else:
+            out["roofline"] = {
+                "kernel": f"gemm_nt_kernel (self_attn.in_proj, M={m} N={n} K={k}, fp32 MFMA 32x32x2)",
+                "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS,
+                "traffic": traffic, "launches": launches, "avg_launch_us": avg_s * 1e6,
+                "flops_per_launch": flop_launch,
+            }
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu:

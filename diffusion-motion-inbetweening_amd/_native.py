@@ -18,6 +18,9 @@ LIB_PATH = _PKG / "csrc" / "libcondmdi_hip.so"
 
 CMDI_MEAN_START_X, CMDI_MEAN_EPSILON = 0, 1
 CMDI_SAMPLER_DDPM, CMDI_SAMPLER_DDIM = 0, 1
+CMDI_PREC_DEFAULT, CMDI_PREC_F32, CMDI_PREC_F16X3 = 0, 1, 2
+PRECISIONS = {None: CMDI_PREC_DEFAULT, "default": CMDI_PREC_DEFAULT, "f32": CMDI_PREC_F32,
+              "f16x3": CMDI_PREC_F16X3}
 
 
 class NativeError(RuntimeError):
@@ -27,7 +30,7 @@ class NativeError(RuntimeError):
 class ModelDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n_layers", "d_model", "d_ff", "n_heads", "n_feats", "max_frames", "max_batch", "pe_rows",
-        "text_cond", "want_grad")]
+        "text_cond", "want_grad", "precision")]
 
 
 class Schedule(C.Structure):
@@ -68,6 +71,10 @@ SIGNATURES = {
     "cmdi_randn": (C.c_int, [_VP, _VP, _I32, _I64, _U64, _I64, _I32, _VP]),
     "cmdi_gemm_nt": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _VP]),
     "cmdi_attention_fwd": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _VP]),
+    "cmdi_precision": (C.c_int, [_VP]),
+    "cmdi_range_status": (C.c_int, [_VP, C.POINTER(_I32), _VP]),
+    "cmdi_split_f16": (C.c_int, [_VP, _VP, _I64, _I32, _VP]),
+    "cmdi_gemm_h3": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _VP]),
     "cmdi_philox4x32_10": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "cmdi_workspace_bytes": (_I64, [_VP]),
     "cmdi_profile_enable": (C.c_int, [_VP, _I32]),

@@ -22,6 +22,7 @@ LIB_PATH = CSRC / "libcondmdi_hip.so"
 UNITS = {
     "api.hip": [],
     "gemm_f32.hip": [],
+    "gemm_h3.hip": [],
     "attention_f32.hip": [],
     "attention_bwd_f32.hip": [],
     "elementwise.hip": [],

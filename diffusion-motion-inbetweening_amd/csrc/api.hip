@@ -34,6 +34,8 @@ struct LayerW {
     float *n1_g = nullptr, *n1_b = nullptr, *n2_g = nullptr, *n2_b = nullptr;
     // transposed copies for the dX backward GEMMs (want_grad only)
     float *in_wT = nullptr, *out_wT = nullptr, *l1_wT = nullptr, *l2_wT = nullptr;
+    // split-f16 copies (hi | lo*2^11 rows, gemm_h3.hpp) for the f16-pipe forward GEMMs
+    _Float16 *in_ws = nullptr, *out_ws = nullptr, *l1_ws = nullptr, *l2_ws = nullptr;
 };
 struct LayerStash {
     float *qkv = nullptr, *attn = nullptr, *row_stats = nullptr;
@@ -81,6 +83,12 @@ struct cmdi_engine {
     bool stash_valid = false;
     float *dA = nullptr, *dB = nullptr, *dH = nullptr, *dqkv = nullptr, *dffn = nullptr,
           *drowdot = nullptr, *gout = nullptr, *gx = nullptr;
+    // precision of the encoder-layer GEMMs: CMDI_PREC_F32 (exact fp32 MFMA) or CMDI_PREC_F16X3
+    // (fp32-equivalent split-f16 products on the f16 matrix pipe, gemm_h3.hpp)
+    int precision = CMDI_PREC_F16X3;
+    _Float16 *tokS = nullptr, *bufHS = nullptr, *attnS = nullptr, *ffnS = nullptr;
+    int* range_flag = nullptr;
+    int h3_tile_qkv = 0, h3_tile_proj = 0, h3_tile_ffn1 = 0, h3_tile_ffn2 = 0;
     int gemm_tile = 0;
     int tile_inproj = 0, tile_proj = 0, tile_ffn1 = 0, tile_ffn2 = 0;  // per-GEMM overrides (0 = auto)
 
@@ -138,6 +146,20 @@ int run_layers(cmdi_engine* e, int seq0, int nseq, bool keep, bool prof, hipStre
     float* tokB = e->tokB + r0 * d;
     float* bufH = e->bufH + r0 * d;
     float* ffn = e->ffn + r0 * f;
+    const bool h3 = e->precision == CMDI_PREC_F16X3;
+    _Float16* tokS = h3 ? e->tokS + r0 * 2 * d : nullptr;
+    _Float16* bufHS = h3 ? e->bufHS + r0 * 2 * d : nullptr;
+    _Float16* attnS = h3 ? e->attnS + r0 * 2 * d : nullptr;
+    _Float16* ffnS = h3 ? e->ffnS + r0 * 2 * f : nullptr;
+    auto hp = [&](const _Float16* A, const _Float16* W, const float* bias, float* C, _Float16* Cs,
+                  int N, int K) {
+        H3Params p{};
+        p.A = A; p.W = W; p.bias = bias; p.C = C; p.Cs = Cs; p.range_flag = e->range_flag;
+        p.M = M; p.N = N; p.K = K; p.ldc = N;
+        return p;
+    };
+    if (h3)  // layer 0 reads the tokens assembled by token0 + the input projection (fp32)
+        HIPCHK(launch_split_f16(tokA, tokS, M, d, d, e->range_flag, s));
     for (int l = 0; l < e->L; ++l) {
         const LayerW& w = e->layers[l];
         const LayerStash* st = keep ? &e->stash[l] : nullptr;
@@ -146,6 +168,49 @@ int run_layers(cmdi_engine* e, int seq0, int nseq, bool keep, bool prof, hipStre
         float* pre1 = keep ? st->pre1 + r0 * d : tokB;
         float* pre2 = keep ? st->pre2 + r0 * d : tokB;
         float* row_stats = keep ? st->row_stats + (size_t)seq0 * e->H * S * 2 : nullptr;
+        if (h3) {
+            // same layer on the f16 matrix pipe; every A operand arrives as split rows written by
+            // its producer (LayerNorm, attention, the GELU epilogue)
+            if (prof) {
+                if (e->ev_used + 2 > e->ev_pool.size()) {
+                    hipEvent_t a, b;
+                    HIPCHK(hipEventCreate(&a));
+                    HIPCHK(hipEventCreate(&b));
+                    e->ev_pool.push_back(a);
+                    e->ev_pool.push_back(b);
+                }
+                HIPCHK(hipEventRecord(e->ev_pool[e->ev_used], s));
+            }
+            HIPCHK(launch_gemm_h3(H3_PLAIN, hp(tokS, w.in_ws, w.in_b, qkv, nullptr, 3 * d, d),
+                                  e->h3_tile_qkv, s));
+            if (prof) {
+                HIPCHK(hipEventRecord(e->ev_pool[e->ev_used + 1], s));
+                e->ev_used += 2;
+                e->prof_m = M; e->prof_n = 3 * d; e->prof_k = d;
+            }
+            HIPCHK(launch_attention_fwd(qkv, keep ? attn : nullptr, attnS, e->range_flag, row_stats,
+                                        nseq, S, e->H, s));
+            {
+                H3Params p = hp(attnS, w.out_ws, w.out_b, pre1, nullptr, d, d);
+                p.R = tokA;
+                HIPCHK(launch_gemm_h3(H3_RESID, p, e->h3_tile_proj, s));
+            }
+            HIPCHK(launch_layernorm(pre1, w.n1_g, w.n1_b, bufH, bufHS, e->range_flag,
+                                    keep ? st->stats1 + r0 * 2 : nullptr, M, d, s));
+            {
+                H3Params p = hp(bufHS, w.l1_ws, w.l1_b, nullptr, ffnS, f, d);
+                p.aux = keep ? st->aux + r0 * f : nullptr;
+                HIPCHK(launch_gemm_h3(H3_GELU_SPLIT, p, e->h3_tile_ffn1, s));
+            }
+            {
+                H3Params p = hp(ffnS, w.l2_ws, w.l2_b, pre2, nullptr, d, f);
+                p.R = bufH;
+                HIPCHK(launch_gemm_h3(H3_RESID, p, e->h3_tile_ffn2, s));
+            }
+            HIPCHK(launch_layernorm(pre2, w.n2_g, w.n2_b, tokA, l + 1 < e->L ? tokS : nullptr,
+                                    e->range_flag, keep ? st->stats2 + r0 * 2 : nullptr, M, d, s));
+            continue;
+        }
         // self-attention block: x = norm1(x + out_proj(MHA(x)))
         if (prof) {
             if (e->ev_used + 2 > e->ev_pool.size()) {
@@ -164,13 +229,13 @@ int run_layers(cmdi_engine* e, int seq0, int nseq, bool keep, bool prof, hipStre
             e->ev_used += 2;
             e->prof_m = M; e->prof_n = 3 * d; e->prof_k = d;
         }
-        HIPCHK(launch_attention_fwd(qkv, attn, row_stats, nseq, S, e->H, s));
+        HIPCHK(launch_attention_fwd(qkv, attn, nullptr, nullptr, row_stats, nseq, S, e->H, s));
         {
             GemmParams p = gp(attn, w.out_w, w.out_b, pre1, M, d, d, d, d, d);
             p.R = tokA;
             HIPCHK(launch_gemm(GK_RESID, p, e->tile_proj, s));
         }
-        HIPCHK(launch_layernorm(pre1, w.n1_g, w.n1_b, bufH, keep ? st->stats1 + r0 * 2 : nullptr, M, d, s));
+        HIPCHK(launch_layernorm(pre1, w.n1_g, w.n1_b, bufH, nullptr, nullptr, keep ? st->stats1 + r0 * 2 : nullptr, M, d, s));
         // feed-forward block: x = norm2(x + linear2(gelu(linear1(x))))
         {
             GemmParams p = gp(bufH, w.l1_w, w.l1_b, ffn, M, f, d, d, d, f);
@@ -182,7 +247,7 @@ int run_layers(cmdi_engine* e, int seq0, int nseq, bool keep, bool prof, hipStre
             p.R = bufH;
             HIPCHK(launch_gemm(GK_RESID, p, e->tile_ffn2, s));
         }
-        HIPCHK(launch_layernorm(pre2, w.n2_g, w.n2_b, tokA, keep ? st->stats2 + r0 * 2 : nullptr, M, d, s));
+        HIPCHK(launch_layernorm(pre2, w.n2_g, w.n2_b, tokA, nullptr, nullptr, keep ? st->stats2 + r0 * 2 : nullptr, M, d, s));
     }
     return CMDI_OK;
 }
@@ -368,7 +433,7 @@ int build_coef(cmdi_engine* e, int sampler, int step, float eta, bool impute, bo
 extern "C" {
 
 const char* cmdi_last_error(void) { return g_err.c_str(); }
-const char* cmdi_version(void) { return "condmdi-hip 0.1 (gfx950, fp32 MFMA)"; }
+const char* cmdi_version(void) { return "condmdi-hip 0.2 (gfx950, fp32 MFMA + split-f16 MFMA)"; }
 
 int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
     if (!desc || !out) return fail(CMDI_E_INVALID, "null argument");
@@ -413,6 +478,22 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
     e->tile_ffn1 = env_int("CMDI_TILE_FFN1", e->gemm_tile);
     e->tile_ffn2 = env_int("CMDI_TILE_FFN2", e->gemm_tile);
     e->n_groups = env_int("CMDI_GROUPS", 0);  // 0 = automatic
+    {
+        int prec = desc->precision;
+        if (prec == CMDI_PREC_DEFAULT) {
+            const char* v = std::getenv("CMDI_PRECISION");
+            prec = (v && std::string(v) == "f32") ? CMDI_PREC_F32 : CMDI_PREC_F16X3;
+        }
+        if (prec != CMDI_PREC_F32 && prec != CMDI_PREC_F16X3)
+            return fail(CMDI_E_INVALID, "precision must be CMDI_PREC_DEFAULT, _F32 or _F16X3");
+        if (prec == CMDI_PREC_F16X3 && (desc->d_model % 64 != 0 || desc->d_ff % 64 != 0))
+            return fail(CMDI_E_INVALID, "f16x3 precision needs d_model and d_ff multiples of 64");
+        e->precision = prec;
+    }
+    e->h3_tile_qkv = env_int("CMDI_H3_TILE_QKV", env_int("CMDI_H3_TILE", 0));
+    e->h3_tile_proj = env_int("CMDI_H3_TILE_PROJ", env_int("CMDI_H3_TILE", 0));
+    e->h3_tile_ffn1 = env_int("CMDI_H3_TILE_FFN1", env_int("CMDI_H3_TILE", 0));
+    e->h3_tile_ffn2 = env_int("CMDI_H3_TILE_FFN2", env_int("CMDI_H3_TILE", 0));
     const int d = e->d, f = e->f, C = e->C;
     const size_t nseq = 2 * (size_t)e->Bmax, Smax = e->Tmax + 1, Mmax = nseq * Smax;
     *out = e;  // so that cmdi_destroy can free a half-built engine
@@ -444,6 +525,16 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
     ALLOC(e->tokA, Mmax * d); ALLOC(e->tokB, Mmax * d); ALLOC(e->bufH, Mmax * d);
     ALLOC(e->qkv, Mmax * 3 * d); ALLOC(e->attn, Mmax * d); ALLOC(e->ffn, Mmax * f);
     ALLOC(e->out_raw, nseq * C * e->Tmax);
+    ALLOC(e->range_flag, 1);
+    HIPCHK(hipMemset(e->range_flag, 0, sizeof(int)));
+    if (e->precision == CMDI_PREC_F16X3) {
+        for (LayerW& w : e->layers) {
+            ALLOC(w.in_ws, (size_t)3 * d * d * 2); ALLOC(w.out_ws, (size_t)d * d * 2);
+            ALLOC(w.l1_ws, (size_t)f * d * 2); ALLOC(w.l2_ws, (size_t)d * f * 2);
+        }
+        ALLOC(e->tokS, Mmax * d * 2); ALLOC(e->bufHS, Mmax * d * 2);
+        ALLOC(e->attnS, Mmax * d * 2); ALLOC(e->ffnS, Mmax * f * 2);
+    }
     if (desc->want_grad) {
         ALLOC(e->w_inT, (size_t)C * d); ALLOC(e->w_outT_pad, (size_t)d * e->Cpad);
         e->stash.resize(e->L);
@@ -563,6 +654,15 @@ int cmdi_finalize_weights(cmdi_handle e, int32_t n_time_rows, cmdi_stream stream
             HIPCHK(launch_transpose_pad(w.l2_wT, w.l2_w, d, f, d, s));          // [f][d]
         }
     }
+    if (e->precision == CMDI_PREC_F16X3) {
+        HIPCHK(hipMemsetAsync(e->range_flag, 0, sizeof(int), s));
+        for (LayerW& w : e->layers) {
+            HIPCHK(launch_split_f16(w.in_w, w.in_ws, 3 * d, d, d, e->range_flag, s));
+            HIPCHK(launch_split_f16(w.out_w, w.out_ws, d, d, d, e->range_flag, s));
+            HIPCHK(launch_split_f16(w.l1_w, w.l1_ws, f, d, d, e->range_flag, s));
+            HIPCHK(launch_split_f16(w.l2_w, w.l2_ws, d, f, f, e->range_flag, s));
+        }
+    }
     // TimestepEmbedder (mdm.py:351-353) for every original timestep: Linear -> SiLU -> Linear on pe[t]
     if (!e->time_table || e->n_time_rows < n_time_rows) {
         int rc = falloc(e, &e->time_table, (size_t)n_time_rows * d);
@@ -576,6 +676,13 @@ int cmdi_finalize_weights(cmdi_handle e, int32_t n_time_rows, cmdi_stream stream
     hipError_t e3 = hipStreamSynchronize(s);  // one-time setup: tmp must outlive the kernels
     (void)hipFree(tmp);
     HIPCHK(e1); HIPCHK(e2); HIPCHK(e3);
+    if (e->precision == CMDI_PREC_F16X3) {
+        int flag = 0;
+        HIPCHK(hipMemcpy(&flag, e->range_flag, sizeof(int), hipMemcpyDeviceToHost));
+        if (flag)
+            return fail(CMDI_E_RANGE, "a weight is not finite or exceeds the f16 range (|w| >= 65504): "
+                                      "create the engine with precision = CMDI_PREC_F32");
+    }
     e->finalized = true;
     return CMDI_OK;
 }
@@ -815,8 +922,57 @@ int cmdi_attention_fwd(const float* d_qkv, float* d_out, int32_t n_seq, int32_t 
                        int32_t n_heads, cmdi_stream stream) {
     if (!d_qkv || !d_out || n_seq < 1 || seq_len < 1 || seq_len > 224 || n_heads < 1)
         return fail(CMDI_E_INVALID, "bad argument");
-    HIPCHK(launch_attention_fwd(d_qkv, d_out, nullptr, n_seq, seq_len, n_heads,
+    HIPCHK(launch_attention_fwd(d_qkv, d_out, nullptr, nullptr, nullptr, n_seq, seq_len, n_heads,
                                 static_cast<hipStream_t>(stream)));
+    return CMDI_OK;
+}
+
+int cmdi_precision(cmdi_handle e) { return e ? e->precision : CMDI_E_INVALID; }
+
+int cmdi_range_status(cmdi_handle e, int32_t* out_flag, cmdi_stream stream) {
+    if (!e || !out_flag) return fail(CMDI_E_INVALID, "null argument");
+    *out_flag = 0;
+    if (!e->range_flag) return CMDI_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int flag = 0;
+    HIPCHK(hipMemcpyAsync(&flag, e->range_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (flag) HIPCHK(hipMemsetAsync(e->range_flag, 0, sizeof(int), s));
+    *out_flag = flag;
+    return CMDI_OK;
+}
+
+int cmdi_split_f16(const float* d_src, void* d_dst, int64_t rows, int32_t cols, cmdi_stream stream) {
+    if (!d_src || !d_dst || rows < 1 || cols < 8 || cols % 8 != 0)
+        return fail(CMDI_E_INVALID, "bad argument (cols must be a positive multiple of 8)");
+    HIPCHK(launch_split_f16(d_src, static_cast<_Float16*>(d_dst), rows, cols, cols, nullptr,
+                            static_cast<hipStream_t>(stream)));
+    return CMDI_OK;
+}
+
+int cmdi_gemm_h3(const void* d_a_split, const void* d_w_split, const float* d_bias,
+                 const float* d_resid, float* d_c, void* d_c_split, int32_t m, int32_t n, int32_t k,
+                 int32_t epi, int32_t tile, cmdi_stream stream) {
+    if (!d_a_split || !d_w_split) return fail(CMDI_E_INVALID, "null tensor");
+    if (k % 64 != 0 || n % 32 != 0) return fail(CMDI_E_INVALID, "K must be a multiple of 64, N of 32");
+    H3Params p{};
+    p.A = static_cast<const _Float16*>(d_a_split);
+    p.W = static_cast<const _Float16*>(d_w_split);
+    p.bias = d_bias; p.C = d_c; p.Cs = static_cast<_Float16*>(d_c_split); p.R = d_resid;
+    p.M = m; p.N = n; p.K = k; p.ldc = n;
+    int kind;
+    switch (epi) {
+        case 0: kind = d_c_split ? H3_PLAIN_SPLIT : H3_PLAIN; break;
+        case 1: kind = H3_GELU_SPLIT; break;
+        case 3: kind = H3_RESID; break;
+        default: return fail(CMDI_E_INVALID, "epi must be 0 (bias), 1 (bias+gelu, split output) or 3 (bias+residual)");
+    }
+    if ((kind == H3_PLAIN || kind == H3_RESID) && !d_c) return fail(CMDI_E_INVALID, "fp32 output needs d_c");
+    if ((kind == H3_GELU_SPLIT || kind == H3_PLAIN_SPLIT) && !d_c_split)
+        return fail(CMDI_E_INVALID, "split output needs d_c_split");
+    if (kind == H3_RESID && !d_resid) return fail(CMDI_E_INVALID, "residual epilogue needs d_resid");
+    hipError_t err = launch_gemm_h3(kind, p, tile, static_cast<hipStream_t>(stream));
+    if (err != hipSuccess) return fail(CMDI_E_HIP, std::string("launch_gemm_h3: ") + hipGetErrorString(err));
     return CMDI_OK;
 }
 

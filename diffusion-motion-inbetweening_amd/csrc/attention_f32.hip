@@ -14,6 +14,7 @@
 //                        lane (q, g) holds in register r), V comes from LDS as the A operand; Oᵀ
 //                        keeps queries on lanes, so the online rescale is a lane-wise multiply.
 #include "common.hpp"
+#include "gemm_h3.hpp"
 #include "kernels.hpp"
 
 namespace cmdi {
@@ -64,6 +65,8 @@ __device__ __forceinline__ void stage_kv(float* kbuf, float* vbuf, const float* 
 template <bool STASH>
 __global__ __launch_bounds__(512, 4) void attention_fwd_kernel(const float* __restrict__ qkv,
                                                             float* __restrict__ out,
+                                                            _Float16* __restrict__ out_s,
+                                                            int* __restrict__ range_flag,
                                                             float* __restrict__ row_stats, int S,
                                                             int H, float scale) {
     extern __shared__ __attribute__((aligned(16))) float kv[];  // [buffer][K tile | V tile]
@@ -188,17 +191,39 @@ __global__ __launch_bounds__(512, 4) void attention_fwd_kernel(const float* __re
                     row_stats[((size_t)bh * S + q) * 2 + 1] = inv;
                 }
             }
-            float* ob = out + ((size_t)b * S + q) * d_model + h * DH + 4 * g;
+            if (out) {
+                float* ob = out + ((size_t)b * S + q) * d_model + h * DH + 4 * g;
 #pragma unroll
-            for (int db = 0; db < 8; ++db)
-                *reinterpret_cast<float4*>(ob + db * 16) =
-                    make_float4(o[db][0] * inv, o[db][1] * inv, o[db][2] * inv, o[db][3] * inv);
+                for (int db = 0; db < 8; ++db)
+                    *reinterpret_cast<float4*>(ob + db * 16) =
+                        make_float4(o[db][0] * inv, o[db][1] * inv, o[db][2] * inv, o[db][3] * inv);
+            }
+            if (out_s) {
+                // split rows for the out_proj GEMM on the f16 pipe (gemm_h3.hpp): [hi(d) | lo(d)]
+                _Float16* ob = out_s + ((size_t)b * S + q) * (2 * d_model) + h * DH + 4 * g;
+                bool overflow = false;
+#pragma unroll
+                for (int db = 0; db < 8; ++db) {
+                    h4 oh, ol;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = o[db][e] * inv;
+                        _Float16 a, c;
+                        split_f16(v, a, c);
+                        oh[e] = a; ol[e] = c;
+                        overflow |= !(fabsf(v) < 65504.0f);
+                    }
+                    *reinterpret_cast<h4*>(ob + db * 16) = oh;
+                    *reinterpret_cast<h4*>(ob + d_model + db * 16) = ol;
+                }
+                if (overflow && range_flag) atomicOr(range_flag, 1);
+            }
         }
     }
 }
 
-hipError_t launch_attention_fwd(const float* qkv, float* out, float* row_stats, int n_seq, int S,
-                                int H, hipStream_t stream) {
+hipError_t launch_attention_fwd(const float* qkv, float* out, _Float16* out_split, int* range_flag,
+                                float* row_stats, int n_seq, int S, int H, hipStream_t stream) {
     const int qblocks = (S + 15) / 16;
     dim3 grid(n_seq * H, (qblocks + NWAVE - 1) / NWAVE);
     const float scale = 1.0f / sqrtf((float)DH);
@@ -215,10 +240,10 @@ hipError_t launch_attention_fwd(const float* qkv, float* out, float* row_stats, 
     }
     if (row_stats)
         hipLaunchKernelGGL(attention_fwd_kernel<true>, grid, dim3(64 * NWAVE), lds, stream, qkv, out,
-                           row_stats, S, H, scale);
+                           out_split, range_flag, row_stats, S, H, scale);
     else
         hipLaunchKernelGGL(attention_fwd_kernel<false>, grid, dim3(64 * NWAVE), lds, stream, qkv, out,
-                           row_stats, S, H, scale);
+                           out_split, range_flag, row_stats, S, H, scale);
     return hipGetLastError();
 }
 

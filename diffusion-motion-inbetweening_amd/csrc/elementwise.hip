@@ -2,6 +2,7 @@
 // nn.TransformerEncoderLayer.norm1/norm2 built at model/mdm.py:107-114), its backward, and the
 // conditioning-token assembly of MDM.forward (model/mdm.py:245-251,279-280).
 #include "common.hpp"
+#include "gemm_h3.hpp"
 #include "kernels.hpp"
 
 namespace cmdi {
@@ -13,6 +14,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
                                                         float* __restrict__ y,
+                                                        _Float16* __restrict__ ys,
+                                                        int* __restrict__ range_flag,
                                                         float* __restrict__ stats, int rows) {
     constexpr int D = NV * 256;
     const int lane = threadIdx.x & 63;
@@ -50,6 +53,22 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         o.z = (v[i].z - mean) * rstd * g.z + bb.z;
         o.w = (v[i].w - mean) * rstd * g.w + bb.w;
         *reinterpret_cast<float4*>(yr + i * 256 + lane * 4) = o;
+        if (ys) {
+            const float ov[4] = {o.x, o.y, o.z, o.w};
+            h4 oh, ol;
+            bool overflow = false;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                _Float16 a, c;
+                split_f16(ov[e], a, c);
+                oh[e] = a; ol[e] = c;
+                overflow |= !(fabsf(ov[e]) < 65504.0f);
+            }
+            _Float16* d = ys + (size_t)row * (2 * D) + i * 256 + lane * 4;
+            *reinterpret_cast<h4*>(d) = oh;
+            *reinterpret_cast<h4*>(d + D) = ol;
+            if (overflow && range_flag) atomicOr(range_flag, 1);
+        }
     }
 }
 
@@ -95,13 +114,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 }
 
 hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, float* y,
-                            float* stats, int rows, int d, hipStream_t stream) {
+                            _Float16* y_split, int* range_flag, float* stats, int rows, int d,
+                            hipStream_t stream) {
     const dim3 grid((rows + 3) / 4), block(256);
     switch (d) {
-        case 256: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, stream, x, gamma, beta, y, stats, rows); break;
-        case 512: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, stream, x, gamma, beta, y, stats, rows); break;
-        case 768: hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, stream, x, gamma, beta, y, stats, rows); break;
-        case 1024: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, stream, x, gamma, beta, y, stats, rows); break;
+        case 256: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, stream, x, gamma, beta, y, y_split, range_flag, stats, rows); break;
+        case 512: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, stream, x, gamma, beta, y, y_split, range_flag, stats, rows); break;
+        case 768: hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, stream, x, gamma, beta, y, y_split, range_flag, stats, rows); break;
+        case 1024: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, stream, x, gamma, beta, y, y_split, range_flag, stats, rows); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -1,0 +1,102 @@
+// Instantiations + host dispatcher of the split-f16 (fp32-equivalent) NT GEMM family (gemm_h3.hpp)
+// and the fp32 -> split-rows conversion kernel.
+#include "gemm_h3.hpp"
+#include "kernels.hpp"
+
+namespace cmdi {
+
+using H128x128k32 = H3Tile<128, 128, 32, 2, 2, 2>;   // 4 waves, 64x64 per wave, 64 KiB LDS, 2 blocks/CU
+using H128x128k64 = H3Tile<128, 128, 64, 2, 2, 1>;   // 128 KiB LDS, 1 block/CU
+using H256x128k32 = H3Tile<256, 128, 32, 4, 2, 2>;   // 8 waves, 64x64 per wave, 96 KiB LDS
+using H128x64k32 = H3Tile<128, 64, 32, 2, 2, 2>;     // 64x32 per wave, 48 KiB LDS, 3 blocks/CU
+using H128x64k64 = H3Tile<128, 64, 64, 2, 2, 2>;     // 96 KiB LDS
+using H64x128k32 = H3Tile<64, 128, 32, 2, 2, 2>;     // 32x64 per wave
+using H128x128k32w8 = H3Tile<128, 128, 32, 4, 2, 2>; // 8 waves, 32x64 per wave
+
+template <class TC, int EPI>
+static hipError_t launch_h3_one(const H3Params& p, hipStream_t stream) {
+    auto kern = gemm_h3_kernel<TC, EPI>;
+    static bool attr_done = false;  // benign race: the attribute call is idempotent
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)TC::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const int tiles = ((p.M + TC::BM - 1) / TC::BM) * ((p.N + TC::BN - 1) / TC::BN);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(TC::NT), TC::LDS_BYTES, stream, p);
+    return hipGetLastError();
+}
+
+template <int EPI>
+static hipError_t launch_h3_tiles(const H3Params& p, int tile, hipStream_t s) {
+    switch (tile) {
+        case 1: return launch_h3_one<H128x128k32, EPI>(p, s);
+        case 2: return launch_h3_one<H128x128k64, EPI>(p, s);
+        case 3: return launch_h3_one<H256x128k32, EPI>(p, s);
+        case 4: return launch_h3_one<H128x64k32, EPI>(p, s);
+        case 5: return launch_h3_one<H128x64k64, EPI>(p, s);
+        case 6: return launch_h3_one<H64x128k32, EPI>(p, s);
+        case 7: return launch_h3_one<H128x128k32w8, EPI>(p, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+int gemm_h3_auto_tile(int M, int N) {
+    (void)M;
+    return N >= 1024 ? 1 : 4;
+}
+
+hipError_t launch_gemm_h3(int epi, const H3Params& p, int tile, hipStream_t s) {
+    if (p.K % 64 != 0 || p.N % 8 != 0 || p.M <= 0 || p.N <= 0) return hipErrorInvalidValue;
+    if (tile == 0) tile = gemm_h3_auto_tile(p.M, p.N);
+    switch (epi) {
+        case H3_PLAIN: return launch_h3_tiles<H3_PLAIN>(p, tile, s);
+        case H3_GELU_SPLIT: return launch_h3_tiles<H3_GELU_SPLIT>(p, tile, s);
+        case H3_RESID: return launch_h3_tiles<H3_RESID>(p, tile, s);
+        case H3_PLAIN_SPLIT: return launch_h3_tiles<H3_PLAIN_SPLIT>(p, tile, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+// fp32 rows [rows][cols] (row stride ld_src floats) -> split rows [rows][2*cols] halves.  One thread
+// converts 8 consecutive elements: two float4 loads, one 16-B store per plane.  HBM-bound.
+__global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ src,
+                                                        _Float16* __restrict__ dst, int64_t rows,
+                                                        int cols, int64_t ld_src,
+                                                        int* __restrict__ range_flag) {
+    const int chunks = cols >> 3;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * chunks) return;
+    const int64_t r = idx / chunks;
+    const int c = (int)(idx - r * chunks) * 8;
+    const float4 a = *reinterpret_cast<const float4*>(src + r * ld_src + c);
+    const float4 b = *reinterpret_cast<const float4*>(src + r * ld_src + c + 4);
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    h8 oh, ol;
+    bool overflow = false;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        _Float16 h, l;
+        split_f16(v[e], h, l);
+        oh[e] = h; ol[e] = l;
+        overflow |= !(fabsf(v[e]) < 65504.0f);
+    }
+    _Float16* d = dst + r * (2 * (int64_t)cols) + c;
+    *reinterpret_cast<h8*>(d) = oh;
+    *reinterpret_cast<h8*>(d + cols) = ol;
+    if (overflow && range_flag) atomicOr(range_flag, 1);
+}
+
+hipError_t launch_split_f16(const float* src, _Float16* dst, int64_t rows, int cols, int64_t ld_src,
+                            int* range_flag, hipStream_t stream) {
+    if (cols % 8 != 0 || ld_src % 4 != 0) return hipErrorInvalidValue;
+    const int64_t n = rows * (cols >> 3);
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(split_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src,
+                       dst, rows, cols, ld_src, range_flag);
+    return hipGetLastError();
+}
+
+}  // namespace cmdi

@@ -38,4 +38,24 @@ struct GemmParams {
     float out_scale;    // EPI_MOTION: multiplies v (1 for the forward pass)
 };
 
+// ---- split-f16 (fp32-equivalent) GEMM family, gemm_h3.hpp ----------------------------------------
+enum H3Epi {
+    H3_PLAIN = 0,       // C = v + bias[n]                                   (fp32)
+    H3_GELU_SPLIT = 1,  // aux = v + bias (optional); Cs = split(gelu_erf(v + bias))
+    H3_RESID = 2,       // C = (v + bias[n]) + R[m][n]                       (fp32)
+    H3_PLAIN_SPLIT = 3, // Cs = split(v + bias[n])
+};
+
+struct H3Params {
+    const _Float16* A;  // split rows [M][2K]
+    const _Float16* W;  // split rows [N][2K]
+    const float* bias;  // [N] or null
+    float* C;           // fp32 output [M][ldc]
+    _Float16* Cs;       // split output [M][2N]
+    const float* R;     // residual [M][ldc]
+    float* aux;         // optional pre-activation stash [M][ldc]
+    int* range_flag;    // set to 1 if a split output leaves the f16 range
+    int M, N, K, ldc;
+};
+
 }  // namespace cmdi

@@ -23,9 +23,20 @@ enum GemmKind {
 hipError_t launch_gemm(GemmKind kind, const GemmParams& p, int tile, hipStream_t stream);
 int gemm_auto_tile(int M, int N);
 
+// ---- gemm_h3.hip (split-f16, fp32-equivalent) ---------------------------------------------------
+// epi: H3Epi; tile: 0 auto, 1 = 128x128x32, 2 = 128x128x64, 3 = 256x128x32 (8 waves), 4 = 128x64x32,
+// 5 = 128x64x64, 6 = 64x128x32, 7 = 128x128x32 (8 waves)
+hipError_t launch_gemm_h3(int epi, const H3Params& p, int tile, hipStream_t stream);
+int gemm_h3_auto_tile(int M, int N);
+// fp32 [rows][cols] (row stride ld_src) -> split rows [rows][2*cols] halves (hi | lo * 2^11)
+hipError_t launch_split_f16(const float* src, _Float16* dst, int64_t rows, int cols, int64_t ld_src,
+                            int* range_flag, hipStream_t stream);
+
 // ---- attention_f32.hip ----------------------------------------------------------------------
-hipError_t launch_attention_fwd(const float* qkv, float* out, float* p_stash, int n_seq, int S,
-                                int H, hipStream_t stream);
+// out (fp32 [M, d]) and out_split (split rows [M, 2d] for the f16-pipe out_proj GEMM) may each be
+// null; row_stats != null stashes (max, 1/sum) per query row for the backward pass.
+hipError_t launch_attention_fwd(const float* qkv, float* out, _Float16* out_split, int* range_flag,
+                                float* row_stats, int n_seq, int S, int H, hipStream_t stream);
 // ---- attention_bwd_f32.hip ------------------------------------------------------------------
 // d_qkv[M,3d] from d_out[M,d]; P is recomputed from the forward's row statistics; d_rowdot is a
 // [n_seq*H*S] scratch (D = rowsum(dO*O)) written by the dQ kernel and read by the dK/dV kernel.
@@ -34,7 +45,9 @@ hipError_t launch_attention_bwd(const float* qkv, const float* o_fwd, const floa
                                 int H, hipStream_t stream);
 
 // ---- elementwise.hip ------------------------------------------------------------------------
+// y_split (optional): the same output as split rows [rows][2d] for the f16-pipe GEMMs
 hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, float* y,
+                            _Float16* y_split, int* range_flag,
                             float* stats /* [rows][2] mean,rstd or null */, int rows, int d,
                             hipStream_t stream);
 // dx = LN backward of dy (optionally + extra residual gradient dres added to the result)

@@ -284,6 +284,7 @@ class GaussianDiffusion:
             stream = draws.take(len(indices)) if draws.active else None
             eng.sample_loop(img, indices[0], indices[-1], sampler=sampler_id, eta=eta,
                             noise_stream=stream, seed=seed)
+            eng.check_range()
             yield {"sample": img, "pred_xstart": None}
             return
 
@@ -298,6 +299,8 @@ class GaussianDiffusion:
             else:
                 self._generic_step(eng, model, img, i, sampler_id, eta, nz, pred, seed, model_kwargs)
             yield {"sample": img.clone(), "pred_xstart": pred}
+        if mdm is not None:
+            eng.check_range()
 
     def _generic_step(self, eng, model, img, i, sampler_id, eta, nz, pred, seed, model_kwargs):
         """Any callable denoiser: the model runs in torch, the sampler arithmetic in the engine."""

@@ -32,7 +32,7 @@ class Engine:
 
     def __init__(self, *, n_layers: int, d_model: int, d_ff: int, n_heads: int, n_feats: int,
                  max_frames: int, max_batch: int, pe_rows: int = 5000, text_cond: bool = False,
-                 want_grad: bool = False, device="cuda"):
+                 want_grad: bool = False, precision: Optional[str] = None, device="cuda"):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise N.NativeError(
@@ -42,13 +42,16 @@ class Engine:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.lib = N.load()
         self.desc = N.ModelDesc(n_layers, d_model, d_ff, n_heads, n_feats, max_frames, max_batch,
-                                pe_rows, int(text_cond), int(want_grad))
+                                pe_rows, int(text_cond), int(want_grad), N.PRECISIONS[precision])
         self.n_feats, self.max_frames, self.max_batch = n_feats, max_frames, max_batch
         self.want_grad = bool(want_grad)
         self.text_cond = bool(text_cond)
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             N.check(self.lib.cmdi_create(C.byref(self.desc), C.byref(self._h)))
+        # "f32" (exact fp32 MFMA) or "f16x3" (fp32-equivalent split-f16 MFMA); None = library default
+        self.precision = {N.CMDI_PREC_F32: "f32", N.CMDI_PREC_F16X3: "f16x3"}.get(
+            self.lib.cmdi_precision(self._h), "f32") if n_layers > 0 else "f32"
         self.n_steps = 0
         self.batch = 0
         self.n_frames = 0
@@ -78,6 +81,19 @@ class Engine:
 
     def workspace_bytes(self) -> int:
         return int(self.lib.cmdi_workspace_bytes(self._h))
+
+    def check_range(self):
+        """f16x3 only: raise if an activation left the f16 range since the last check (one 4-byte
+        read-back, synchronises the stream — call once per sampling chain)."""
+        if self.precision != "f16x3":
+            return
+        flag = C.c_int32(0)
+        with torch.cuda.device(self.device):
+            N.check(self.lib.cmdi_range_status(self._h, C.byref(flag), self.stream))
+        if flag.value:
+            raise N.NativeError(
+                "an activation left the f16 range (|x| >= 65504 or non-finite) in the split-f16 GEMM "
+                "path: results are invalid; re-run with precision='f32' (CMDI_PRECISION=f32)")
 
     def profile_enable(self, on: bool):
         N.check(self.lib.cmdi_profile_enable(self._h, int(on)))
@@ -271,6 +287,49 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
         N.check(lib.cmdi_gemm_nt(N.ptr(a), N.ptr(w), N.ptr(bias), N.ptr(resid), N.ptr(c), m, n, k,
                                  int(epi), int(tile), N.current_stream(a.device)))
     return c
+
+
+def split_f16(x: torch.Tensor) -> torch.Tensor:
+    """fp32 [rows, cols] -> split rows [rows, 2*cols] float16: hi | (x - hi) * 2^11 (test hook)."""
+    lib = N.load()
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2
+    x = x.contiguous()
+    out = torch.empty((x.shape[0], 2 * x.shape[1]), dtype=torch.float16, device=x.device)
+    with torch.cuda.device(x.device):
+        N.check(lib.cmdi_split_f16(N.ptr(x), N.ptr(out), x.shape[0], x.shape[1],
+                                   N.current_stream(x.device)))
+    return out
+
+
+def gemm_h3(a_split: torch.Tensor, w_split: torch.Tensor, bias: Optional[torch.Tensor] = None,
+            tile: int = 0, epi: int = 0, resid: Optional[torch.Tensor] = None,
+            split_out: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """C = epi(A · Wᵀ + bias) on the split-f16 path (test / bench hook); operands from split_f16().
+    epi 0 = bias, 1 = bias + GELU (always split output), 3 = bias + residual."""
+    lib = N.load()
+    assert a_split.dtype == torch.float16 and w_split.dtype == torch.float16
+    m, k2 = a_split.shape
+    n = w_split.shape[0]
+    assert w_split.shape[1] == k2 and k2 % 2 == 0
+    k = k2 // 2
+    split_out = split_out or epi == 1
+    if out is not None:
+        c = out
+    elif split_out:
+        c = torch.empty((m, 2 * n), dtype=torch.float16, device=a_split.device)
+    else:
+        c = torch.empty((m, n), dtype=torch.float32, device=a_split.device)
+    with torch.cuda.device(a_split.device):
+        N.check(lib.cmdi_gemm_h3(N.ptr(a_split), N.ptr(w_split), N.ptr(bias), N.ptr(resid),
+                                 0 if split_out else N.ptr(c), N.ptr(c) if split_out else 0, m, n, k,
+                                 int(epi), int(tile), N.current_stream(a_split.device)))
+    return c
+
+
+def unsplit_f16(s: torch.Tensor) -> torch.Tensor:
+    """Inverse of split_f16 (exact in float64, returned as fp32)."""
+    k = s.shape[1] // 2
+    return (s[:, :k].double() + s[:, k:].double() / 2048.0).float()
 
 
 def attention_fwd(qkv: torch.Tensor, n_seq: int, seq_len: int, n_heads: int) -> torch.Tensor:

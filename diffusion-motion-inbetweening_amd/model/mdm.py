@@ -186,8 +186,10 @@ class MDM(nn.Module):
         pe_rows = self.sequence_pos_encoder.pe.shape[0]
         n_time_rows = min(int(n_time_rows), pe_rows)
         eng = self._engine
+        precision = getattr(self, "native_precision", None)  # None = library default (f16x3)
         need_new = (eng is None or eng.device != device or eng.max_batch < max_batch
                     or eng.max_frames < max_frames or (want_grad and not eng.want_grad)
+                    or (precision is not None and eng.precision != precision)
                     or self._engine_key != self._weights_key(n_time_rows))
         if need_new:
             if eng is not None:
@@ -198,7 +200,7 @@ class MDM(nn.Module):
             eng = Engine(n_layers=self.num_layers, d_model=self.latent_dim, d_ff=self.ff_size,
                          n_heads=self.num_heads, n_feats=self.input_feats, max_frames=max_frames,
                          max_batch=max_batch, pe_rows=pe_rows, text_cond='text' in self.cond_mode,
-                         want_grad=want_grad, device=device)
+                         want_grad=want_grad, precision=precision, device=device)
             sd = {k: v for k, v in self.state_dict().items() if not k.startswith('clip_model.')}
             eng.load_state_dict(sd, n_time_rows=n_time_rows)
             self._engine = eng

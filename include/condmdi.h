@@ -34,8 +34,19 @@ enum {
     CMDI_E_STATE = -2,     /* call order violated (weights/schedule missing) */
     CMDI_E_HIP = -3,       /* a HIP runtime call failed                      */
     CMDI_E_NOMEM = -4,     /* workspace allocation failed                    */
-    CMDI_E_UNKNOWN_WEIGHT = -5
+    CMDI_E_UNKNOWN_WEIGHT = -5,
+    CMDI_E_RANGE = -6      /* a value left the f16 range of the split-f16 GEMM path      */
 };
+
+/* Arithmetic of the encoder-layer GEMMs.  Inputs, outputs and accumulation are IEEE fp32 in both
+ * modes; they differ in how the products are formed:
+ *   CMDI_PREC_F32    v_mfma_f32_32x32x2_f32, exact fp32 products (157 TFLOP/s peak);
+ *   CMDI_PREC_F16X3  every fp32 operand is carried as two f16 (hi, lo*2^11; 22 significant bits) and
+ *                    a product is three v_mfma_f32_32x32x16_f16 accumulated in fp32 — error below
+ *                    the fp32 accumulation roundoff of the same dot product, valid for |x| < 65504
+ *                    (checked: CMDI_E_RANGE at cmdi_finalize_weights, cmdi_range_status after a run).
+ *   CMDI_PREC_DEFAULT  F16X3 unless the environment variable CMDI_PRECISION=f32 is set. */
+enum { CMDI_PREC_DEFAULT = 0, CMDI_PREC_F32 = 1, CMDI_PREC_F16X3 = 2 };
 
 /* Model geometry.  Replaces the keyword arguments of MDM.__init__ (model/mdm.py:11-36) that the
  * trans_enc / hml_vec path reads, as produced by get_model_args (utils/model_util.py:40-119). */
@@ -50,6 +61,7 @@ typedef struct {
     int32_t pe_rows;     /* rows of sequence_pos_encoder.pe (5000)             */
     int32_t text_cond;   /* 1 if cond_mode contains 'text' (embed_text exists) */
     int32_t want_grad;   /* 1: allocate the activation stash for cmdi_mdm_vjp  */
+    int32_t precision;   /* CMDI_PREC_*                                        */
 } cmdi_model_desc;
 
 /* Model-output → x0 conventions (diffusion/gaussian_diffusion.py:74-95). */
@@ -179,6 +191,22 @@ int cmdi_randn(cmdi_handle h, float* d_out, int32_t batch, int64_t per_sample, u
 int cmdi_gemm_nt(const float* d_a, const float* d_w, const float* d_bias, const float* d_resid,
                  float* d_c, int32_t m, int32_t n, int32_t k, int32_t epi, int32_t tile,
                  cmdi_stream stream);
+/* The precision the handle runs at (CMDI_PREC_F32 or CMDI_PREC_F16X3). */
+int cmdi_precision(cmdi_handle h);
+/* F16X3 only: *out_flag = 1 if, since the last call, an activation left the f16 range (|x| >= 65504
+ * or non-finite) while being split; the results of that run are then invalid and the caller should
+ * re-run on an engine created with CMDI_PREC_F32.  SYNCHRONISES `stream` (one 4-byte read-back);
+ * call it once per sampling chain, not per step.  Clears the flag. */
+int cmdi_range_status(cmdi_handle h, int32_t* out_flag, cmdi_stream stream);
+/* Split-f16 GEMM family alone (test / bench hooks).  cmdi_split_f16: fp32 [rows, cols] -> split rows
+ * [rows, 2*cols] f16 (cols hi values, then cols values of (x - hi) * 2^11), cols % 8 == 0.
+ * cmdi_gemm_h3: C[M,N] = epi(A[M,K] · W[N,K]^T + bias[N]) with A, W in split rows; epi as in
+ * cmdi_gemm_nt (1 = bias + GELU writes split rows to d_c_split; 0 writes fp32 to d_c, or split rows
+ * if d_c_split != NULL); K % 64 == 0, N % 32 == 0. */
+int cmdi_split_f16(const float* d_src, void* d_dst, int64_t rows, int32_t cols, cmdi_stream stream);
+int cmdi_gemm_h3(const void* d_a_split, const void* d_w_split, const float* d_bias,
+                 const float* d_resid, float* d_c, void* d_c_split, int32_t m, int32_t n, int32_t k,
+                 int32_t epi, int32_t tile, cmdi_stream stream);
 /* Self-attention core alone (test / bench hook): d_qkv [n_seq*S, 3*H*128] -> d_out [n_seq*S, H*128]. */
 int cmdi_attention_fwd(const float* d_qkv, float* d_out, int32_t n_seq, int32_t seq_len,
                        int32_t n_heads, cmdi_stream stream);

@@ -1,6 +1,10 @@
 """Parity tests proper: the HIP engine (through the C-ABI and the public Python API) against the
 golden vectors of the REAL reference and against the numpy oracle.  Needs an MI355X: `-m gpu`.
 
+Every model-level test runs in BOTH arithmetic modes of the engine (include/condmdi.h CMDI_PREC_*):
+"f32" (exact fp32 MFMA products) and "f16x3" (fp32-equivalent split-f16 products, the default) —
+and both are held to the SAME tolerances.
+
 Stated fp32 tolerances (SURVEY.md §8c asks to state and measure them):
     one denoiser evaluation (8 layers, T<=196)  max-abs <= 1e-4, rel-L2 <= 2e-5 vs reference CPU
     input-VJP of the CFG denoiser               rel-L2 <= 5e-5
@@ -27,13 +31,17 @@ def tt(a, dev=DEV):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
-def make_model(case, cfg=None, layers=8):
+PRECISIONS = ["f16x3", "f32"]
+
+
+def make_model(case, cfg=None, layers=8, precision=None):
     mu = sub("utils.model_util")
     args = SimpleNamespace(dataset="humanml", unconstrained=not case["text"], layers=layers)
     model, _ = mu.create_model_and_diffusion(args, None)
     sd = weights.make_state_dict(case["weight_seed"], text=case["text"], n_layers=layers)
     mu.load_model_wo_clip(model, weights.to_torch(sd))
     model.to(DEV).eval()
+    model.native_precision = precision
     if cfg if cfg is not None else case.get("cfg", False):
         model = sub("model.cfg_sampler").ClassifierFreeSampleModel(model)
         model.eval()
@@ -76,6 +84,63 @@ def test_gemm_nt(tile, shape):
     assert rel_l2(out.numpy(), torch.nn.functional.gelu(ref).numpy()) <= 2e-6
 
 
+# ---- split-f16 (fp32-equivalent) GEMM family -------------------------------------------------------
+def test_split_f16_roundtrip():
+    """x = hi + lo * 2^-11 to 22 significant bits over the whole f16 range (abs floor 2^-35)."""
+    eng = sub("engine")
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(257, 512, generator=g) * torch.pow(10.0, torch.rand(257, 512, generator=g) * 9.5 - 6)
+    x[0, :8] = torch.tensor([0.0, -0.0, 65000.0, -65000.0, 1e-7, 6e-8, 2.0 ** -14, 1.0])
+    s = eng.split_f16(x.to(DEV))
+    assert s.shape == (257, 1024) and s.dtype == torch.float16
+    back = eng.unsplit_f16(s).cpu().double()
+    err = (back - x.double()).abs()
+    bound = torch.maximum(x.double().abs() * 2.0 ** -21.5, torch.tensor(2.0 ** -35, dtype=torch.float64))
+    assert bool((err <= bound).all()), float((err / bound).max())
+    assert torch.equal(s[:, :512].cpu(), x.half())  # hi plane = round-to-nearest f16
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("shape", [(333, 512, 512), (197 * 4, 1536, 512), (1000, 512, 1024)])
+def test_gemm_h3(tile, shape):
+    """Same inputs, same float64 reference and the same 2e-6 bound as the exact-fp32 kernels; the
+    split-f16 error must also stay within 1.5x of the fp32-MFMA kernel's own error."""
+    eng = sub("engine")
+    m, n, k = shape
+    g = torch.Generator().manual_seed(m * 7 + n)
+    a = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g) * (torch.arange(n).float()[:, None] % 7 + 1)  # asymmetric
+    b = torch.randn(n, generator=g)
+    r = torch.randn(m, n, generator=g)
+    ref = (a.double() @ w.double().T + b.double())
+    a_s, w_s = eng.split_f16(a.to(DEV)), eng.split_f16(w.to(DEV))
+    out = eng.gemm_h3(a_s, w_s, b.to(DEV), tile=tile).cpu()
+    e_h3 = rel_l2(out.numpy(), ref.numpy())
+    e_f32 = rel_l2(eng.gemm_nt(a.to(DEV), w.to(DEV), b.to(DEV)).cpu().numpy(), ref.numpy())
+    assert e_h3 <= 2e-6 and e_h3 <= 1.5 * e_f32 + 1e-8, (e_h3, e_f32)
+    out = eng.gemm_h3(a_s, w_s, b.to(DEV), tile=tile, epi=3, resid=r.to(DEV)).cpu()
+    assert rel_l2(out.numpy(), (ref + r.double()).numpy()) <= 2e-6
+    out = eng.unsplit_f16(eng.gemm_h3(a_s, w_s, b.to(DEV), tile=tile, epi=1)).cpu()
+    assert rel_l2(out.numpy(), torch.nn.functional.gelu(ref).numpy()) <= 2e-6
+    out = eng.unsplit_f16(eng.gemm_h3(a_s, w_s, b.to(DEV), tile=tile, split_out=True)).cpu()
+    assert rel_l2(out.numpy(), ref.numpy()) <= 2e-6
+
+
+def test_f16x3_range_guard():
+    """|x| >= 65504 cannot be split: weights are refused at finalize, activations raise after the run."""
+    N = sub("_native")
+    case = dict(text=False, weight_seed=5)
+    model, _ = make_model(case, layers=1, precision="f16x3")
+    with torch.no_grad():
+        model.seqTransEncoder.layers[0].linear1.weight[3, 7] = 7e4
+    with pytest.raises(N.NativeError, match="f16 range"):
+        model.engine(torch.device(DEV), max_batch=2, max_frames=20)
+    model.native_precision = "f32"   # the exact-fp32 mode takes the same weights
+    model.invalidate_engine()
+    out = model(torch.randn(2, 263, 1, 20, device=DEV), torch.tensor([5, 9], device=DEV), y={})
+    assert torch.isfinite(out).all()
+
+
 # ---- attention -----------------------------------------------------------------------------------
 @pytest.mark.parametrize("S", [197, 61, 16, 17, 224, 33])
 def test_attention_core_vs_torch(S):
@@ -105,22 +170,26 @@ def test_engine_rng_matches_oracle():
 
 
 # ---- denoiser --------------------------------------------------------------------------------------
-def test_forward_uncond_vs_reference(cases):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_forward_uncond_vs_reference(cases, precision):
     case = cases.CASES["fwd_uncond"]
     inp = cases.make_inputs(case)
     check_fingerprint(cases, "fwd_uncond", inp)
-    model, sd = make_model(case)
+    model, sd = make_model(case, precision=precision)
+    assert model.engine(torch.device(DEV), max_batch=inp["x"].shape[0],
+                        max_frames=inp["x"].shape[-1]).precision == precision
     out = model(tt(inp["x"]), tt(inp["t"]), y={}).cpu().numpy()
     ref = load_golden("fwd_uncond")["out"]
     assert max_abs(out, ref) <= 1e-4 and rel_l2(out, ref) <= 2e-5, (max_abs(out, ref), rel_l2(out, ref))
     assert rel_l2(out, MDMOracle(sd).forward(inp["x"], inp["t"])) <= 2e-5
 
 
-def test_forward_text_cfg_vs_reference(cases):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_forward_text_cfg_vs_reference(cases, precision):
     case = cases.CASES["fwd_text"]
     inp = cases.make_inputs(case)
     check_fingerprint(cases, "fwd_text", inp)
-    model, _ = make_model(case, cfg=False)
+    model, _ = make_model(case, cfg=False, precision=precision)
     g = load_golden("fwd_text")
     x, t = tt(inp["x"]), tt(inp["t"])
     y = {"text_embed": tt(inp["enc_text"])}
@@ -133,11 +202,12 @@ def test_forward_text_cfg_vs_reference(cases):
             (key, max_abs(mine, g[key]), rel_l2(mine, g[key]))
 
 
-def test_vjp_vs_reference_autograd(cases):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_vjp_vs_reference_autograd(cases, precision):
     case = cases.CASES["vjp_text_cfg"]
     inp = cases.make_inputs(case)
     check_fingerprint(cases, "vjp_text_cfg", inp)
-    model, _ = make_model(case)
+    model, _ = make_model(case, precision=precision)
     mdm = model.model
     B, _, _, T = inp["x"].shape
     eng = mdm.engine(torch.device(DEV), max_batch=B, max_frames=T, want_grad=True)
@@ -185,11 +255,11 @@ def test_sampler_update_bit_exact(sampler, eta, mode):
 
 
 # ---- chains through the public API -----------------------------------------------------------------
-def run_chain(cases, name):
+def run_chain(cases, name, precision):
     case = cases.CASES[name]
     inp = cases.make_inputs(case)
     check_fingerprint(cases, name, inp)
-    model, _ = make_model(case)
+    model, _ = make_model(case, precision=precision)
     diffusion = make_diffusion(case["respacing"])
     B = inp["x_T"].shape[0]
     y = {"mask": tt(inp["len_mask"]), "lengths": tt(inp["lengths"])}
@@ -215,8 +285,9 @@ def run_chain(cases, name):
 
 @pytest.mark.parametrize("name", ["chain_uncond_ddpm", "chain_impute_only", "chain_edit_recon",
                                   "chain_ddim_eta0", "chain_ddim_eta05", "chain_skip_init"])
-def test_chain_vs_reference(cases, name):
-    final, dumps, g = run_chain(cases, name)
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_chain_vs_reference(cases, name, precision):
+    final, dumps, g = run_chain(cases, name, precision)
     assert rel_l2(final, g["final"]) <= 1e-4, rel_l2(final, g["final"])
     assert len(dumps) == g["pred_xstart"].shape[0]
     for k, d in enumerate(dumps):
@@ -224,9 +295,10 @@ def test_chain_vs_reference(cases, name):
 
 
 # ---- full-size properties (BASELINE config 2 shape: B=32, T=196, CFG) --------------------------------
-def test_full_size_batch_independence_and_sharding():
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_full_size_batch_independence_and_sharding(precision):
     case = dict(text=True, weight_seed=21, cfg=True)
-    model, _ = make_model(case)
+    model, _ = make_model(case, precision=precision)
     diffusion = make_diffusion([4])  # 4 steps of the 1000-step chain: t = 0, 333, 666, 999
     B, T = 32, 196
     rng = np.random.default_rng(5)

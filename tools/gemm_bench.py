@@ -31,7 +31,9 @@ def main():
     shapes = [(M, 1536, 512, 0, "in_proj"), (M, 512, 512, 3, "out_proj+res"),
               (M, 1024, 512, 1, "linear1+gelu"), (M, 512, 1024, 3, "linear2+res"),
               (2 * 256 * 197, 1536, 512, 0, "in_proj B=256"), (4096, 4096, 4096, 0, "4096^3")]
-    print("tiles: 1=128x128 2=64x128 3=128x64 4=64x64 5=256x128(8w); +10 = pipelined loop")
+    h3_tiles = [int(t) for t in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1, 2, 3, 4, 5, 6, 7]
+    print("tiles: 1=128x128 2=64x128 3=128x64 4=64x64 5=256x128(8w); +10 = pipelined loop; "
+          "hN = split-f16 family (fp32-equivalent TFLOP/s = 2MNK/t; executed f16 flops are 3x)")
     for (m, n, k, epi, name) in shapes:
         a = torch.randn(m, k, device=dev)
         w = torch.randn(n, k, device=dev)
@@ -42,6 +44,12 @@ def main():
         for tile in tiles:
             dt = timeit(lambda: eng.gemm_nt(a, w, b, tile=tile, epi=epi, resid=r, out=c), iters=iters)
             row.append(f"t{tile}:{2.0 * m * n * k / dt / 1e12:6.1f}")
+        a_s, w_s = eng.split_f16(a), eng.split_f16(w)
+        cs = torch.empty(m, 2 * n, device=dev, dtype=torch.float16)
+        for tile in h3_tiles:
+            o = cs if epi == 1 else c
+            dt = timeit(lambda: eng.gemm_h3(a_s, w_s, b, tile=tile, epi=epi, resid=r, out=o), iters=iters)
+            row.append(f"h{tile}:{2.0 * m * n * k / dt / 1e12:6.1f}")
         print(f"{name:14s} M={m:6d} N={n:5d} K={k:5d}  " + " ".join(row), flush=True)
 
 
