@@ -24,6 +24,7 @@ UNITS = {
     "gemm_f32.hip": [],
     "gemm_h3.hip": [],
     "attention_f32.hip": [],
+    "attention_h3.hip": [],
     "attention_bwd_f32.hip": [],
     "elementwise.hip": [],
     # reference evaluation order, every op rounded separately (see the header of sampler.hip)

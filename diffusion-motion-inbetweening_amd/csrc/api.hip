@@ -86,7 +86,7 @@ struct cmdi_engine {
     // precision of the encoder-layer GEMMs: CMDI_PREC_F32 (exact fp32 MFMA) or CMDI_PREC_F16X3
     // (fp32-equivalent split-f16 products on the f16 matrix pipe, gemm_h3.hpp)
     int precision = CMDI_PREC_F16X3;
-    _Float16 *tokS = nullptr, *bufHS = nullptr, *attnS = nullptr, *ffnS = nullptr;
+    _Float16 *tokS = nullptr, *bufHS = nullptr, *attnS = nullptr, *ffnS = nullptr, *qkvS = nullptr;
     int* range_flag = nullptr;
     int h3_tile_qkv = 0, h3_tile_proj = 0, h3_tile_ffn1 = 0, h3_tile_ffn2 = 0;
     int gemm_tile = 0;
@@ -151,6 +151,7 @@ int run_layers(cmdi_engine* e, int seq0, int nseq, bool keep, bool prof, hipStre
     _Float16* bufHS = h3 ? e->bufHS + r0 * 2 * d : nullptr;
     _Float16* attnS = h3 ? e->attnS + r0 * 2 * d : nullptr;
     _Float16* ffnS = h3 ? e->ffnS + r0 * 2 * f : nullptr;
+    _Float16* qkvS = h3 ? e->qkvS + r0 * 6 * d : nullptr;
     auto hp = [&](const _Float16* A, const _Float16* W, const float* bias, float* C, _Float16* Cs,
                   int N, int K) {
         H3Params p{};
@@ -181,15 +182,18 @@ int run_layers(cmdi_engine* e, int seq0, int nseq, bool keep, bool prof, hipStre
                 }
                 HIPCHK(hipEventRecord(e->ev_pool[e->ev_used], s));
             }
-            HIPCHK(launch_gemm_h3(H3_PLAIN, hp(tokS, w.in_ws, w.in_b, qkv, nullptr, 3 * d, d),
-                                  e->h3_tile_qkv, s));
+            {   // qkv leaves as split rows for the f16-pipe attention (+ an fp32 copy for the backward)
+                H3Params p = hp(tokS, w.in_ws, w.in_b, nullptr, qkvS, 3 * d, d);
+                p.aux = keep ? qkv : nullptr;
+                HIPCHK(launch_gemm_h3(H3_PLAIN_SPLIT, p, e->h3_tile_qkv, s));
+            }
             if (prof) {
                 HIPCHK(hipEventRecord(e->ev_pool[e->ev_used + 1], s));
                 e->ev_used += 2;
                 e->prof_m = M; e->prof_n = 3 * d; e->prof_k = d;
             }
-            HIPCHK(launch_attention_fwd(qkv, keep ? attn : nullptr, attnS, e->range_flag, row_stats,
-                                        nseq, S, e->H, s));
+            HIPCHK(launch_attention_h3(qkvS, keep ? attn : nullptr, attnS, e->range_flag, row_stats,
+                                       nseq, S, e->H, s));
             {
                 H3Params p = hp(attnS, w.out_ws, w.out_b, pre1, nullptr, d, d);
                 p.R = tokA;
@@ -486,8 +490,8 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
         }
         if (prec != CMDI_PREC_F32 && prec != CMDI_PREC_F16X3)
             return fail(CMDI_E_INVALID, "precision must be CMDI_PREC_DEFAULT, _F32 or _F16X3");
-        if (prec == CMDI_PREC_F16X3 && (desc->d_model % 64 != 0 || desc->d_ff % 64 != 0))
-            return fail(CMDI_E_INVALID, "f16x3 precision needs d_model and d_ff multiples of 64");
+        if (prec == CMDI_PREC_F16X3 && (desc->d_model % 32 != 0 || desc->d_ff % 32 != 0))
+            return fail(CMDI_E_INVALID, "f16x3 precision needs d_model and d_ff multiples of 32");
         e->precision = prec;
     }
     e->h3_tile_qkv = env_int("CMDI_H3_TILE_QKV", env_int("CMDI_H3_TILE", 0));
@@ -533,7 +537,7 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
             ALLOC(w.l1_ws, (size_t)f * d * 2); ALLOC(w.l2_ws, (size_t)d * f * 2);
         }
         ALLOC(e->tokS, Mmax * d * 2); ALLOC(e->bufHS, Mmax * d * 2);
-        ALLOC(e->attnS, Mmax * d * 2); ALLOC(e->ffnS, Mmax * f * 2);
+        ALLOC(e->attnS, Mmax * d * 2); ALLOC(e->ffnS, Mmax * f * 2); ALLOC(e->qkvS, Mmax * 3 * d * 2);
     }
     if (desc->want_grad) {
         ALLOC(e->w_inT, (size_t)C * d); ALLOC(e->w_outT_pad, (size_t)d * e->Cpad);
@@ -943,8 +947,8 @@ int cmdi_range_status(cmdi_handle e, int32_t* out_flag, cmdi_stream stream) {
 }
 
 int cmdi_split_f16(const float* d_src, void* d_dst, int64_t rows, int32_t cols, cmdi_stream stream) {
-    if (!d_src || !d_dst || rows < 1 || cols < 8 || cols % 8 != 0)
-        return fail(CMDI_E_INVALID, "bad argument (cols must be a positive multiple of 8)");
+    if (!d_src || !d_dst || rows < 1 || cols < 32 || cols % 32 != 0)
+        return fail(CMDI_E_INVALID, "bad argument (cols must be a positive multiple of 32)");
     HIPCHK(launch_split_f16(d_src, static_cast<_Float16*>(d_dst), rows, cols, cols, nullptr,
                             static_cast<hipStream_t>(stream)));
     return CMDI_OK;
@@ -954,12 +958,13 @@ int cmdi_gemm_h3(const void* d_a_split, const void* d_w_split, const float* d_bi
                  const float* d_resid, float* d_c, void* d_c_split, int32_t m, int32_t n, int32_t k,
                  int32_t epi, int32_t tile, cmdi_stream stream) {
     if (!d_a_split || !d_w_split) return fail(CMDI_E_INVALID, "null tensor");
-    if (k % 64 != 0 || n % 32 != 0) return fail(CMDI_E_INVALID, "K must be a multiple of 64, N of 32");
+    if (k % 32 != 0 || n % 32 != 0) return fail(CMDI_E_INVALID, "K and N must be multiples of 32");
     H3Params p{};
     p.A = static_cast<const _Float16*>(d_a_split);
     p.W = static_cast<const _Float16*>(d_w_split);
     p.bias = d_bias; p.C = d_c; p.Cs = static_cast<_Float16*>(d_c_split); p.R = d_resid;
     p.M = m; p.N = n; p.K = k; p.ldc = n;
+    { const char* v = std::getenv("CMDI_H3_DBG"); p.dbg = v ? std::atoi(v) : 0; }
     int kind;
     switch (epi) {
         case 0: kind = d_c_split ? H3_PLAIN_SPLIT : H3_PLAIN; break;
@@ -973,6 +978,15 @@ int cmdi_gemm_h3(const void* d_a_split, const void* d_w_split, const float* d_bi
     if (kind == H3_RESID && !d_resid) return fail(CMDI_E_INVALID, "residual epilogue needs d_resid");
     hipError_t err = launch_gemm_h3(kind, p, tile, static_cast<hipStream_t>(stream));
     if (err != hipSuccess) return fail(CMDI_E_HIP, std::string("launch_gemm_h3: ") + hipGetErrorString(err));
+    return CMDI_OK;
+}
+
+int cmdi_attention_fwd_h3(const void* d_qkv_split, float* d_out, int32_t n_seq, int32_t seq_len,
+                          int32_t n_heads, cmdi_stream stream) {
+    if (!d_qkv_split || !d_out || n_seq < 1 || seq_len < 1 || seq_len > 224 || n_heads < 1)
+        return fail(CMDI_E_INVALID, "bad argument");
+    HIPCHK(launch_attention_h3(static_cast<const _Float16*>(d_qkv_split), d_out, nullptr, nullptr,
+                               nullptr, n_seq, seq_len, n_heads, static_cast<hipStream_t>(stream)));
     return CMDI_OK;
 }
 

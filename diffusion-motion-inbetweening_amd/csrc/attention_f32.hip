@@ -199,8 +199,8 @@ __global__ __launch_bounds__(512, 4) void attention_fwd_kernel(const float* __re
                         make_float4(o[db][0] * inv, o[db][1] * inv, o[db][2] * inv, o[db][3] * inv);
             }
             if (out_s) {
-                // split rows for the out_proj GEMM on the f16 pipe (gemm_h3.hpp): [hi(d) | lo(d)]
-                _Float16* ob = out_s + ((size_t)b * S + q) * (2 * d_model) + h * DH + 4 * g;
+                // split rows for the out_proj GEMM on the f16 pipe (format: gemm_h3.hpp)
+                _Float16* ob = out_s + ((size_t)b * S + q) * (2 * d_model) + split_pos(h * DH + 4 * g);
                 bool overflow = false;
 #pragma unroll
                 for (int db = 0; db < 8; ++db) {
@@ -213,8 +213,9 @@ __global__ __launch_bounds__(512, 4) void attention_fwd_kernel(const float* __re
                         oh[e] = a; ol[e] = c;
                         overflow |= !(fabsf(v) < 65504.0f);
                     }
-                    *reinterpret_cast<h4*>(ob + db * 16) = oh;
-                    *reinterpret_cast<h4*>(ob + d_model + db * 16) = ol;
+                    // dims advance by 16 per db: two db per 32-column chunk (64 halves)
+                    *reinterpret_cast<h4*>(ob + (db >> 1) * 64 + (db & 1) * 16) = oh;
+                    *reinterpret_cast<h4*>(ob + (db >> 1) * 64 + (db & 1) * 16 + 32) = ol;
                 }
                 if (overflow && range_flag) atomicOr(range_flag, 1);
             }

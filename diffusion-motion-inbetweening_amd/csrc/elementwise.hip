@@ -64,9 +64,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                 oh[e] = a; ol[e] = c;
                 overflow |= !(fabsf(ov[e]) < 65504.0f);
             }
-            _Float16* d = ys + (size_t)row * (2 * D) + i * 256 + lane * 4;
+            _Float16* d = ys + (size_t)row * (2 * D) + split_pos(i * 256 + lane * 4);
             *reinterpret_cast<h4*>(d) = oh;
-            *reinterpret_cast<h4*>(d + D) = ol;
+            *reinterpret_cast<h4*>(d + 32) = ol;
             if (overflow && range_flag) atomicOr(range_flag, 1);
         }
     }

@@ -5,13 +5,15 @@
 
 namespace cmdi {
 
-using H128x128k32 = H3Tile<128, 128, 32, 2, 2, 2>;   // 4 waves, 64x64 per wave, 64 KiB LDS, 2 blocks/CU
-using H128x128k64 = H3Tile<128, 128, 64, 2, 2, 1>;   // 128 KiB LDS, 1 block/CU
-using H256x128k32 = H3Tile<256, 128, 32, 4, 2, 2>;   // 8 waves, 64x64 per wave, 96 KiB LDS
-using H128x64k32 = H3Tile<128, 64, 32, 2, 2, 2>;     // 64x32 per wave, 48 KiB LDS, 3 blocks/CU
-using H128x64k64 = H3Tile<128, 64, 64, 2, 2, 2>;     // 96 KiB LDS
-using H64x128k32 = H3Tile<64, 128, 32, 2, 2, 2>;     // 32x64 per wave
-using H128x128k32w8 = H3Tile<128, 128, 32, 4, 2, 2>; // 8 waves, 32x64 per wave
+using H128x128s2 = H3Tile<128, 128, 2, 2, 2, 2>;    // 4 waves, 64x64 per wave, 64 KiB LDS, 2 blocks/CU
+using H256x128s3 = H3Tile<256, 128, 4, 2, 3, 2>;    // 8 waves, 64x64 per wave, 3 stages = 144 KiB
+using H256x128s2 = H3Tile<256, 128, 4, 2, 2, 2>;    // 8 waves, 96 KiB
+using H128x64s2 = H3Tile<128, 64, 2, 2, 2, 2>;      // 64x32 per wave, 48 KiB, 3 blocks/CU
+using H128x64s3 = H3Tile<128, 64, 2, 2, 3, 2>;      // 72 KiB, 2 blocks/CU
+using H64x128s2 = H3Tile<64, 128, 2, 2, 2, 2>;      // 32x64 per wave
+using H128x128w8s3 = H3Tile<128, 128, 4, 2, 3, 2>;  // 8 waves, 32x64 per wave, 96 KiB
+using H128x128w8s2 = H3Tile<128, 128, 4, 2, 2, 2>;  // 8 waves, 64 KiB, 2 blocks/CU (16 waves)
+using H128x256s2 = H3Tile<128, 256, 2, 4, 2, 2>;    // 8 waves, 64x64 per wave, 96 KiB
 
 template <class TC, int EPI>
 static hipError_t launch_h3_one(const H3Params& p, hipStream_t stream) {
@@ -32,24 +34,28 @@ static hipError_t launch_h3_one(const H3Params& p, hipStream_t stream) {
 template <int EPI>
 static hipError_t launch_h3_tiles(const H3Params& p, int tile, hipStream_t s) {
     switch (tile) {
-        case 1: return launch_h3_one<H128x128k32, EPI>(p, s);
-        case 2: return launch_h3_one<H128x128k64, EPI>(p, s);
-        case 3: return launch_h3_one<H256x128k32, EPI>(p, s);
-        case 4: return launch_h3_one<H128x64k32, EPI>(p, s);
-        case 5: return launch_h3_one<H128x64k64, EPI>(p, s);
-        case 6: return launch_h3_one<H64x128k32, EPI>(p, s);
-        case 7: return launch_h3_one<H128x128k32w8, EPI>(p, s);
+        case 1: return launch_h3_one<H128x128s2, EPI>(p, s);
+        case 2: return launch_h3_one<H256x128s3, EPI>(p, s);
+        case 3: return launch_h3_one<H256x128s2, EPI>(p, s);
+        case 4: return launch_h3_one<H128x64s2, EPI>(p, s);
+        case 5: return launch_h3_one<H128x64s3, EPI>(p, s);
+        case 6: return launch_h3_one<H64x128s2, EPI>(p, s);
+        case 7: return launch_h3_one<H128x128w8s3, EPI>(p, s);
+        case 8: return launch_h3_one<H128x128w8s2, EPI>(p, s);
+        case 9: return launch_h3_one<H128x256s2, EPI>(p, s);
         default: return hipErrorInvalidValue;
     }
 }
 
+// Measured on MI355X at the denoiser's shapes (M = 12,608; tools/gemm_bench.py): 128x128 with 8 waves
+// (32x64 per wave), 2 stages, 2 blocks = 16 waves per CU wins every projection.
 int gemm_h3_auto_tile(int M, int N) {
-    (void)M;
-    return N >= 1024 ? 1 : 4;
+    (void)M; (void)N;
+    return 8;
 }
 
 hipError_t launch_gemm_h3(int epi, const H3Params& p, int tile, hipStream_t s) {
-    if (p.K % 64 != 0 || p.N % 8 != 0 || p.M <= 0 || p.N <= 0) return hipErrorInvalidValue;
+    if (p.K % 32 != 0 || p.N % 8 != 0 || p.M <= 0 || p.N <= 0) return hipErrorInvalidValue;
     if (tile == 0) tile = gemm_h3_auto_tile(p.M, p.N);
     switch (epi) {
         case H3_PLAIN: return launch_h3_tiles<H3_PLAIN>(p, tile, s);
@@ -60,7 +66,8 @@ hipError_t launch_gemm_h3(int epi, const H3Params& p, int tile, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 
-// fp32 rows [rows][cols] (row stride ld_src floats) -> split rows [rows][2*cols] halves.  One thread
+// fp32 rows [rows][cols] (row stride ld_src floats) -> split rows [rows][2*cols] halves (32-column
+// chunks, hi then lo, see gemm_h3.hpp).  One thread
 // converts 8 consecutive elements: two float4 loads, one 16-B store per plane.  HBM-bound.
 __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ src,
                                                         _Float16* __restrict__ dst, int64_t rows,
@@ -83,15 +90,15 @@ __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict_
         oh[e] = h; ol[e] = l;
         overflow |= !(fabsf(v[e]) < 65504.0f);
     }
-    _Float16* d = dst + r * (2 * (int64_t)cols) + c;
+    _Float16* d = dst + r * (2 * (int64_t)cols) + split_pos(c);
     *reinterpret_cast<h8*>(d) = oh;
-    *reinterpret_cast<h8*>(d + cols) = ol;
+    *reinterpret_cast<h8*>(d + 32) = ol;
     if (overflow && range_flag) atomicOr(range_flag, 1);
 }
 
 hipError_t launch_split_f16(const float* src, _Float16* dst, int64_t rows, int cols, int64_t ld_src,
                             int* range_flag, hipStream_t stream) {
-    if (cols % 8 != 0 || ld_src % 4 != 0) return hipErrorInvalidValue;
+    if (cols % 32 != 0 || ld_src % 4 != 0) return hipErrorInvalidValue;
     const int64_t n = rows * (cols >> 3);
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(split_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src,

@@ -12,12 +12,15 @@
 // same tolerances as the exact-fp32 kernels, and tools/split_accuracy.py shows the error against
 // float64 (f16x3: 2.6e-7 rel-L2 on a full denoiser evaluation; numpy fp32: 4.9e-7).
 //
-// Operand format ("split rows"): row r of a [rows, K] matrix is 2K halves — K hi values followed by
-// K lo values — so a split matrix occupies exactly the bytes of its fp32 original.
+// Operand format ("split rows"): row r of a [rows, K] matrix is 2K halves, interleaved in chunks of
+// 32 columns — [hi k0..31 | lo k0..31 | hi k32..63 | lo k32..63 | ...] — so a split matrix occupies
+// exactly the bytes of its fp32 original and one K step of 32 columns is ONE contiguous 128-byte
+// line per row holding both planes (full-line LDS-DMA fetches, 8 rows per 1-KiB wave-instruction).
 //
-// Roles are swapped inside the MFMA (W rows feed the A operand, activation rows the B operand): a
-// lane's 16 accumulators are then 4 runs of 4 CONSECUTIVE output columns n of ONE row m, and the
-// epilogue loads bias / residual and stores C as float4 (split outputs as 8-byte half4).
+// Epilogue: the accumulators (lane = one column of 16 rows per fragment) are transposed through the
+// wave's private slice of the now idle LDS stages, 32 rows at a time, and leave as row-major float4:
+// every global instruction (bias / residual loads, C stores) covers whole 128- or 256-byte row
+// segments (split outputs: the hi and the lo half of whole 128-byte chunks).
 #pragma once
 #include "common.hpp"
 #include "gemm_params.hpp"
@@ -30,31 +33,37 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 constexpr float kLoScale = 2048.0f;          // 2^11
 constexpr float kLoInv = 1.0f / 2048.0f;
 
+// position (in halves) of column k's hi value inside a split row; its lo value is 32 further on
+__host__ __device__ __forceinline__ int split_pos(int k) { return ((k >> 5) << 6) + (k & 31); }
+
 __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
     hi = (_Float16)x;                         // round to nearest even
     lo = (_Float16)((x - (float)hi) * kLoScale);
 }
 
-template <int BM_, int BN_, int BK_, int WM_, int WN_, int MINW_>
+template <int BM_, int BN_, int WM_, int WN_, int NSTAGE_, int MINW_>
 struct H3Tile {
-    static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, MINW = MINW_;
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, NSTAGE = NSTAGE_, MINW = MINW_;
+    static constexpr int BK = 32;                  // columns per K step = one 128-B line per row
     static constexpr int NW = WM * WN, NT = 64 * NW;
     static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    static constexpr int RB = BK * 2;              // bytes per tile row per plane
-    static constexpr int SL = RB / 16;             // 16-B slots per row
-    static constexpr int RPB = 16 / SL;            // rows per 256-B bank row
-    static constexpr int PROWS = 1024 / RB;        // rows per LDS-DMA piece (one wave-instruction)
-    static constexpr int STAGE = 2 * (BM + BN) * RB;   // bytes: A_hi, A_lo, W_hi, W_lo
-    static constexpr size_t LDS_BYTES = 2ull * STAGE;
-    static_assert(BK == 32 || BK == 64, "BK");
+    static constexpr int STAGE = (BM + BN) * 128;  // bytes: A rows then W rows, 128 B each
+    static constexpr int PW = (BM + BN) / 8 / NW;  // LDS-DMA pieces (1 KiB = 8 rows) per wave per stage
+    static constexpr size_t LDS_BYTES = (size_t)NSTAGE * STAGE;
+    static_assert(NSTAGE == 2 || NSTAGE == 3, "NSTAGE");
     static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "wave tile must be 32-aligned");
-    static_assert((BM / PROWS) % NW == 0 && (BN / PROWS) % NW == 0, "DMA pieces per wave");
+    static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "DMA pieces per wave");
 };
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
 template <class TC, int EPI>
 __global__ __launch_bounds__(TC::NT, TC::MINW) void gemm_h3_kernel(const H3Params p) {
-    constexpr int BM = TC::BM, BN = TC::BN, BK = TC::BK, TM = TC::TM, TN = TC::TN, NW = TC::NW;
-    constexpr int RB = TC::RB, SL = TC::SL, RPB = TC::RPB, PROWS = TC::PROWS, STAGE = TC::STAGE;
+    constexpr int BM = TC::BM, BN = TC::BN, TM = TC::TM, TN = TC::TN, NW = TC::NW;
+    constexpr int STAGE = TC::STAGE, NSTAGE = TC::NSTAGE, PW = TC::PW;
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -65,123 +74,150 @@ __global__ __launch_bounds__(TC::NT, TC::MINW) void gemm_h3_kernel(const H3Param
     const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
 
-    f32x16 acc0[TN][TM], acc1[TN][TM];   // [W fragment (rows n)][A fragment (cols m)]
+    f32x16 acc0[TM][TN], acc1[TM][TN];   // [A fragment (rows m)][W fragment (cols n)]
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc0[j][i][r] = 0.f; acc1[j][i][r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { acc0[i][j][r] = 0.f; acc1[i][j][r] = 0.f; }
 
-    // ---- LDS-DMA staging: HBM/L2 -> LDS, lane-linear 1-KiB pieces, swizzle on the SOURCE address:
-    // the 16-B slot c of tile row r is stored at slot position c ^ ((r / RPB) % SL), so that the 16
-    // rows of a ds_read_b128 lane group cover all 16 slots of a 256-B bank row.
-    const int prow = lane / SL, pslot = lane % SL;
-    const int K = p.K;
+    // ---- LDS-DMA staging: HBM/L2 -> LDS in lane-linear 1-KiB pieces (8 rows x 128 B).  The bank
+    // swizzle sits on the SOURCE address: the 16-B slot c of tile row r is stored at slot position
+    // c ^ ((r >> 1) & 7), so the 16 rows of a ds_read_b128 lane group cover all 16 slots of a 256-B
+    // bank row.  Slots 0-3 of a row are the hi plane, 4-7 the lo plane.
+    const int prow = lane >> 3, pslot = lane & 7;
+    const size_t ldk = 2 * (size_t)p.K;
+    const _Float16* a_src[BM / 8 / NW];
+    const _Float16* w_src[BN / 8 / NW];
+#pragma unroll
+    for (int q = 0; q < BM / 8 / NW; ++q) {
+        const int row = (q * NW + wave) * 8 + prow;
+        int grow = m0 + row;
+        grow = grow < p.M ? grow : p.M - 1;
+        a_src[q] = p.A + (size_t)grow * ldk + ((pslot ^ ((row >> 1) & 7)) << 3);
+    }
+#pragma unroll
+    for (int q = 0; q < BN / 8 / NW; ++q) {
+        const int row = (q * NW + wave) * 8 + prow;
+        int grow = n0 + row;
+        grow = grow < p.N ? grow : p.N - 1;
+        w_src[q] = p.W + (size_t)grow * ldk + ((pslot ^ ((row >> 1) & 7)) << 3);
+    }
     auto issue = [&](int kt, int buf) {
         char* stage = lds + buf * STAGE;
 #pragma unroll
-        for (int plane = 0; plane < 2; ++plane) {
+        for (int q = 0; q < BM / 8 / NW; ++q)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(a_src[q] + kt * 64),
+                (__attribute__((address_space(3))) void*)(stage + (q * NW + wave) * 1024), 16, 0, 0);
 #pragma unroll
-            for (int g0 = 0; g0 < BM / PROWS; g0 += NW) {
-                const int g = g0 + wave;
-                const int row = g * PROWS + prow;
-                const int c = pslot ^ ((row / RPB) % SL);
-                int grow = m0 + row;
-                grow = grow < p.M ? grow : p.M - 1;
-                const _Float16* src = p.A + (size_t)grow * (2 * K) + plane * K + kt * BK + c * 8;
-                char* dst = stage + plane * BM * RB + g * 1024;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int plane = 0; plane < 2; ++plane) {
-#pragma unroll
-            for (int g0 = 0; g0 < BN / PROWS; g0 += NW) {
-                const int g = g0 + wave;
-                const int row = g * PROWS + prow;
-                const int c = pslot ^ ((row / RPB) % SL);
-                int grow = n0 + row;
-                grow = grow < p.N ? grow : p.N - 1;
-                const _Float16* src = p.W + (size_t)grow * (2 * K) + plane * K + kt * BK + c * 8;
-                char* dst = stage + 2 * BM * RB + plane * BN * RB + g * 1024;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-            }
-        }
+        for (int q = 0; q < BN / 8 / NW; ++q)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(w_src[q] + kt * 64),
+                (__attribute__((address_space(3))) void*)(stage + BM * 128 + (q * NW + wave) * 1024), 16, 0, 0);
     };
 
-    const int swz = (l31 / RPB) % SL;
-    int poff[BK / 16];   // byte offset inside a tile row of this lane's slot for k-substep ks
+    const int swz = (l31 >> 1) & 7;
+    int off_hi[2], off_lo[2];   // byte offset inside a tile row of this lane's slot for k-substep ks
 #pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) poff[ks] = ((2 * ks + hi) ^ swz) * 16;
-    const int a_row = (wm * TM * 32 + l31) * RB;    // + i * 32 * RB
-    const int w_row = (wn * TN * 32 + l31) * RB;    // + j * 32 * RB
+    for (int ks = 0; ks < 2; ++ks) {
+        off_hi[ks] = ((2 * ks + hi) ^ swz) * 16;
+        off_lo[ks] = ((4 + 2 * ks + hi) ^ swz) * 16;
+    }
+    const int a_row = (wm * TM * 32 + l31) * 128;            // + i * 32 * 128
+    const int w_row = BM * 128 + (wn * TN * 32 + l31) * 128;  // + j * 32 * 128
 
-    const int nk = K / BK;
-    issue(0, 0);
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
-        const char* st = lds + cur * STAGE;
-        const char* a_hi = st + a_row;
-        const char* a_lo = a_hi + BM * RB;
-        const char* w_hi = st + 2 * BM * RB + w_row;
-        const char* w_lo = w_hi + BN * RB;
+    const int nk = p.K / 32;
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            h8 ah[TM], al[TM], wh[TN], wl[TN];
+    for (int s = 0; s < NSTAGE - 1; ++s)
+        if (s < nk) issue(s, s);
+    if (NSTAGE == 3 && nk > 1) wait_vmcnt<PW>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+
+    int cur = 0, nxt = NSTAGE - 1;   // stage being multiplied / stage being filled
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + NSTAGE - 1 < nk;
+        if (more && !(p.dbg & 1)) issue(kt + NSTAGE - 1, nxt);
+        const char* st = lds + cur * STAGE;
+        h8 ah[2][TM], al[2][TM], wh[2][TN], wl[2][TN];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                ah[i] = *reinterpret_cast<const h8*>(a_hi + i * 32 * RB + poff[ks]);
-                al[i] = *reinterpret_cast<const h8*>(a_lo + i * 32 * RB + poff[ks]);
+                ah[ks][i] = *reinterpret_cast<const h8*>(st + a_row + i * 4096 + off_hi[ks]);
+                al[ks][i] = *reinterpret_cast<const h8*>(st + a_row + i * 4096 + off_lo[ks]);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                wh[j] = *reinterpret_cast<const h8*>(w_hi + j * 32 * RB + poff[ks]);
-                wl[j] = *reinterpret_cast<const h8*>(w_lo + j * 32 * RB + poff[ks]);
+                wh[ks][j] = *reinterpret_cast<const h8*>(st + w_row + j * 4096 + off_hi[ks]);
+                wl[ks][j] = *reinterpret_cast<const h8*>(st + w_row + j * 4096 + off_lo[ks]);
             }
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    acc0[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], ah[i], acc0[j][i], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    acc1[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[j], ah[i], acc1[j][i], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    acc1[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], al[i], acc1[j][i], 0, 0, 0);
         }
-        __syncthreads();  // with an LDS-DMA in flight hipcc puts s_waitcnt vmcnt(0) in front
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][i], wh[ks][j], acc0[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][i], wl[ks][j], acc1[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks][i], wh[ks][j], acc1[i][j], 0, 0, 0);
+        }
+        // issue order inside the K step: the 8 fragment reads of k-substep 0 first, then one MFMA per
+        // remaining read (k-substep 1's fragments land under k-substep 0's products), then the rest
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);
+#pragma unroll
+        for (int q = 0; q < 2 * (TM + TN); ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 6 * TM * TN - 2 * (TM + TN), 0);
+        // stage kt+1 must have landed (this wave's pieces; the barrier extends it to every wave's);
+        // with 3 stages the pieces of stage kt+2, issued above, stay in flight across the barrier
+        if (NSTAGE == 3 && more) wait_vmcnt<PW>(); else wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+        nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
     }
 
-    // ---- epilogue: lane owns row m = .. + l31 and, per fragment, 4 runs of 4 consecutive n ------
+    // ---- epilogue ---------------------------------------------------------------------------------
     bool overflow = false;
+    if ((p.dbg & 2) && acc0[0][0][0] != 12345.678f) return;
+    {
+        constexpr int ROWLEN = 32 * TN;          // floats per row of the wave's tile
+        constexpr int LPR = ROWLEN / 4;          // lanes per row (float4 each)
+        constexpr int RPI = 64 / LPR;            // rows per wave-instruction
+        float* wl = reinterpret_cast<float*>(lds) + wave * (32 * ROWLEN);
+        const int rl = lane / LPR, cl = (lane % LPR) * 4;
+        const int n = n0 + wn * ROWLEN + cl;     // first of this lane's 4 consecutive columns
+        const bool nok = n < p.N;
+        float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias && nok) bias4 = *reinterpret_cast<const float4*>(p.bias + n);
+        const int npos = split_pos(n);
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + (wm * TM + i) * 32 + l31;
-        if (m >= p.M) continue;
+        for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = n0 + (wn * TN + j) * 32 + 8 * q + 4 * hi;
-                if (n >= p.N) continue;
-                float v[4];
+                for (int r = 0; r < 16; ++r)
+                    wl[mfma32_row(r, lane) * ROWLEN + j * 32 + l31] = acc0[i][j][r] + acc1[i][j][r] * kLoInv;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc0[j][i][4 * q + e] + acc1[j][i][4 * q + e] * kLoInv;
-                if (p.bias) {
-                    const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-                    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-                }
+            for (int it = 0; it < 32 / RPI; ++it) {
+                const int row = it * RPI + rl;
+                const int m = m0 + (wm * TM + i) * 32 + row;
+                const float4 t = *reinterpret_cast<const float4*>(wl + row * ROWLEN + cl);
+                if (m >= p.M || !nok) continue;
+                float v[4] = {t.x + bias4.x, t.y + bias4.y, t.z + bias4.z, t.w + bias4.w};
                 const size_t off = (size_t)m * p.ldc + n;
                 if constexpr (EPI == H3_PLAIN) {
                     *reinterpret_cast<float4*>(p.C + off) = make_float4(v[0], v[1], v[2], v[3]);
@@ -190,8 +226,8 @@ __global__ __launch_bounds__(TC::NT, TC::MINW) void gemm_h3_kernel(const H3Param
                     *reinterpret_cast<float4*>(p.C + off) =
                         make_float4(v[0] + rr.x, v[1] + rr.y, v[2] + rr.z, v[3] + rr.w);
                 } else {
+                    if (p.aux) *reinterpret_cast<float4*>(p.aux + off) = make_float4(v[0], v[1], v[2], v[3]);
                     if constexpr (EPI == H3_GELU_SPLIT) {
-                        if (p.aux) *reinterpret_cast<float4*>(p.aux + off) = make_float4(v[0], v[1], v[2], v[3]);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
                     }
@@ -203,9 +239,9 @@ __global__ __launch_bounds__(TC::NT, TC::MINW) void gemm_h3_kernel(const H3Param
                         oh[e] = a; ol[e] = b;
                         overflow |= !(fabsf(v[e]) < 65504.0f);
                     }
-                    _Float16* dst = p.Cs + (size_t)m * (2 * p.N) + n;
+                    _Float16* dst = p.Cs + (size_t)m * (2 * p.N) + npos;
                     *reinterpret_cast<h4*>(dst) = oh;
-                    *reinterpret_cast<h4*>(dst + p.N) = ol;
+                    *reinterpret_cast<h4*>(dst + 32) = ol;
                 }
             }
         }

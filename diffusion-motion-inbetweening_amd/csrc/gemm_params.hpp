@@ -43,7 +43,7 @@ enum H3Epi {
     H3_PLAIN = 0,       // C = v + bias[n]                                   (fp32)
     H3_GELU_SPLIT = 1,  // aux = v + bias (optional); Cs = split(gelu_erf(v + bias))
     H3_RESID = 2,       // C = (v + bias[n]) + R[m][n]                       (fp32)
-    H3_PLAIN_SPLIT = 3, // Cs = split(v + bias[n])
+    H3_PLAIN_SPLIT = 3, // aux = v + bias (optional fp32 copy); Cs = split(v + bias[n])
 };
 
 struct H3Params {
@@ -56,6 +56,7 @@ struct H3Params {
     float* aux;         // optional pre-activation stash [M][ldc]
     int* range_flag;    // set to 1 if a split output leaves the f16 range
     int M, N, K, ldc;
+    int dbg;            // bench-only ablations: 1 = no in-loop loads, 2 = no epilogue stores
 };
 
 }  // namespace cmdi

@@ -24,11 +24,11 @@ hipError_t launch_gemm(GemmKind kind, const GemmParams& p, int tile, hipStream_t
 int gemm_auto_tile(int M, int N);
 
 // ---- gemm_h3.hip (split-f16, fp32-equivalent) ---------------------------------------------------
-// epi: H3Epi; tile: 0 auto, 1 = 128x128x32, 2 = 128x128x64, 3 = 256x128x32 (8 waves), 4 = 128x64x32,
-// 5 = 128x64x64, 6 = 64x128x32, 7 = 128x128x32 (8 waves)
+// epi: H3Epi; tile: 0 auto, 1 = 128x128 (2 stages), 2 = 256x128 8 waves (3 stages), 3 = same (2 stages),
+// 4 = 128x64 (2), 5 = 128x64 (3), 6 = 64x128 (2), 7 = 128x128 8 waves (3), 8 = same (2), 9 = 128x256 8 waves (2)
 hipError_t launch_gemm_h3(int epi, const H3Params& p, int tile, hipStream_t stream);
 int gemm_h3_auto_tile(int M, int N);
-// fp32 [rows][cols] (row stride ld_src) -> split rows [rows][2*cols] halves (hi | lo * 2^11)
+// fp32 [rows][cols] (row stride ld_src) -> split rows [rows][2*cols] halves (format: gemm_h3.hpp)
 hipError_t launch_split_f16(const float* src, _Float16* dst, int64_t rows, int cols, int64_t ld_src,
                             int* range_flag, hipStream_t stream);
 
@@ -37,6 +37,11 @@ hipError_t launch_split_f16(const float* src, _Float16* dst, int64_t rows, int c
 // null; row_stats != null stashes (max, 1/sum) per query row for the backward pass.
 hipError_t launch_attention_fwd(const float* qkv, float* out, _Float16* out_split, int* range_flag,
                                 float* row_stats, int n_seq, int S, int H, hipStream_t stream);
+// ---- attention_h3.hip (split-f16 products, fp32-equivalent) -------------------------------------
+// qkv_split: split rows [M, 2*3d] (gemm_h3.hpp format); outputs as launch_attention_fwd
+hipError_t launch_attention_h3(const _Float16* qkv_split, float* out, _Float16* out_split,
+                               int* range_flag, float* row_stats, int n_seq, int S, int H,
+                               hipStream_t stream);
 // ---- attention_bwd_f32.hip ------------------------------------------------------------------
 // d_qkv[M,3d] from d_out[M,d]; P is recomputed from the forward's row statistics; d_rowdot is a
 // [n_seq*H*S] scratch (D = rowsum(dO*O)) written by the dQ kernel and read by the dK/dV kernel.

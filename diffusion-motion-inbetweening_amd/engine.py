@@ -290,7 +290,8 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
 
 
 def split_f16(x: torch.Tensor) -> torch.Tensor:
-    """fp32 [rows, cols] -> split rows [rows, 2*cols] float16: hi | (x - hi) * 2^11 (test hook)."""
+    """fp32 [rows, cols] -> split rows [rows, 2*cols] float16; per 32-column chunk 32 hi values then
+    32 values of (x - hi) * 2^11 (test hook)."""
     lib = N.load()
     assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2
     x = x.contiguous()
@@ -328,8 +329,8 @@ def gemm_h3(a_split: torch.Tensor, w_split: torch.Tensor, bias: Optional[torch.T
 
 def unsplit_f16(s: torch.Tensor) -> torch.Tensor:
     """Inverse of split_f16 (exact in float64, returned as fp32)."""
-    k = s.shape[1] // 2
-    return (s[:, :k].double() + s[:, k:].double() / 2048.0).float()
+    c = s.view(s.shape[0], -1, 2, 32).double()
+    return (c[:, :, 0] + c[:, :, 1] / 2048.0).reshape(s.shape[0], -1).float()
 
 
 def attention_fwd(qkv: torch.Tensor, n_seq: int, seq_len: int, n_heads: int) -> torch.Tensor:
@@ -341,6 +342,18 @@ def attention_fwd(qkv: torch.Tensor, n_seq: int, seq_len: int, n_heads: int) -> 
     with torch.cuda.device(qkv.device):
         N.check(lib.cmdi_attention_fwd(N.ptr(qkv), N.ptr(out), n_seq, seq_len, n_heads,
                                        N.current_stream(qkv.device)))
+    return out
+
+
+def attention_fwd_h3(qkv: torch.Tensor, n_seq: int, seq_len: int, n_heads: int) -> torch.Tensor:
+    """attention_fwd on the split-f16 path: qkv (fp32) is split on the device first (test hook)."""
+    lib = N.load()
+    assert qkv.shape == (n_seq * seq_len, 3 * n_heads * 128)
+    qs = split_f16(qkv)
+    out = torch.empty((n_seq * seq_len, n_heads * 128), dtype=torch.float32, device=qkv.device)
+    with torch.cuda.device(qkv.device):
+        N.check(lib.cmdi_attention_fwd_h3(N.ptr(qs), N.ptr(out), n_seq, seq_len, n_heads,
+                                          N.current_stream(qkv.device)))
     return out
 
 

@@ -199,10 +199,11 @@ int cmdi_precision(cmdi_handle h);
  * call it once per sampling chain, not per step.  Clears the flag. */
 int cmdi_range_status(cmdi_handle h, int32_t* out_flag, cmdi_stream stream);
 /* Split-f16 GEMM family alone (test / bench hooks).  cmdi_split_f16: fp32 [rows, cols] -> split rows
- * [rows, 2*cols] f16 (cols hi values, then cols values of (x - hi) * 2^11), cols % 8 == 0.
+ * [rows, 2*cols] f16; per 32-column chunk: 32 hi values f16(x), then 32 lo values
+ * f16((x - hi) * 2^11); cols % 32 == 0.
  * cmdi_gemm_h3: C[M,N] = epi(A[M,K] · W[N,K]^T + bias[N]) with A, W in split rows; epi as in
  * cmdi_gemm_nt (1 = bias + GELU writes split rows to d_c_split; 0 writes fp32 to d_c, or split rows
- * if d_c_split != NULL); K % 64 == 0, N % 32 == 0. */
+ * if d_c_split != NULL); K % 32 == 0, N % 32 == 0. */
 int cmdi_split_f16(const float* d_src, void* d_dst, int64_t rows, int32_t cols, cmdi_stream stream);
 int cmdi_gemm_h3(const void* d_a_split, const void* d_w_split, const float* d_bias,
                  const float* d_resid, float* d_c, void* d_c_split, int32_t m, int32_t n, int32_t k,
@@ -210,6 +211,9 @@ int cmdi_gemm_h3(const void* d_a_split, const void* d_w_split, const float* d_bi
 /* Self-attention core alone (test / bench hook): d_qkv [n_seq*S, 3*H*128] -> d_out [n_seq*S, H*128]. */
 int cmdi_attention_fwd(const float* d_qkv, float* d_out, int32_t n_seq, int32_t seq_len,
                        int32_t n_heads, cmdi_stream stream);
+/* The same on the f16 matrix pipe (split-f16 products): d_qkv_split = cmdi_split_f16 of d_qkv. */
+int cmdi_attention_fwd_h3(const void* d_qkv_split, float* d_out, int32_t n_seq, int32_t seq_len,
+                          int32_t n_heads, cmdi_stream stream);
 /* Philox4x32-10 raw block (host, for known-answer tests): out[4] = philox(counter[4], key[2]). */
 void cmdi_philox4x32_10(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]);
 /* Live timing of the dominant kernel (the self-attention in_proj GEMM, one launch per layer):
