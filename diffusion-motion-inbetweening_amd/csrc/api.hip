@@ -36,6 +36,7 @@ struct LayerW {
     float *in_wT = nullptr, *out_wT = nullptr, *l1_wT = nullptr, *l2_wT = nullptr;
     // split-f16 copies (hi | lo*2^11 rows, gemm_h3.hpp) for the f16-pipe forward GEMMs
     _Float16 *in_ws = nullptr, *out_ws = nullptr, *l1_ws = nullptr, *l2_ws = nullptr;
+    _Float16 *in_wTs = nullptr, *out_wTs = nullptr, *l1_wTs = nullptr, *l2_wTs = nullptr;  // want_grad
 };
 struct LayerStash {
     float *qkv = nullptr, *attn = nullptr, *row_stats = nullptr;
@@ -87,7 +88,9 @@ struct cmdi_engine {
     // (fp32-equivalent split-f16 products on the f16 matrix pipe, gemm_h3.hpp)
     int precision = CMDI_PREC_F16X3;
     _Float16 *tokS = nullptr, *bufHS = nullptr, *attnS = nullptr, *ffnS = nullptr, *qkvS = nullptr;
+    _Float16 *dBS = nullptr, *dffnS = nullptr, *dqkvS = nullptr;  // backward operands (want_grad)
     int* range_flag = nullptr;
+    unsigned* gs_bits = nullptr;   // max|gout| bits -> power-of-two gradient scale (f16x3 backward)
     int h3_tile_qkv = 0, h3_tile_proj = 0, h3_tile_ffn1 = 0, h3_tile_ffn2 = 0;
     int gemm_tile = 0;
     int tile_inproj = 0, tile_proj = 0, tile_ffn1 = 0, tile_ffn2 = 0;  // per-GEMM overrides (0 = auto)
@@ -324,11 +327,50 @@ int run_layers_bwd(cmdi_engine* e, int seq0, int nseq, hipStream_t s) {
     float* dqkv = e->dqkv + r0 * 3 * d;
     float* dffn = e->dffn + r0 * f;
     const int tile = e->gemm_tile;
+    const bool h3 = e->precision == CMDI_PREC_F16X3;
+    _Float16* dBS = h3 ? e->dBS + r0 * 2 * d : nullptr;
+    _Float16* dffnS = h3 ? e->dffnS + r0 * 2 * f : nullptr;
+    _Float16* dqkvS = h3 ? e->dqkvS + r0 * 6 * d : nullptr;
+    auto hp = [&](const _Float16* A, const _Float16* W, float* C, _Float16* Cs, int N, int K) {
+        H3Params p{};
+        // gradients carry no range flag: a gradient beyond the f16 range would already have shown
+        // up as a non-finite sample (bench / callers check), and the forward pass guards the rest
+        p.A = A; p.W = W; p.C = C; p.Cs = Cs;
+        p.M = M; p.N = N; p.K = K; p.ldc = N;
+        return p;
+    };
     for (int l = e->L - 1; l >= 0; --l) {
         const LayerW& w = e->layers[l];
         const LayerStash& st = e->stash[l];
+        if (h3) {
+            // same chain with the four dX GEMMs on the f16 matrix pipe (weights: split transposes)
+            HIPCHK(launch_layernorm_bwd(st.pre2 + r0 * d, st.stats2 + r0 * 2, w.n2_g, dA, dB, dBS, M, d, s));
+            {   // dffn = (dB · W2) * gelu'(aux)
+                H3Params p = hp(dBS, w.l2_wTs, nullptr, dffnS, f, d);
+                p.aux = st.aux + r0 * f;
+                HIPCHK(launch_gemm_h3(H3_GELUGRAD_SPLIT, p, e->h3_tile_ffn1, s));
+            }
+            {   // dH = dffn · W1 + dB
+                H3Params p = hp(dffnS, w.l1_wTs, dH, nullptr, d, f);
+                p.R = dB;
+                HIPCHK(launch_gemm_h3(H3_RESID, p, e->h3_tile_ffn2, s));
+            }
+            HIPCHK(launch_layernorm_bwd(st.pre1 + r0 * d, st.stats1 + r0 * 2, w.n1_g, dH, dB, dBS, M, d, s));
+            // d attn = dB · Wo -> dH
+            HIPCHK(launch_gemm_h3(H3_PLAIN, hp(dBS, w.out_wTs, dH, nullptr, d, d), e->h3_tile_proj, s));
+            HIPCHK(launch_attention_bwd(st.qkv + r0 * 3 * d, st.attn + r0 * d,
+                                        st.row_stats + (size_t)seq0 * e->H * S * 2, dH, dqkv,
+                                        e->drowdot + (size_t)seq0 * e->H * S, nseq, S, e->H, s));
+            HIPCHK(launch_split_f16(dqkv, dqkvS, M, 3 * d, 3 * d, nullptr, s));
+            {   // dA = dqkv · Wqkv + dB
+                H3Params p = hp(dqkvS, w.in_wTs, dA, nullptr, d, 3 * d);
+                p.R = dB;
+                HIPCHK(launch_gemm_h3(H3_RESID, p, e->h3_tile_proj, s));
+            }
+            continue;
+        }
         // norm2
-        HIPCHK(launch_layernorm_bwd(st.pre2 + r0 * d, st.stats2 + r0 * 2, w.n2_g, dA, dB, M, d, s));
+        HIPCHK(launch_layernorm_bwd(st.pre2 + r0 * d, st.stats2 + r0 * 2, w.n2_g, dA, dB, nullptr, M, d, s));
         // linear2 + GELU: dffn = (dB · W2) * gelu'(aux)
         {
             GemmParams p = gp(dB, w.l2_wT, nullptr, dffn, M, f, d, d, d, f);
@@ -342,7 +384,7 @@ int run_layers_bwd(cmdi_engine* e, int seq0, int nseq, hipStream_t s) {
             HIPCHK(launch_gemm(GK_ACCUM, p, tile, s));
         }
         // norm1
-        HIPCHK(launch_layernorm_bwd(st.pre1 + r0 * d, st.stats1 + r0 * 2, w.n1_g, dH, dB, M, d, s));
+        HIPCHK(launch_layernorm_bwd(st.pre1 + r0 * d, st.stats1 + r0 * 2, w.n1_g, dH, dB, nullptr, M, d, s));
         // out_proj: d attn = dB · Wo   (no bias, no residual) -> reuse dH as d attn
         HIPCHK(launch_gemm(GK_PLAIN, gp(dB, w.out_wT, nullptr, dH, M, d, d, d, d, d), tile, s));
         // attention core
@@ -368,9 +410,15 @@ int mdm_backward(cmdi_engine* e, const float* gout, float* gx, hipStream_t s) {
 
     // output projection: d tok[b*S+1+t][k] = sum_c gout[b][c][t] W_out[c][k]; token 0 rows get 0
     HIPCHK(hipMemsetAsync(e->dA, 0, (size_t)M * d * sizeof(float), s));
+    const bool h3 = e->precision == CMDI_PREC_F16X3;
+    if (h3) {   // power-of-two gradient scale: applied here, undone by the last GEMM below
+        HIPCHK(hipMemsetAsync(e->gs_bits, 0, sizeof(unsigned), s));
+        HIPCHK(launch_absmax_bits(gout, (int64_t)n_seq * C * T, e->gs_bits, s));
+    }
     {
         GemmParams p = gp(gout, e->w_outT_pad, nullptr, e->dA, n_seq * T, d, e->Cpad, 0, e->Cpad, d);
         p.T = T; p.S = S; p.Cf = C;
+        p.gs_bits = h3 ? e->gs_bits : nullptr;
         HIPCHK(launch_gemm(GK_OUTPROJ_BWD, p, 0, s));
     }
     int rc = for_groups(e, n_seq, s, [&](int seq0, int nseq, hipStream_t gs) {
@@ -380,6 +428,7 @@ int mdm_backward(cmdi_engine* e, const float* gout, float* gx, hipStream_t s) {
     {   // input projection: gx[b][c][t] = sum_n dA[b*S+1+t][n] W_in[n][c]
         GemmParams p = gp(e->w_inT, e->dA, nullptr, gx, C, n_seq * T, d, d, d, 0);
         p.T = T; p.S = S; p.Cf = C;
+        p.gs_bits = h3 ? e->gs_bits : nullptr;
         HIPCHK(launch_gemm(GK_OUTPROJ, p, 0, s));
     }
     return CMDI_OK;
@@ -530,6 +579,7 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
     ALLOC(e->qkv, Mmax * 3 * d); ALLOC(e->attn, Mmax * d); ALLOC(e->ffn, Mmax * f);
     ALLOC(e->out_raw, nseq * C * e->Tmax);
     ALLOC(e->range_flag, 1);
+    ALLOC(e->gs_bits, 1);
     HIPCHK(hipMemset(e->range_flag, 0, sizeof(int)));
     if (e->precision == CMDI_PREC_F16X3) {
         for (LayerW& w : e->layers) {
@@ -538,6 +588,13 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
         }
         ALLOC(e->tokS, Mmax * d * 2); ALLOC(e->bufHS, Mmax * d * 2);
         ALLOC(e->attnS, Mmax * d * 2); ALLOC(e->ffnS, Mmax * f * 2); ALLOC(e->qkvS, Mmax * 3 * d * 2);
+        if (desc->want_grad) {
+            for (LayerW& w : e->layers) {
+                ALLOC(w.in_wTs, (size_t)3 * d * d * 2); ALLOC(w.out_wTs, (size_t)d * d * 2);
+                ALLOC(w.l1_wTs, (size_t)f * d * 2); ALLOC(w.l2_wTs, (size_t)d * f * 2);
+            }
+            ALLOC(e->dBS, Mmax * d * 2); ALLOC(e->dffnS, Mmax * f * 2); ALLOC(e->dqkvS, Mmax * 3 * d * 2);
+        }
     }
     if (desc->want_grad) {
         ALLOC(e->w_inT, (size_t)C * d); ALLOC(e->w_outT_pad, (size_t)d * e->Cpad);
@@ -665,6 +722,12 @@ int cmdi_finalize_weights(cmdi_handle e, int32_t n_time_rows, cmdi_stream stream
             HIPCHK(launch_split_f16(w.out_w, w.out_ws, d, d, d, e->range_flag, s));
             HIPCHK(launch_split_f16(w.l1_w, w.l1_ws, f, d, d, e->range_flag, s));
             HIPCHK(launch_split_f16(w.l2_w, w.l2_ws, d, f, f, e->range_flag, s));
+            if (e->desc.want_grad) {
+                HIPCHK(launch_split_f16(w.in_wT, w.in_wTs, d, 3 * d, 3 * d, e->range_flag, s));
+                HIPCHK(launch_split_f16(w.out_wT, w.out_wTs, d, d, d, e->range_flag, s));
+                HIPCHK(launch_split_f16(w.l1_wT, w.l1_wTs, d, f, f, e->range_flag, s));
+                HIPCHK(launch_split_f16(w.l2_wT, w.l2_wTs, f, d, d, e->range_flag, s));
+            }
         }
     }
     // TimestepEmbedder (mdm.py:351-353) for every original timestep: Linear -> SiLU -> Linear on pe[t]

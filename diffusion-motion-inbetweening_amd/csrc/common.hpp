@@ -38,6 +38,18 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
 
+// Power-of-two "loss scale" of the reconstruction-guidance backward pass on the f16 matrix pipe:
+// bits = float bits of max|g| over the output gradient; the scale moves that maximum to [2^6, 2^7)
+// so the whole gradient chain sits well inside the f16 range of the split operands (gemm_h3.hpp).
+// Exact (a power of two) and undone at the end of the chain, which is linear in g.
+__device__ __forceinline__ float grad_scale_from_bits(unsigned bits) {
+    const int e = (int)(bits >> 23) - 127;          // floor(log2(max)); bits == 0 -> -127
+    if (bits == 0u || e > 120) return 1.0f;          // zero / inf / nan gradient: leave as is
+    int sh = 6 - e;
+    sh = sh < -100 ? -100 : (sh > 100 ? 100 : sh);
+    return __uint_as_float((unsigned)(127 + sh) << 23);
+}
+
 // XCD-aware bijective remap of a linear block id (guide T1): blocks that the dispatcher places on
 // the same XCD (id % 8) get a contiguous chunk of the tile space, so tiles sharing an operand
 // panel hit the same private L2.  Speed only; any mapping is correct.

@@ -78,7 +78,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ stats,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ dy,
-                                                            float* __restrict__ dx, int rows) {
+                                                            float* __restrict__ dx,
+                                                            _Float16* __restrict__ dxs, int rows) {
     constexpr int D = NV * 256;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -110,6 +111,19 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         o.z = rstd * (g[i].z - m1 - xh[i].z * m2);
         o.w = rstd * (g[i].w - m1 - xh[i].w * m2);
         *reinterpret_cast<float4*>(dxr + i * 256 + lane * 4) = o;
+        if (dxs) {   // split rows for the f16-pipe dX GEMMs (gradients: no range flag, see api.hip)
+            const float ov[4] = {o.x, o.y, o.z, o.w};
+            h4 oh, ol;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                _Float16 a, c;
+                split_f16(ov[e], a, c);
+                oh[e] = a; ol[e] = c;
+            }
+            _Float16* d = dxs + (size_t)row * (2 * D) + split_pos(i * 256 + lane * 4);
+            *reinterpret_cast<h4*>(d) = oh;
+            *reinterpret_cast<h4*>(d + 32) = ol;
+        }
     }
 }
 
@@ -128,13 +142,14 @@ hipError_t launch_layernorm(const float* x, const float* gamma, const float* bet
 }
 
 hipError_t launch_layernorm_bwd(const float* x, const float* stats, const float* gamma,
-                                const float* dy, float* dx, int rows, int d, hipStream_t stream) {
+                                const float* dy, float* dx, _Float16* dx_split, int rows, int d,
+                                hipStream_t stream) {
     const dim3 grid((rows + 3) / 4), block(256);
     switch (d) {
-        case 256: hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, block, 0, stream, x, stats, gamma, dy, dx, rows); break;
-        case 512: hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, block, 0, stream, x, stats, gamma, dy, dx, rows); break;
-        case 768: hipLaunchKernelGGL(layernorm_bwd_kernel<3>, grid, block, 0, stream, x, stats, gamma, dy, dx, rows); break;
-        case 1024: hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, block, 0, stream, x, stats, gamma, dy, dx, rows); break;
+        case 256: hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, block, 0, stream, x, stats, gamma, dy, dx, dx_split, rows); break;
+        case 512: hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, block, 0, stream, x, stats, gamma, dy, dx, dx_split, rows); break;
+        case 768: hipLaunchKernelGGL(layernorm_bwd_kernel<3>, grid, block, 0, stream, x, stats, gamma, dy, dx, dx_split, rows); break;
+        case 1024: hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, block, 0, stream, x, stats, gamma, dy, dx, dx_split, rows); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -184,6 +199,25 @@ __global__ void add2_kernel(float* __restrict__ dst, const float* __restrict__ a
          i += (int64_t)gridDim.x * blockDim.x)
         dst[i] = a[i] + b[i];
 }
+// *out = max(*out, bits of max|x|) (non-negative floats order like their bit patterns); *out is
+// zeroed by the caller.  NaN / inf propagate as large bit patterns (grad_scale_from_bits -> 1).
+__global__ __launch_bounds__(256) void absmax_bits_kernel(const float* __restrict__ x, int64_t n,
+                                                          unsigned* __restrict__ out) {
+    unsigned m = 0u;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        m = max(m, __float_as_uint(fabsf(x[i])));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+hipError_t launch_absmax_bits(const float* x, int64_t n, unsigned* out, hipStream_t stream) {
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(absmax_bits_kernel, dim3(blocks), dim3(256), 0, stream, x, n, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_add2(float* dst, const float* a, const float* b, int64_t n, hipStream_t stream) {
     int64_t blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;

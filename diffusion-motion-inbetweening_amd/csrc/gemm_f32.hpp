@@ -368,9 +368,14 @@ __global__ __launch_bounds__(TC::NT) void gemm_nt_kernel(const GemmParams p) {
                 if (p.bias) bn = p.bias[n];
             }
             int nb = 0, ntt = 0;
+            float gs = 1.0f;
             if constexpr (EPI == EPI_MOTION) {
                 nb = n / p.T;
                 ntt = n - nb * p.T;
+                if (p.gs_bits) gs = 1.0f / grad_scale_from_bits(*p.gs_bits);  // exact: power of two
+            }
+            if constexpr (EPI == EPI_TOKOUT) {
+                if (p.gs_bits) gs = grad_scale_from_bits(*p.gs_bits);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -401,11 +406,11 @@ __global__ __launch_bounds__(TC::NT) void gemm_nt_kernel(const GemmParams p) {
                     if (p.Bdup) p.C[((size_t)(b + p.Bdup) * p.S + 1 + t) * p.ldc + n] = o;
                 } else if constexpr (EPI == EPI_TOKOUT) {
                     const int b = m / p.T, t = m - b * p.T;
-                    p.C[((size_t)b * p.S + 1 + t) * p.ldc + n] = v;
+                    p.C[((size_t)b * p.S + 1 + t) * p.ldc + n] = v * gs;
                 } else if constexpr (EPI == EPI_MOTION) {
                     // m = feature c, n = (b, t): lanes run along t -> 128-B contiguous stores
                     const float bm = p.bias ? p.bias[m] : 0.f;
-                    p.C[((size_t)nb * p.Cf + m) * p.T + ntt] = v * p.out_scale + bm;
+                    p.C[((size_t)nb * p.Cf + m) * p.T + ntt] = (v * gs) * p.out_scale + bm;
                 }
             }
         }

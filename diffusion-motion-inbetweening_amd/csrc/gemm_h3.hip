@@ -14,6 +14,8 @@ using H64x128s2 = H3Tile<64, 128, 2, 2, 2, 2>;      // 32x64 per wave
 using H128x128w8s3 = H3Tile<128, 128, 4, 2, 3, 2>;  // 8 waves, 32x64 per wave, 96 KiB
 using H128x128w8s2 = H3Tile<128, 128, 4, 2, 2, 2>;  // 8 waves, 64 KiB, 2 blocks/CU (16 waves)
 using H128x256s2 = H3Tile<128, 256, 2, 4, 2, 2>;    // 8 waves, 64x64 per wave, 96 KiB
+using H256x128w16 = H3Tile<256, 128, 8, 2, 3, 4>;   // 16 waves, 32x64 per wave, 3 stages = 144 KiB
+using H128x256w16 = H3Tile<128, 256, 4, 4, 3, 4>;   // 16 waves, 32x64 per wave
 
 template <class TC, int EPI>
 static hipError_t launch_h3_one(const H3Params& p, hipStream_t stream) {
@@ -43,6 +45,8 @@ static hipError_t launch_h3_tiles(const H3Params& p, int tile, hipStream_t s) {
         case 7: return launch_h3_one<H128x128w8s3, EPI>(p, s);
         case 8: return launch_h3_one<H128x128w8s2, EPI>(p, s);
         case 9: return launch_h3_one<H128x256s2, EPI>(p, s);
+        case 10: return launch_h3_one<H256x128w16, EPI>(p, s);
+        case 11: return launch_h3_one<H128x256w16, EPI>(p, s);
         default: return hipErrorInvalidValue;
     }
 }
@@ -62,6 +66,7 @@ hipError_t launch_gemm_h3(int epi, const H3Params& p, int tile, hipStream_t s) {
         case H3_GELU_SPLIT: return launch_h3_tiles<H3_GELU_SPLIT>(p, tile, s);
         case H3_RESID: return launch_h3_tiles<H3_RESID>(p, tile, s);
         case H3_PLAIN_SPLIT: return launch_h3_tiles<H3_PLAIN_SPLIT>(p, tile, s);
+        case H3_GELUGRAD_SPLIT: return launch_h3_tiles<H3_GELUGRAD_SPLIT>(p, tile, s);
     }
     return hipErrorInvalidValue;
 }

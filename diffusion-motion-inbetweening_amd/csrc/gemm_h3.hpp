@@ -226,7 +226,13 @@ __global__ __launch_bounds__(TC::NT, TC::MINW) void gemm_h3_kernel(const H3Param
                     *reinterpret_cast<float4*>(p.C + off) =
                         make_float4(v[0] + rr.x, v[1] + rr.y, v[2] + rr.z, v[3] + rr.w);
                 } else {
-                    if (p.aux) *reinterpret_cast<float4*>(p.aux + off) = make_float4(v[0], v[1], v[2], v[3]);
+                    if constexpr (EPI == H3_GELUGRAD_SPLIT) {
+                        const float4 ax = *reinterpret_cast<const float4*>(p.aux + off);
+                        v[0] *= gelu_erf_grad(ax.x); v[1] *= gelu_erf_grad(ax.y);
+                        v[2] *= gelu_erf_grad(ax.z); v[3] *= gelu_erf_grad(ax.w);
+                    } else if (p.aux) {
+                        *reinterpret_cast<float4*>(p.aux + off) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
                     if constexpr (EPI == H3_GELU_SPLIT) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(TC::NT, TC::MINW) void gemm_h3_kernel(const H3Param
             }
         }
     }
-    if constexpr (EPI == H3_GELU_SPLIT || EPI == H3_PLAIN_SPLIT) {
+    if constexpr (EPI == H3_GELU_SPLIT || EPI == H3_PLAIN_SPLIT || EPI == H3_GELUGRAD_SPLIT) {
         if (overflow && p.range_flag) atomicOr(p.range_flag, 1);
     }
 }

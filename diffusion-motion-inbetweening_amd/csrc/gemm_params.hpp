@@ -36,6 +36,8 @@ struct GemmParams {
     int T, S, Cf;       // frames, tokens per sequence (T+1), motion features (263)
     int Bdup;           // EPI_INPROJ: B if an unconditional copy is also written, else 0
     float out_scale;    // EPI_MOTION: multiplies v (1 for the forward pass)
+    const unsigned* gs_bits;  // optional gradient scale (common.hpp grad_scale_from_bits):
+                              // EPI_TOKOUT multiplies v by it, EPI_MOTION divides v by it
 };
 
 // ---- split-f16 (fp32-equivalent) GEMM family, gemm_h3.hpp ----------------------------------------
@@ -44,6 +46,7 @@ enum H3Epi {
     H3_GELU_SPLIT = 1,  // aux = v + bias (optional); Cs = split(gelu_erf(v + bias))
     H3_RESID = 2,       // C = (v + bias[n]) + R[m][n]                       (fp32)
     H3_PLAIN_SPLIT = 3, // aux = v + bias (optional fp32 copy); Cs = split(v + bias[n])
+    H3_GELUGRAD_SPLIT = 4, // Cs = split(v * gelu'(aux[m][n]))   (backward through linear1's GELU)
 };
 
 struct H3Params {

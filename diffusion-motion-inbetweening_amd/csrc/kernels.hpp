@@ -57,7 +57,8 @@ hipError_t launch_layernorm(const float* x, const float* gamma, const float* bet
                             hipStream_t stream);
 // dx = LN backward of dy (optionally + extra residual gradient dres added to the result)
 hipError_t launch_layernorm_bwd(const float* x, const float* stats, const float* gamma,
-                                const float* dy, float* dx, int rows, int d, hipStream_t stream);
+                                const float* dy, float* dx, _Float16* dx_split /* optional */,
+                                int rows, int d, hipStream_t stream);
 // tok[b*S + 0][:] = time_table[t_b] + text_term[b] + pe[0]
 hipError_t launch_token0(float* tok, const float* time_table, const float* text_term,
                          const float* pe, const int64_t* t_dev, int64_t t_scalar, int n_seq,
@@ -65,6 +66,8 @@ hipError_t launch_token0(float* tok, const float* time_table, const float* text_
 // text_term[b'] rows: conditional rows get proj[b] (already W·c+b), unconditional rows get bias
 hipError_t launch_fill_rows(float* dst, const float* row, int rows, int d, hipStream_t stream);
 hipError_t launch_add2(float* dst, const float* a, const float* b, int64_t n, hipStream_t stream);
+// atomicMax of the bit pattern of max|x| into *out (zeroed by the caller)
+hipError_t launch_absmax_bits(const float* x, int64_t n, unsigned* out, hipStream_t stream);
 // dst[r][c] = c < cols ? src[r][c] : 0   (dst row stride ldd >= cols)
 hipError_t launch_pad_copy(float* dst, const float* src, int rows, int cols, int ldd,
                            hipStream_t stream);

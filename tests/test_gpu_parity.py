@@ -101,7 +101,7 @@ def test_split_f16_roundtrip():
     assert torch.equal(hi_plane.cpu(), x.half())  # hi plane = round-to-nearest f16
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
 @pytest.mark.parametrize("shape", [(333, 512, 512), (197 * 4, 1536, 512), (1000, 512, 1024), (130, 256, 32)])
 def test_gemm_h3(tile, shape):
     """Same inputs, same float64 reference and the same 2e-6 bound as the exact-fp32 kernels; the
@@ -220,6 +220,11 @@ def test_vjp_vs_reference_autograd(cases, precision):
     assert rel_l2(out, g["out"]) <= 2e-5
     gx = eng.mdm_vjp(tt(inp["gout"])).cpu().numpy()
     assert rel_l2(gx, g["gx"]) <= 5e-5, rel_l2(gx, g["gx"])
+    # the VJP is linear in gout: tiny and huge output gradients must come back to the same
+    # tolerance (f16x3: the power-of-two gradient scale keeps them inside the f16 range)
+    for k in (1e-12, 1e9):
+        gk = eng.mdm_vjp(tt(inp["gout"] * np.float32(k))).cpu().numpy().astype(np.float64) / k
+        assert rel_l2(gk, g["gx"]) <= 5e-5, (k, rel_l2(gk, g["gx"]))
 
 
 # ---- sampler arithmetic ----------------------------------------------------------------------------
