@@ -71,6 +71,7 @@ SIGNATURES = {
     "cmdi_randn": (C.c_int, [_VP, _VP, _I32, _I64, _U64, _I64, _I32, _VP]),
     "cmdi_gemm_nt": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _VP]),
     "cmdi_attention_fwd": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _VP]),
+    "cmdi_gemm_h3_ln": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _VP]),
     "cmdi_attention_fwd_h3": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _VP]),
     "cmdi_precision": (C.c_int, [_VP]),
     "cmdi_range_status": (C.c_int, [_VP, C.POINTER(_I32), _VP]),

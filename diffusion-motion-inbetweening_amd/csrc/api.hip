@@ -92,6 +92,10 @@ struct cmdi_engine {
     int* range_flag = nullptr;
     unsigned* gs_bits = nullptr;   // max|gout| bits -> power-of-two gradient scale (f16x3 backward)
     int h3_tile_qkv = 0, h3_tile_proj = 0, h3_tile_ffn1 = 0, h3_tile_ffn2 = 0;
+    // f16x3: LayerNorm inside the out_proj / linear2 GEMM epilogue (d_model = 512).  Off by default:
+    // the full-row 64x512 tile it needs (197 blocks, 8 waves per CU) loses more in the GEMM than the
+    // saved LayerNorm pass returns (B=32 CFG: 2.60 vs 2.29 ms per step on MI355X).
+    int ln_fuse = 0;
     int gemm_tile = 0;
     int tile_inproj = 0, tile_proj = 0, tile_ffn1 = 0, tile_ffn2 = 0;  // per-GEMM overrides (0 = auto)
 
@@ -197,25 +201,37 @@ int run_layers(cmdi_engine* e, int seq0, int nseq, bool keep, bool prof, hipStre
             }
             HIPCHK(launch_attention_h3(qkvS, keep ? attn : nullptr, attnS, e->range_flag, row_stats,
                                        nseq, S, e->H, s));
-            {
+            if (e->ln_fuse) {   // x = norm1(x + out_proj(attn)) in one kernel
+                H3Params p = hp(attnS, w.out_ws, w.out_b, bufH, bufHS, d, d);
+                p.R = tokA; p.ln_g = w.n1_g; p.ln_b = w.n1_b;
+                p.aux = keep ? pre1 : nullptr;
+                p.ln_stats = keep ? st->stats1 + r0 * 2 : nullptr;
+                HIPCHK(launch_gemm_h3(H3_RESID_LN, p, 0, s));
+            } else {
                 H3Params p = hp(attnS, w.out_ws, w.out_b, pre1, nullptr, d, d);
                 p.R = tokA;
                 HIPCHK(launch_gemm_h3(H3_RESID, p, e->h3_tile_proj, s));
+                HIPCHK(launch_layernorm(pre1, w.n1_g, w.n1_b, bufH, bufHS, e->range_flag,
+                                        keep ? st->stats1 + r0 * 2 : nullptr, M, d, s));
             }
-            HIPCHK(launch_layernorm(pre1, w.n1_g, w.n1_b, bufH, bufHS, e->range_flag,
-                                    keep ? st->stats1 + r0 * 2 : nullptr, M, d, s));
             {
                 H3Params p = hp(bufHS, w.l1_ws, w.l1_b, nullptr, ffnS, f, d);
                 p.aux = keep ? st->aux + r0 * f : nullptr;
                 HIPCHK(launch_gemm_h3(H3_GELU_SPLIT, p, e->h3_tile_ffn1, s));
             }
-            {
+            if (e->ln_fuse) {   // x = norm2(x + linear2(gelu(linear1(x))))
+                H3Params p = hp(ffnS, w.l2_ws, w.l2_b, tokA, l + 1 < e->L ? tokS : nullptr, d, f);
+                p.R = bufH; p.ln_g = w.n2_g; p.ln_b = w.n2_b;
+                p.aux = keep ? pre2 : nullptr;
+                p.ln_stats = keep ? st->stats2 + r0 * 2 : nullptr;
+                HIPCHK(launch_gemm_h3(H3_RESID_LN, p, 0, s));
+            } else {
                 H3Params p = hp(ffnS, w.l2_ws, w.l2_b, pre2, nullptr, d, f);
                 p.R = bufH;
                 HIPCHK(launch_gemm_h3(H3_RESID, p, e->h3_tile_ffn2, s));
+                HIPCHK(launch_layernorm(pre2, w.n2_g, w.n2_b, tokA, l + 1 < e->L ? tokS : nullptr,
+                                        e->range_flag, keep ? st->stats2 + r0 * 2 : nullptr, M, d, s));
             }
-            HIPCHK(launch_layernorm(pre2, w.n2_g, w.n2_b, tokA, l + 1 < e->L ? tokS : nullptr,
-                                    e->range_flag, keep ? st->stats2 + r0 * 2 : nullptr, M, d, s));
             continue;
         }
         // self-attention block: x = norm1(x + out_proj(MHA(x)))
@@ -547,6 +563,7 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
     e->h3_tile_proj = env_int("CMDI_H3_TILE_PROJ", env_int("CMDI_H3_TILE", 0));
     e->h3_tile_ffn1 = env_int("CMDI_H3_TILE_FFN1", env_int("CMDI_H3_TILE", 0));
     e->h3_tile_ffn2 = env_int("CMDI_H3_TILE_FFN2", env_int("CMDI_H3_TILE", 0));
+    e->ln_fuse = env_int("CMDI_LN_FUSE", 0) && desc->d_model == 512;
     const int d = e->d, f = e->f, C = e->C;
     const size_t nseq = 2 * (size_t)e->Bmax, Smax = e->Tmax + 1, Mmax = nseq * Smax;
     *out = e;  // so that cmdi_destroy can free a half-built engine
@@ -1040,6 +1057,23 @@ int cmdi_gemm_h3(const void* d_a_split, const void* d_w_split, const float* d_bi
         return fail(CMDI_E_INVALID, "split output needs d_c_split");
     if (kind == H3_RESID && !d_resid) return fail(CMDI_E_INVALID, "residual epilogue needs d_resid");
     hipError_t err = launch_gemm_h3(kind, p, tile, static_cast<hipStream_t>(stream));
+    if (err != hipSuccess) return fail(CMDI_E_HIP, std::string("launch_gemm_h3: ") + hipGetErrorString(err));
+    return CMDI_OK;
+}
+
+int cmdi_gemm_h3_ln(const void* d_a_split, const void* d_w_split, const float* d_bias,
+                    const float* d_resid, const float* d_gamma, const float* d_beta, float* d_y,
+                    void* d_y_split, int32_t m, int32_t n, int32_t k, cmdi_stream stream) {
+    if (!d_a_split || !d_w_split || !d_resid || !d_gamma || !d_beta || !d_y)
+        return fail(CMDI_E_INVALID, "null tensor");
+    if (n != 512 || k % 32 != 0) return fail(CMDI_E_INVALID, "the fused LayerNorm epilogue needs N = 512, K % 32 == 0");
+    H3Params p{};
+    p.A = static_cast<const _Float16*>(d_a_split);
+    p.W = static_cast<const _Float16*>(d_w_split);
+    p.bias = d_bias; p.R = d_resid; p.ln_g = d_gamma; p.ln_b = d_beta;
+    p.C = d_y; p.Cs = static_cast<_Float16*>(d_y_split);
+    p.M = m; p.N = n; p.K = k; p.ldc = n;
+    hipError_t err = launch_gemm_h3(H3_RESID_LN, p, 0, static_cast<hipStream_t>(stream));
     if (err != hipSuccess) return fail(CMDI_E_HIP, std::string("launch_gemm_h3: ") + hipGetErrorString(err));
     return CMDI_OK;
 }

@@ -203,17 +203,30 @@ __global__ void add2_kernel(float* __restrict__ dst, const float* __restrict__ a
 // zeroed by the caller.  NaN / inf propagate as large bit patterns (grad_scale_from_bits -> 1).
 __global__ __launch_bounds__(256) void absmax_bits_kernel(const float* __restrict__ x, int64_t n,
                                                           unsigned* __restrict__ out) {
+    __shared__ unsigned part[4];
     unsigned m = 0u;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-        m = max(m, __float_as_uint(fabsf(x[i])));
+    const int64_t n4 = n >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = x4[i];
+        m = max(max(m, __float_as_uint(fabsf(v.x))), __float_as_uint(fabsf(v.y)));
+        m = max(max(m, __float_as_uint(fabsf(v.z))), __float_as_uint(fabsf(v.w)));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3))
+        m = max(m, __float_as_uint(fabsf(x[(n4 << 2) + threadIdx.x])));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(part[0], part[1]), max(part[2], part[3]));
+        if (m) atomicMax(out, m);   // one atomic per block
+    }
 }
 
 hipError_t launch_absmax_bits(const float* x, int64_t n, unsigned* out, hipStream_t stream) {
-    int64_t blocks = (n + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    int64_t blocks = ((n >> 2) + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
     hipLaunchKernelGGL(absmax_bits_kernel, dim3(blocks), dim3(256), 0, stream, x, n, out);
     return hipGetLastError();
 }

@@ -14,6 +14,7 @@ using H64x128s2 = H3Tile<64, 128, 2, 2, 2, 2>;      // 32x64 per wave
 using H128x128w8s3 = H3Tile<128, 128, 4, 2, 3, 2>;  // 8 waves, 32x64 per wave, 96 KiB
 using H128x128w8s2 = H3Tile<128, 128, 4, 2, 2, 2>;  // 8 waves, 64 KiB, 2 blocks/CU (16 waves)
 using H128x256s2 = H3Tile<128, 256, 2, 4, 2, 2>;    // 8 waves, 64x64 per wave, 96 KiB
+using H64x512ln = H3Tile<64, 512, 2, 4, 2, 2>;      // 8 waves, 32x128 per wave: full rows of d = 512 (LN fused)
 using H256x128w16 = H3Tile<256, 128, 8, 2, 3, 4>;   // 16 waves, 32x64 per wave, 3 stages = 144 KiB
 using H128x256w16 = H3Tile<128, 256, 4, 4, 3, 4>;   // 16 waves, 32x64 per wave
 
@@ -60,6 +61,10 @@ int gemm_h3_auto_tile(int M, int N) {
 
 hipError_t launch_gemm_h3(int epi, const H3Params& p, int tile, hipStream_t s) {
     if (p.K % 32 != 0 || p.N % 8 != 0 || p.M <= 0 || p.N <= 0) return hipErrorInvalidValue;
+    if (epi == H3_RESID_LN) {
+        if (p.N != 512 || !p.R || !p.ln_g || !p.ln_b || !p.C) return hipErrorInvalidValue;
+        return launch_h3_one<H64x512ln, H3_RESID_LN>(p, s);
+    }
     if (tile == 0) tile = gemm_h3_auto_tile(p.M, p.N);
     switch (epi) {
         case H3_PLAIN: return launch_h3_tiles<H3_PLAIN>(p, tile, s);

@@ -49,7 +49,8 @@ struct H3Tile {
     static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     static constexpr int STAGE = (BM + BN) * 128;  // bytes: A rows then W rows, 128 B each
     static constexpr int PW = (BM + BN) / 8 / NW;  // LDS-DMA pieces (1 KiB = 8 rows) per wave per stage
-    static constexpr size_t LDS_BYTES = (size_t)NSTAGE * STAGE;
+    static constexpr size_t EPI_BYTES = (size_t)NW * 32 * 32 * TN * 4 + 2 * WN * BM * 4;  // transpose + LN sums
+    static constexpr size_t LDS_BYTES = (size_t)NSTAGE * STAGE > EPI_BYTES ? (size_t)NSTAGE * STAGE : EPI_BYTES;
     static_assert(NSTAGE == 2 || NSTAGE == 3, "NSTAGE");
     static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "wave tile must be 32-aligned");
     static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "DMA pieces per wave");
@@ -193,7 +194,95 @@ __global__ __launch_bounds__(TC::NT, TC::MINW) void gemm_h3_kernel(const H3Param
     // ---- epilogue ---------------------------------------------------------------------------------
     bool overflow = false;
     if ((p.dbg & 2) && acc0[0][0][0] != 12345.678f) return;
-    {
+    if constexpr (EPI == H3_RESID_LN) {
+        // y = LayerNorm((v + bias) + R) over the full row (the block tile spans all N = BN columns):
+        // nn.TransformerEncoderLayer.norm1/norm2 (post-norm, eps 1e-5, biased variance, two-pass as
+        // in layernorm_kernel).  Row sums: 32 lanes of a row by shuffles, the WN waves through LDS.
+        static_assert(TM == 1, "LN epilogue: one 32-row fragment per wave");
+        constexpr int ROWLEN = 32 * TN, LPR = ROWLEN / 4, RPI = 64 / LPR, NIT = 32 / RPI;
+        static_assert(LPR == 32, "LN epilogue written for 128-column wave tiles");
+        float* wl = reinterpret_cast<float*>(lds) + wave * (32 * ROWLEN);
+        float* red = reinterpret_cast<float*>(lds) + NW * (32 * ROWLEN);   // [2][WN][BM]
+        const int rl = lane / LPR, cl = (lane % LPR) * 4;
+        const int n = wn * ROWLEN + cl;
+        const float4 bias4 = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 g4 = *reinterpret_cast<const float4*>(p.ln_g + n);
+        const float4 b4 = *reinterpret_cast<const float4*>(p.ln_b + n);
+        const float inv_n = 1.0f / (float)BN;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                wl[mfma32_row(r, lane) * ROWLEN + j * 32 + l31] = acc0[0][j][r] + acc1[0][j][r] * kLoInv;
+        float x[NIT][4];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int row = it * RPI + rl;
+            int m = m0 + wm * 32 + row;
+            const bool mok = m < p.M;
+            m = mok ? m : p.M - 1;
+            const float4 t = *reinterpret_cast<const float4*>(wl + row * ROWLEN + cl);
+            const float4 rr = *reinterpret_cast<const float4*>(p.R + (size_t)m * BN + n);
+            x[it][0] = (t.x + bias4.x) + rr.x; x[it][1] = (t.y + bias4.y) + rr.y;
+            x[it][2] = (t.z + bias4.z) + rr.z; x[it][3] = (t.w + bias4.w) + rr.w;
+            if (p.aux && mok)
+                *reinterpret_cast<float4*>(p.aux + (size_t)m * BN + n) = make_float4(x[it][0], x[it][1], x[it][2], x[it][3]);
+            float sm = (x[it][0] + x[it][1]) + (x[it][2] + x[it][3]);
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+            if ((lane & 31) == 0) red[wn * BM + wm * 32 + row] = sm;
+        }
+        __syncthreads();
+        float mean[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int row = wm * 32 + it * RPI + rl;
+            float sm = 0.f;
+#pragma unroll
+            for (int w = 0; w < TC::WN; ++w) sm += red[w * BM + row];
+            mean[it] = sm * inv_n;
+            const float a = x[it][0] - mean[it], b = x[it][1] - mean[it], c = x[it][2] - mean[it], d = x[it][3] - mean[it];
+            float q = (a * a + b * b) + (c * c + d * d);
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+            if ((lane & 31) == 0) red[(TC::WN + wn) * BM + row] = q;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int row = wm * 32 + it * RPI + rl;
+            const int m = m0 + row;
+            float q = 0.f;
+#pragma unroll
+            for (int w = 0; w < TC::WN; ++w) q += red[(TC::WN + w) * BM + row];
+            const float rstd = 1.0f / sqrtf(q * inv_n + 1e-5f);
+            if (m >= p.M) continue;
+            if (p.ln_stats && wn == 0 && (lane & 31) == 0) {
+                p.ln_stats[2 * (size_t)m] = mean[it];
+                p.ln_stats[2 * (size_t)m + 1] = rstd;
+            }
+            float y[4];
+            y[0] = (x[it][0] - mean[it]) * rstd * g4.x + b4.x;
+            y[1] = (x[it][1] - mean[it]) * rstd * g4.y + b4.y;
+            y[2] = (x[it][2] - mean[it]) * rstd * g4.z + b4.z;
+            y[3] = (x[it][3] - mean[it]) * rstd * g4.w + b4.w;
+            *reinterpret_cast<float4*>(p.C + (size_t)m * BN + n) = make_float4(y[0], y[1], y[2], y[3]);
+            if (p.Cs) {
+                h4 oh, ol;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    _Float16 a, b;
+                    split_f16(y[e], a, b);
+                    oh[e] = a; ol[e] = b;
+                    overflow |= !(fabsf(y[e]) < 65504.0f);
+                }
+                _Float16* dst = p.Cs + (size_t)m * (2 * BN) + split_pos(n);
+                *reinterpret_cast<h4*>(dst) = oh;
+                *reinterpret_cast<h4*>(dst + 32) = ol;
+            }
+        }
+        if (overflow && p.range_flag) atomicOr(p.range_flag, 1);
+    } else {
         constexpr int ROWLEN = 32 * TN;          // floats per row of the wave's tile
         constexpr int LPR = ROWLEN / 4;          // lanes per row (float4 each)
         constexpr int RPI = 64 / LPR;            // rows per wave-instruction
@@ -219,6 +308,8 @@ __global__ __launch_bounds__(TC::NT, TC::MINW) void gemm_h3_kernel(const H3Param
                 if (m >= p.M || !nok) continue;
                 float v[4] = {t.x + bias4.x, t.y + bias4.y, t.z + bias4.z, t.w + bias4.w};
                 const size_t off = (size_t)m * p.ldc + n;
+                // (non-temporal stores were measured: faster in isolation, slower in the layer chain —
+                // the next kernel then finds its input in HBM instead of the memory-side cache)
                 if constexpr (EPI == H3_PLAIN) {
                     *reinterpret_cast<float4*>(p.C + off) = make_float4(v[0], v[1], v[2], v[3]);
                 } else if constexpr (EPI == H3_RESID) {

@@ -47,6 +47,8 @@ enum H3Epi {
     H3_RESID = 2,       // C = (v + bias[n]) + R[m][n]                       (fp32)
     H3_PLAIN_SPLIT = 3, // aux = v + bias (optional fp32 copy); Cs = split(v + bias[n])
     H3_GELUGRAD_SPLIT = 4, // Cs = split(v * gelu'(aux[m][n]))   (backward through linear1's GELU)
+    H3_RESID_LN = 5,    // x = (v + bias) + R; aux = x (optional); y = LayerNorm(x) -> C (fp32) and Cs (split,
+                        // optional); needs a tile that spans the whole row (N == BN)
 };
 
 struct H3Params {
@@ -57,6 +59,9 @@ struct H3Params {
     _Float16* Cs;       // split output [M][2N]
     const float* R;     // residual [M][ldc]
     float* aux;         // optional pre-activation stash [M][ldc]
+    const float* ln_g;  // H3_RESID_LN: LayerNorm weight / bias [N], optional (mean, rstd) [M][2]
+    const float* ln_b;
+    float* ln_stats;
     int* range_flag;    // set to 1 if a split output leaves the f16 range
     int M, N, K, ldc;
     int dbg;            // bench-only ablations: 1 = no in-loop loads, 2 = no epilogue stores

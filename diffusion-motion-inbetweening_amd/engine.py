@@ -327,6 +327,20 @@ def gemm_h3(a_split: torch.Tensor, w_split: torch.Tensor, bias: Optional[torch.T
     return c
 
 
+def gemm_h3_ln(a_split, w_split, bias, resid, gamma, beta, want_split: bool = False):
+    """LayerNorm((A · Wᵀ + bias) + resid) with the normalisation fused into the GEMM epilogue (test hook)."""
+    lib = N.load()
+    m, k2 = a_split.shape
+    n = w_split.shape[0]
+    y = torch.empty((m, n), dtype=torch.float32, device=a_split.device)
+    ys = torch.empty((m, 2 * n), dtype=torch.float16, device=a_split.device) if want_split else None
+    with torch.cuda.device(a_split.device):
+        N.check(lib.cmdi_gemm_h3_ln(N.ptr(a_split), N.ptr(w_split), N.ptr(bias), N.ptr(resid),
+                                    N.ptr(gamma), N.ptr(beta), N.ptr(y), N.ptr(ys), m, n, k2 // 2,
+                                    N.current_stream(a_split.device)))
+    return (y, ys) if want_split else y
+
+
 def unsplit_f16(s: torch.Tensor) -> torch.Tensor:
     """Inverse of split_f16 (exact in float64, returned as fp32)."""
     c = s.view(s.shape[0], -1, 2, 32).double()

@@ -211,6 +211,11 @@ int cmdi_gemm_h3(const void* d_a_split, const void* d_w_split, const float* d_bi
 /* Self-attention core alone (test / bench hook): d_qkv [n_seq*S, 3*H*128] -> d_out [n_seq*S, H*128]. */
 int cmdi_attention_fwd(const float* d_qkv, float* d_out, int32_t n_seq, int32_t seq_len,
                        int32_t n_heads, cmdi_stream stream);
+/* Y = LayerNorm((A · W^T + bias) + resid; gamma, beta, eps 1e-5) with the normalisation fused into the
+ * GEMM epilogue (N must be 512 = d_model); d_y fp32 [M,N], d_y_split optional split rows [M,2N]. */
+int cmdi_gemm_h3_ln(const void* d_a_split, const void* d_w_split, const float* d_bias,
+                    const float* d_resid, const float* d_gamma, const float* d_beta, float* d_y,
+                    void* d_y_split, int32_t m, int32_t n, int32_t k, cmdi_stream stream);
 /* The same on the f16 matrix pipe (split-f16 products): d_qkv_split = cmdi_split_f16 of d_qkv. */
 int cmdi_attention_fwd_h3(const void* d_qkv_split, float* d_out, int32_t n_seq, int32_t seq_len,
                           int32_t n_heads, cmdi_stream stream);

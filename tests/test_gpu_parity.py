@@ -127,6 +127,24 @@ def test_gemm_h3(tile, shape):
     assert rel_l2(out.numpy(), ref.numpy()) <= 2e-6
 
 
+@pytest.mark.parametrize("shape", [(333, 512), (12608, 1024), (64, 32)])
+def test_fused_layernorm_gemm(shape):
+    """out = LayerNorm(A·Wᵀ + b + R) with the normalisation inside the GEMM epilogue, vs float64."""
+    eng = sub("engine")
+    m, k = shape
+    g = torch.Generator().manual_seed(m + k)
+    a = torch.randn(m, k, generator=g)
+    w = torch.randn(512, k, generator=g) * 0.05 * (torch.arange(512).float()[:, None] % 5 + 1)
+    b, r = torch.randn(512, generator=g), torch.randn(m, 512, generator=g)
+    gamma, beta = torch.rand(512, generator=g) + 0.5, torch.randn(512, generator=g)
+    x = a.double() @ w.double().T + b.double() + r.double()
+    ref = torch.nn.functional.layer_norm(x, (512,), gamma.double(), beta.double(), 1e-5)
+    y, ys = eng.gemm_h3_ln(eng.split_f16(a.to(DEV)), eng.split_f16(w.to(DEV)), b.to(DEV), r.to(DEV),
+                           gamma.to(DEV), beta.to(DEV), want_split=True)
+    assert rel_l2(y.cpu().numpy(), ref.numpy()) <= 2e-6, rel_l2(y.cpu().numpy(), ref.numpy())
+    assert rel_l2(eng.unsplit_f16(ys).cpu().numpy(), ref.numpy()) <= 2e-6
+
+
 def test_f16x3_range_guard():
     """|x| >= 65504 cannot be split: weights are refused at finalize, activations raise after the run."""
     N = sub("_native")
