@@ -75,6 +75,8 @@ __global__ __launch_bounds__(TC::NT, TC::MINW) void gemm_h3_kernel(const H3Param
     const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
 
+    long long t_start = 0, t_loop = 0, t_loop_end = 0, r_start = 0;
+    if (p.dbg & 16) { t_start = __builtin_readcyclecounter(); r_start = __builtin_amdgcn_s_memrealtime(); }
     f32x16 acc0[TM][TN], acc1[TM][TN];   // [A fragment (rows m)][W fragment (cols n)]
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -136,6 +138,7 @@ __global__ __launch_bounds__(TC::NT, TC::MINW) void gemm_h3_kernel(const H3Param
     if (NSTAGE == 3 && nk > 1) wait_vmcnt<PW>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
 
+    if (p.dbg & 16) t_loop = __builtin_readcyclecounter();
     int cur = 0, nxt = NSTAGE - 1;   // stage being multiplied / stage being filled
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + NSTAGE - 1 < nk;
@@ -191,6 +194,7 @@ __global__ __launch_bounds__(TC::NT, TC::MINW) void gemm_h3_kernel(const H3Param
         nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
     }
 
+    if (p.dbg & 16) t_loop_end = __builtin_readcyclecounter();
     // ---- epilogue ---------------------------------------------------------------------------------
     bool overflow = false;
     if ((p.dbg & 2) && acc0[0][0][0] != 12345.678f) return;
@@ -345,6 +349,17 @@ __global__ __launch_bounds__(TC::NT, TC::MINW) void gemm_h3_kernel(const H3Param
     }
     if constexpr (EPI == H3_GELU_SPLIT || EPI == H3_PLAIN_SPLIT || EPI == H3_GELUGRAD_SPLIT) {
         if (overflow && p.range_flag) atomicOr(p.range_flag, 1);
+    }
+    if ((p.dbg & 16) && p.dbg_buf && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        long long* o = p.dbg_buf + (size_t)blockIdx.x * 6;
+        o[0] = t_start; o[1] = t_loop; o[2] = t_loop_end; o[3] = __builtin_readcyclecounter();
+        o[4] = r_start; o[5] = __builtin_amdgcn_s_memrealtime();   // 100 MHz constant clock
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        o[2] = (o[2] - o[1]);   // loop duration
+        o[1] = (long long)(((unsigned long long)xcc << 32) | hwid);
     }
 }
 
