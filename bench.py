@@ -234,7 +234,7 @@ def main():
             peak = F16_MFMA_PEAK_TFLOPS / 3.0
             out["roofline"] = {
                 "kernel": f"gemm_h3_kernel (self_attn.in_proj, M={m} N={n} K={k}, 3x v_mfma_f32_32x32x16_f16 "
-                          "per fp32-equivalent product)",
+                          "per fp32-equivalent product, split-rows output)",
                 "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                 "traffic": traffic, "launches": launches, "avg_launch_us": avg_s * 1e6,
                 "flops_per_launch": flop_launch, "executed_f16_tflops": 3.0 * ach,
