@@ -1086,8 +1086,12 @@ int cmdi_attention_fwd_h3(const void* d_qkv_split, float* d_out, int32_t n_seq, 
                           int32_t n_heads, cmdi_stream stream) {
     if (!d_qkv_split || !d_out || n_seq < 1 || seq_len < 1 || seq_len > 224 || n_heads < 1)
         return fail(CMDI_E_INVALID, "bad argument");
+    // (CMDI_ATTN_DBG & 16, bench only: 32 B of cycle stamps per block are written BEHIND the output,
+    // the caller allocates n_seq * n_heads * 32 extra bytes)
+    static const bool stamps = std::getenv("CMDI_ATTN_DBG") && (std::atoi(std::getenv("CMDI_ATTN_DBG")) & 16);
     HIPCHK(launch_attention_h3(static_cast<const _Float16*>(d_qkv_split), d_out, nullptr, nullptr,
-                               nullptr, n_seq, seq_len, n_heads, static_cast<hipStream_t>(stream)));
+                               stamps ? d_out + (size_t)n_seq * seq_len * n_heads * 128 : nullptr, n_seq, seq_len, n_heads,
+                               static_cast<hipStream_t>(stream)));
     return CMDI_OK;
 }
 

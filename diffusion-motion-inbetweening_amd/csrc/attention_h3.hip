@@ -6,8 +6,9 @@
 // 32 hi halves then 32 lo halves (lo = (x - hi)·2^11), so one head of Q, K or V of one token is 512
 // contiguous bytes.  d_head = 128, S <= 224.
 //
-// Work split: grid = (B'·H, ceil(S/128)); 4 waves per block, 2 blocks per CU; a wave owns 32 queries.
-// K / V stream through LDS in 32-key stages (LDS-DMA, double buffered, 32 KiB per stage).
+// Work split: grid = (B'·H, ceil(S/256)); 8 waves per block (one block per (sequence, head) and CU:
+// K / V are staged once, not once per query half); a wave owns 32 queries.
+// K / V stream through LDS in 32-key stages (LDS-DMA, ring of 4 stages x 32 KiB, 3 in flight).
 // Per 32-key block a wave computes, with v_mfma_f32_32x32x16_f16,
 //   Sᵀ = K·Qᵀ        operands swapped so that a lane owns ONE query (column) and 16 keys: row max /
 //                    sum are in-lane plus one lane^32 exchange; three accumulators (hi·hi, hi·lo,
@@ -18,6 +19,8 @@
 //                    to 2^-25 absolute, and the three products V_hi·p_hi + V_hi·p_lo +
 //                    V_lo'·(p_hi·2^-11) share ONE accumulator.  Vᵀ fragments come from the row-major
 //                    V tile through ds_read_b64_tr_b16 (hardware 4x4 transpose).
+#include <cstdlib>
+
 #include "common.hpp"
 #include "gemm_h3.hpp"
 #include "kernels.hpp"
@@ -27,10 +30,11 @@ namespace cmdi {
 namespace {
 constexpr int DH = 128;
 constexpr int KBLK = 32;                 // keys per stage
-constexpr int NWAVE = 4;
+constexpr int NWAVE = 8;                 // 256 queries per block: one block per (sequence, head) at S <= 224
 constexpr int ROWB = 512;                // bytes of one head of one token: 4 chunks x (64 B hi + 64 B lo)
 constexpr int TILE = KBLK * ROWB;        // 16 KiB per K or V tile
 constexpr int STAGE = 2 * TILE;
+constexpr int NSTG = 4;                  // LDS ring: 3 stages (96 KiB) in flight ahead of the one being used
 
 typedef short s4v __attribute__((ext_vector_type(4)));
 typedef short s8v __attribute__((ext_vector_type(8)));
@@ -44,7 +48,7 @@ __device__ __forceinline__ int kswz(int k) { return ((k & 3) << 2) | ((k >> 2) &
 __device__ __forceinline__ void stage_kv(char* stage, const _Float16* __restrict__ base, size_t ld,
                                          int koff, int voff, int key0, int S, int wave, int lane) {
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < 32 / NWAVE; ++it) {
         const int pc = it * NWAVE + wave;        // 0..15 K pieces, 16..31 V pieces (2 keys each)
         const int mat = pc >> 4, g = pc & 15;
         const int kl = 2 * g + (lane >> 5);
@@ -66,17 +70,19 @@ __device__ __forceinline__ h8 tr_pair(const char* p0, const char* p1) {
 }  // namespace
 
 template <bool STASH>
-__global__ __launch_bounds__(256, 2) void attention_h3_kernel(const _Float16* __restrict__ qkv,
+__global__ __launch_bounds__(64 * NWAVE, 2) void attention_h3_kernel(const _Float16* __restrict__ qkv,
                                                               float* __restrict__ out,
                                                               _Float16* __restrict__ out_s,
                                                               int* __restrict__ range_flag,
                                                               float* __restrict__ row_stats, int S,
-                                                              int H, float scale) {
+                                                              int H, float scale, int dbg) {
     extern __shared__ __attribute__((aligned(16))) char lds[];  // [2][K tile | V tile]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int bh = blockIdx.x, b = bh / H, h = bh % H;
     const int d_model = H * DH;
+    long long t0 = 0, t1 = 0, t2 = 0;
+    if (dbg & 16) t0 = __builtin_readcyclecounter();
     const size_t ld = 6 * (size_t)d_model;           // halves per token row of the split qkv
     const int qoff = 2 * h * DH, koff = 2 * (d_model + h * DH), voff = 2 * (2 * d_model + h * DH);
     const _Float16* base = qkv + (size_t)b * S * ld;
@@ -103,7 +109,8 @@ __global__ __launch_bounds__(256, 2) void attention_h3_kernel(const _Float16* __
     for (int db = 0; db < 4; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;   // m_run in log2 units
+    const float scale2 = scale * 1.4426950408889634f;
 
     // K fragment addressing: row l31, slot (ks>>1)*8 + plane*4 + (ks&1)*2 + hi, swizzled
     const int fk = kswz(l31);
@@ -116,14 +123,24 @@ __global__ __launch_bounds__(256, 2) void attention_h3_kernel(const _Float16* __
     const int v_slot = 2 * (G & 1) + ((L & 3) >> 1); // + db * 8 + plane * 4
     const int v_half = (L & 1) * 8;
 
-    stage_kv(lds, base, ld, koff, voff, 0, S, wave, lane);
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-    __syncthreads();
+    // K/V of a whole (sequence, head) is only 7 stages, each a fabric round trip: keep NSTG - 1 stages
+    // in flight (counted vmcnt, raw barrier) so the loop is not one memory latency per 32 keys.
+    constexpr int PCS = 32 / NWAVE;   // LDS-DMA pieces per wave per stage
+#pragma unroll
+    for (int st = 0; st < NSTG - 1; ++st)
+        if (st < nkb) stage_kv(lds + st * STAGE, base, ld, koff, voff, st * KBLK, S, wave, lane);
+    {
+        const int ahead = (nkb - 1 < NSTG - 2 ? nkb - 1 : NSTG - 2);   // stages allowed to stay in flight
+        if (ahead >= 2) wait_vmcnt<2 * PCS>(); else if (ahead == 1) wait_vmcnt<PCS>(); else wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    if (dbg & 16) t1 = __builtin_readcyclecounter();
 
     for (int kb = 0; kb < nkb; ++kb) {
-        const int cur = kb & 1;
-        if (kb + 1 < nkb)
-            stage_kv(lds + (cur ^ 1) * STAGE, base, ld, koff, voff, (kb + 1) * KBLK, S, wave, lane);
+        const int cur = kb % NSTG;
+        if (kb + NSTG - 1 < nkb)
+            stage_kv(lds + ((kb + NSTG - 1) % NSTG) * STAGE, base, ld, koff, voff, (kb + NSTG - 1) * KBLK, S,
+                     wave, lane);
         if (active) {
             const char* kt = lds + cur * STAGE;
             const char* vt = kt + TILE;
@@ -133,6 +150,7 @@ __global__ __launch_bounds__(256, 2) void attention_h3_kernel(const _Float16* __
             for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; a2[r] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
+                if ((dbg & 1) && ks > 0) break;   // bench-only ablation: 1/8 of the QK^T MFMAs
                 const int t = (ks >> 1) * 8 + (ks & 1) * 2 + hi;
                 const h8 kh = *reinterpret_cast<const h8*>(kt + k_row + ((t ^ fk) << 4));
                 const h8 kl = *reinterpret_cast<const h8*>(kt + k_row + (((t + 4) ^ fk) << 4));
@@ -140,23 +158,32 @@ __global__ __launch_bounds__(256, 2) void attention_h3_kernel(const _Float16* __
                 a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], a1, 0, 0, 0);
                 a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], a2, 0, 0, 0);
             }
+            // scores in log2 units: p = 2^(s2 - m2) with s2 = s * log2(e) (v_exp_f32 is a base-2
+            // exponential; the absolute error of p stays below 2.2e-8 because |x| 2^-24 e^-|x| <= 2^-24 / e)
             float s[16];
             float mloc = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = kb * KBLK + mfma32_row(r, lane);
-                const float v = (a0[r] + (a1[r] + a2[r]) * kLoInv) * scale;
-                s[r] = key < S ? v : -INFINITY;
+                s[r] = (a0[r] + (a1[r] + a2[r]) * kLoInv) * scale2;
                 mloc = fmaxf(mloc, s[r]);
+            }
+            if (kb == nkb - 1) {   // only the last block can hold keys past S (wave-uniform branch)
+                mloc = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb * KBLK + mfma32_row(r, lane);
+                    s[r] = key < S ? s[r] : -INFINITY;
+                    mloc = fmaxf(mloc, s[r]);
+                }
             }
             // ---- online softmax (per query = per lane column) -----------------------------------
             mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
             const float m_new = fmaxf(m_run, mloc);   // finite: every block holds a valid key
-            const float alpha = expf(m_run - m_new);  // exp(-inf) = 0 on the first block
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // 2^-inf = 0 on the first block
             float psum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                s[r] = expf(s[r] - m_new);            // masked keys: exp(-inf) = 0
+                s[r] = (dbg & 2) ? (s[r] - m_new) * 1e-3f : __builtin_amdgcn_exp2f(s[r] - m_new);   // masked keys: 2^-inf = 0
                 psum += s[r];
             }
             l_run = l_run * alpha + psum;             // partial over this lane's keys
@@ -168,15 +195,16 @@ __global__ __launch_bounds__(256, 2) void attention_h3_kernel(const _Float16* __
             // ---- Oᵀ += Vᵀ · Pᵀ -------------------------------------------------------------------
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                h8 ph, pl, ps;   // p_hi, p - p_hi (unscaled), p_hi * 2^-11
+                if ((dbg & 4) && kk > 0) break;   // bench-only ablation: half of the PV work
+                h8 ph, pl, ps;   // p_hi (round to nearest), p - p_hi (unscaled), p_hi * 2^-11
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float pv = s[8 * kk + e];
                     const _Float16 a = (_Float16)pv;
                     ph[e] = a;
                     pl[e] = (_Float16)(pv - (float)a);
-                    ps[e] = (_Float16)((float)a * kLoInv);
                 }
+                ps = ph * (_Float16)kLoInv;   // packed f16 multiply: exact (power of two) above 2^-14
                 h8 vh[4], vl[4];
 #pragma unroll
                 for (int db = 0; db < 4; ++db) {
@@ -198,17 +226,23 @@ __global__ __launch_bounds__(256, 2) void attention_h3_kernel(const _Float16* __
                     o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[db], ps, o[db], 0, 0, 0);
             }
         }
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        __syncthreads();
+        {   // stage kb+1 must have landed; later stages may stay in flight across the barrier
+            const int last = nkb - 1 < kb + NSTG - 1 ? nkb - 1 : kb + NSTG - 1;   // newest stage issued
+            const int ahead = last - (kb + 1);
+            if (ahead >= 2) wait_vmcnt<2 * PCS>(); else if (ahead == 1) wait_vmcnt<PCS>(); else wait_vmcnt<0>();
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
 
+    if (dbg & 16) t2 = __builtin_readcyclecounter();
     if (active) {
         const float lsum = l_run + __shfl_xor(l_run, 32, 64);
         const float inv = 1.0f / lsum;
         if (qok) {
             if constexpr (STASH) {
                 if (hi == 0) {
-                    row_stats[((size_t)bh * S + q) * 2] = m_run;
+                    row_stats[((size_t)bh * S + q) * 2] = m_run * 0.6931471805599453f;   // back to ln units
                     row_stats[((size_t)bh * S + q) * 2 + 1] = inv;
                 }
             }
@@ -246,15 +280,24 @@ __global__ __launch_bounds__(256, 2) void attention_h3_kernel(const _Float16* __
             }
         }
     }
+    if constexpr (!STASH) {
+        if ((dbg & 16) && row_stats && tid == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            long long* o = reinterpret_cast<long long*>(row_stats) + (size_t)blockIdx.x * 4;
+            o[0] = t1 - t0; o[1] = t2 - t1; o[2] = __builtin_readcyclecounter() - t2; o[3] = 0;
+        }
+    }
 }
 
+// (bench-only: with dbg & 16 and STASH == false, row_stats receives 4 cycle stamps per block)
 hipError_t launch_attention_h3(const _Float16* qkv_split, float* out, _Float16* out_split,
                                int* range_flag, float* row_stats, int n_seq, int S, int H,
                                hipStream_t stream) {
     if (S < 1 || S > 224) return hipErrorInvalidValue;
     dim3 grid(n_seq * H, (S + 32 * NWAVE - 1) / (32 * NWAVE));
     const float scale = 1.0f / sqrtf((float)DH);
-    constexpr size_t lds = 2ull * STAGE;  // 64 KiB
+    constexpr size_t lds = (size_t)NSTG * STAGE;  // 128 KiB: one block per CU
+    static const int dbg = std::getenv("CMDI_ATTN_DBG") ? std::atoi(std::getenv("CMDI_ATTN_DBG")) : 0;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_h3_kernel<true>),
@@ -265,12 +308,12 @@ hipError_t launch_attention_h3(const _Float16* qkv_split, float* out, _Float16* 
         if (e2 != hipSuccess) return e2;
         attr_done = true;
     }
-    if (row_stats)
+    if (row_stats && !(dbg & 16))
         hipLaunchKernelGGL(attention_h3_kernel<true>, grid, dim3(64 * NWAVE), lds, stream, qkv_split,
-                           out, out_split, range_flag, row_stats, S, H, scale);
+                           out, out_split, range_flag, row_stats, S, H, scale, dbg);
     else
         hipLaunchKernelGGL(attention_h3_kernel<false>, grid, dim3(64 * NWAVE), lds, stream, qkv_split,
-                           out, out_split, range_flag, row_stats, S, H, scale);
+                           out, out_split, range_flag, row_stats, S, H, scale, dbg);
     return hipGetLastError();
 }
 
