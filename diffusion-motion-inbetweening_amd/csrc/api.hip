@@ -40,6 +40,7 @@ struct LayerW {
 };
 struct LayerStash {
     float *qkv = nullptr, *attn = nullptr, *row_stats = nullptr;
+    _Float16* qkvS = nullptr;   // f16x3: the split qkv replaces the fp32 copy (attention fwd and bwd read it)
     float *pre1 = nullptr, *stats1 = nullptr, *aux = nullptr, *pre2 = nullptr, *stats2 = nullptr;
 };
 
@@ -88,7 +89,7 @@ struct cmdi_engine {
     // (fp32-equivalent split-f16 products on the f16 matrix pipe, gemm_h3.hpp)
     int precision = CMDI_PREC_F16X3;
     _Float16 *tokS = nullptr, *bufHS = nullptr, *attnS = nullptr, *ffnS = nullptr, *qkvS = nullptr;
-    _Float16 *dBS = nullptr, *dffnS = nullptr, *dqkvS = nullptr;  // backward operands (want_grad)
+    _Float16 *dBS = nullptr, *dffnS = nullptr, *dqkvS = nullptr, *dOS = nullptr;  // backward operands (want_grad)
     int* range_flag = nullptr;
     unsigned* gs_bits = nullptr;   // max|gout| bits -> power-of-two gradient scale (f16x3 backward)
     int h3_tile_qkv = 0, h3_tile_proj = 0, h3_tile_ffn1 = 0, h3_tile_ffn2 = 0;
@@ -96,6 +97,7 @@ struct cmdi_engine {
     // the full-row 64x512 tile it needs (197 blocks, 8 waves per CU) loses more in the GEMM than the
     // saved LayerNorm pass returns (B=32 CFG: 2.60 vs 2.29 ms per step on MI355X).
     int ln_fuse = 0;
+    int io_pipe = 0;   // 1: software-pipelined input / output projection GEMMs
     int gemm_tile = 0;
     int tile_inproj = 0, tile_proj = 0, tile_ffn1 = 0, tile_ffn2 = 0;  // per-GEMM overrides (0 = auto)
 
@@ -171,7 +173,7 @@ int run_layers(cmdi_engine* e, int seq0, int nseq, bool keep, bool prof, hipStre
     for (int l = 0; l < e->L; ++l) {
         const LayerW& w = e->layers[l];
         const LayerStash* st = keep ? &e->stash[l] : nullptr;
-        float* qkv = (keep ? st->qkv : e->qkv) + r0 * 3 * d;
+        float* qkv = (keep && !h3 ? st->qkv : e->qkv) + r0 * 3 * d;
         float* attn = (keep ? st->attn : e->attn) + r0 * d;
         float* pre1 = keep ? st->pre1 + r0 * d : tokB;
         float* pre2 = keep ? st->pre2 + r0 * d : tokB;
@@ -189,17 +191,16 @@ int run_layers(cmdi_engine* e, int seq0, int nseq, bool keep, bool prof, hipStre
                 }
                 HIPCHK(hipEventRecord(e->ev_pool[e->ev_used], s));
             }
-            {   // qkv leaves as split rows for the f16-pipe attention (+ an fp32 copy for the backward)
-                H3Params p = hp(tokS, w.in_ws, w.in_b, nullptr, qkvS, 3 * d, d);
-                p.aux = keep ? qkv : nullptr;
-                HIPCHK(launch_gemm_h3(H3_PLAIN_SPLIT, p, e->h3_tile_qkv, s));
-            }
+            // qkv leaves as split rows for the f16-pipe attention (stashed per layer for the backward)
+            _Float16* qkvL = keep ? st->qkvS + r0 * 6 * d : qkvS;
+            HIPCHK(launch_gemm_h3(H3_PLAIN_SPLIT, hp(tokS, w.in_ws, w.in_b, nullptr, qkvL, 3 * d, d),
+                                  e->h3_tile_qkv, s));
             if (prof) {
                 HIPCHK(hipEventRecord(e->ev_pool[e->ev_used + 1], s));
                 e->ev_used += 2;
                 e->prof_m = M; e->prof_n = 3 * d; e->prof_k = d;
             }
-            HIPCHK(launch_attention_h3(qkvS, keep ? attn : nullptr, attnS, e->range_flag, row_stats,
+            HIPCHK(launch_attention_h3(qkvL, keep ? attn : nullptr, attnS, e->range_flag, row_stats,
                                        nseq, S, e->H, s));
             if (e->ln_fuse) {   // x = norm1(x + out_proj(attn)) in one kernel
                 H3Params p = hp(attnS, w.out_ws, w.out_b, bufH, bufHS, d, d);
@@ -317,7 +318,7 @@ int mdm_forward(cmdi_engine* e, const float* x, const int64_t* t_dev, int64_t t_
     {   // InputProcess + sequence_pos_encoder for the frame tokens (mdm.py:271,279-280)
         GemmParams p = gp(x, e->w_in_pad, e->b_in, e->tokA, B * T, d, e->Cpad, 0, e->Cpad, d);
         p.pe = e->pe; p.T = T; p.S = S; p.Cf = C; p.Bdup = e->cfg ? B : 0;
-        HIPCHK(launch_gemm(GK_INPROJ, p, 0, s));
+        HIPCHK(launch_gemm(GK_INPROJ, p, e->io_pipe, s));
     }
     int rc = for_groups(e, n_seq, s, [&](int seq0, int nseq, hipStream_t gs) {
         return run_layers(e, seq0, nseq, keep, e->profile, gs);
@@ -326,7 +327,7 @@ int mdm_forward(cmdi_engine* e, const float* x, const int64_t* t_dev, int64_t t_
     {   // OutputProcess on tokens 1..T, stored straight into [n_seq, C, 1, T] (mdm.py:284,304,412-422)
         GemmParams p = gp(e->w_out, e->tokA, e->b_out, out_buf, C, n_seq * T, d, d, d, 0);
         p.T = T; p.S = S; p.Cf = C;
-        HIPCHK(launch_gemm(GK_OUTPROJ, p, 0, s));
+        HIPCHK(launch_gemm(GK_OUTPROJ, p, e->io_pipe, s));
     }
     e->stash_valid = keep;
     return CMDI_OK;
@@ -347,6 +348,7 @@ int run_layers_bwd(cmdi_engine* e, int seq0, int nseq, hipStream_t s) {
     _Float16* dBS = h3 ? e->dBS + r0 * 2 * d : nullptr;
     _Float16* dffnS = h3 ? e->dffnS + r0 * 2 * f : nullptr;
     _Float16* dqkvS = h3 ? e->dqkvS + r0 * 6 * d : nullptr;
+    _Float16* dOS = h3 ? e->dOS + r0 * 2 * d : nullptr;
     auto hp = [&](const _Float16* A, const _Float16* W, float* C, _Float16* Cs, int N, int K) {
         H3Params p{};
         // gradients carry no range flag: a gradient beyond the f16 range would already have shown
@@ -372,12 +374,14 @@ int run_layers_bwd(cmdi_engine* e, int seq0, int nseq, hipStream_t s) {
                 HIPCHK(launch_gemm_h3(H3_RESID, p, e->h3_tile_ffn2, s));
             }
             HIPCHK(launch_layernorm_bwd(st.pre1 + r0 * d, st.stats1 + r0 * 2, w.n1_g, dH, dB, dBS, M, d, s));
-            // d attn = dB · Wo -> dH
-            HIPCHK(launch_gemm_h3(H3_PLAIN, hp(dBS, w.out_wTs, dH, nullptr, d, d), e->h3_tile_proj, s));
-            HIPCHK(launch_attention_bwd(st.qkv + r0 * 3 * d, st.attn + r0 * d,
-                                        st.row_stats + (size_t)seq0 * e->H * S * 2, dH, dqkv,
-                                        e->drowdot + (size_t)seq0 * e->H * S, nseq, S, e->H, s));
-            HIPCHK(launch_split_f16(dqkv, dqkvS, M, 3 * d, 3 * d, nullptr, s));
+            {   // d attn = dB · Wo -> dH (fp32, for D = rowsum(dO*O)) and dOS (split, MFMA operand)
+                H3Params p = hp(dBS, w.out_wTs, nullptr, dOS, d, d);
+                p.aux = dH;
+                HIPCHK(launch_gemm_h3(H3_PLAIN_SPLIT, p, e->h3_tile_proj, s));
+            }
+            HIPCHK(launch_attention_bwd_h3(st.qkvS + r0 * 6 * d, st.attn + r0 * d,
+                                           st.row_stats + (size_t)seq0 * e->H * S * 2, dH, dOS, dqkvS,
+                                           e->drowdot + (size_t)seq0 * e->H * S, nseq, S, e->H, s));
             {   // dA = dqkv · Wqkv + dB
                 H3Params p = hp(dqkvS, w.in_wTs, dA, nullptr, d, 3 * d);
                 p.R = dB;
@@ -547,6 +551,7 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
     e->tile_ffn1 = env_int("CMDI_TILE_FFN1", e->gemm_tile);
     e->tile_ffn2 = env_int("CMDI_TILE_FFN2", e->gemm_tile);
     e->n_groups = env_int("CMDI_GROUPS", 0);  // 0 = automatic
+    e->io_pipe = env_int("CMDI_IO_PIPE", 0);
     {
         int prec = desc->precision;
         if (prec == CMDI_PREC_DEFAULT) {
@@ -611,13 +616,16 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
                 ALLOC(w.l1_wTs, (size_t)f * d * 2); ALLOC(w.l2_wTs, (size_t)d * f * 2);
             }
             ALLOC(e->dBS, Mmax * d * 2); ALLOC(e->dffnS, Mmax * f * 2); ALLOC(e->dqkvS, Mmax * 3 * d * 2);
+            ALLOC(e->dOS, Mmax * d * 2);
         }
     }
     if (desc->want_grad) {
         ALLOC(e->w_inT, (size_t)C * d); ALLOC(e->w_outT_pad, (size_t)d * e->Cpad);
         e->stash.resize(e->L);
         for (LayerStash& st : e->stash) {
-            ALLOC(st.qkv, Mmax * 3 * d); ALLOC(st.attn, Mmax * d);
+            if (e->precision == CMDI_PREC_F16X3) ALLOC(st.qkvS, Mmax * 3 * d * 2);
+            else ALLOC(st.qkv, Mmax * 3 * d);
+            ALLOC(st.attn, Mmax * d);
             ALLOC(st.row_stats, nseq * e->H * Smax * 2);
             ALLOC(st.pre1, Mmax * d); ALLOC(st.stats1, Mmax * 2); ALLOC(st.aux, Mmax * f);
             ALLOC(st.pre2, Mmax * d); ALLOC(st.stats2, Mmax * 2);

@@ -81,8 +81,12 @@ hipError_t launch_gemm(GemmKind kind, const GemmParams& p, int tile, hipStream_t
         case GK_ACCUM: return launch_plain_tiles<EPI_ACCUM>(p, tile, s);
         case GK_GELUGRAD: return launch_plain_tiles<EPI_GELUGRAD>(p, tile, s);
         case GK_SILU: return launch_one<T64x64, ROWS_PLAIN, ROWS_PLAIN, EPI_SILU>(p, s);
-        case GK_INPROJ: return launch_one<T64x128, ROWS_MOTION, ROWS_PLAIN, EPI_INPROJ>(p, s);
-        case GK_OUTPROJ: return launch_one<T64x128, ROWS_PLAIN, ROWS_TOK, EPI_MOTION>(p, s);
+        case GK_INPROJ:
+            return tile == 1 ? launch_one<T64x128, ROWS_MOTION, ROWS_PLAIN, EPI_INPROJ, 1>(p, s)
+                             : launch_one<T64x128, ROWS_MOTION, ROWS_PLAIN, EPI_INPROJ>(p, s);
+        case GK_OUTPROJ:
+            return tile == 1 ? launch_one<T64x128, ROWS_PLAIN, ROWS_TOK, EPI_MOTION, 1>(p, s)
+                             : launch_one<T64x128, ROWS_PLAIN, ROWS_TOK, EPI_MOTION>(p, s);
         case GK_OUTPROJ_BWD: return launch_one<T64x128, ROWS_MOTION, ROWS_PLAIN, EPI_TOKOUT>(p, s);
     }
     return hipErrorInvalidValue;

@@ -42,6 +42,10 @@ hipError_t launch_attention_fwd(const float* qkv, float* out, _Float16* out_spli
 hipError_t launch_attention_h3(const _Float16* qkv_split, float* out, _Float16* out_split,
                                int* range_flag, float* row_stats, int n_seq, int S, int H,
                                hipStream_t stream);
+// backward on the f16 pipe: everything in split rows except o_fwd / d_out (fp32, for D = rowsum(dO*O))
+hipError_t launch_attention_bwd_h3(const _Float16* qkv_split, const float* o_fwd, const float* row_stats,
+                                   const float* d_out, const _Float16* d_out_split, _Float16* d_qkv_split,
+                                   float* d_rowdot, int n_seq, int S, int H, hipStream_t stream);
 // ---- attention_bwd_f32.hip ------------------------------------------------------------------
 // d_qkv[M,3d] from d_out[M,d]; P is recomputed from the forward's row statistics; d_rowdot is a
 // [n_seq*H*S] scratch (D = rowsum(dO*O)) written by the dQ kernel and read by the dK/dV kernel.
