@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay each denoising step as a hipGraph")
     ap.add_argument("--precision", default=None, choices=["f32", "f16x3"],
                     help="encoder GEMM arithmetic (include/condmdi.h CMDI_PREC_*); default: the library's")
     args = ap.parse_args()
@@ -148,6 +149,7 @@ def main():
     model.native_precision = args.precision
     eng = model.engine(dev, max_batch=B, max_frames=T_FRAMES, want_grad=cfg["edit"])
     split = eng.precision == "f16x3"
+    eng.set_graph(args.graph)
     eng.set_schedule(diffusion.engine_tables(), key="bench")
 
     # synthetic per-rank inputs keyed by GLOBAL sample index (rank r owns samples [r*B, (r+1)*B))
@@ -203,7 +205,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": ("f32 (products as 3 split-f16 MFMAs on 22-bit operand pairs, fp32 accumulate; same "
                   "parity tolerances as exact fp32)") if split else "f32",
-        "precision_mode": eng.precision,
+        "precision_mode": eng.precision, "hip_graph": bool(args.graph),
         "data": "synthetic (random-init MDM weights, z-scored N(0,1) motions, fake CLIP embeddings)",
         "config": {"workload": cfg["desc"], "batch_per_gpu": B, "global_batch": world * B,
                    "n_frames": T_FRAMES, "n_feats": N_FEATS, "chain_steps": n_chain,

@@ -66,6 +66,7 @@ SIGNATURES = {
     "cmdi_mdm_vjp": (C.c_int, [_VP, _VP, _VP, _VP]),
     "cmdi_step": (C.c_int, [_VP, _I32, _I32, _F, _VP, _VP, _VP, _U64, _I64, _VP]),
     "cmdi_sample_loop": (C.c_int, [_VP, _I32, _I32, _I32, _F, _VP, _VP, _U64, _I64, _VP]),
+    "cmdi_set_graph": (C.c_int, [_VP, _I32]),
     "cmdi_sampler_update": (C.c_int, [_VP, _I32, _I32, _F, _VP, _VP, _VP, _VP, _VP, _U64, _I64, _VP]),
     "cmdi_q_sample": (C.c_int, [_VP, _I32, _VP, _VP, _VP, _I64, _VP]),
     "cmdi_randn": (C.c_int, [_VP, _VP, _I32, _I64, _U64, _I64, _I32, _VP]),

@@ -108,6 +108,22 @@ struct cmdi_engine {
     std::vector<hipStream_t> gstreams;
     std::vector<hipEvent_t> gevents;  // [0] = fork, [1 + g] = join of group g
 
+    // hipGraph replay of whole denoising steps (cmdi_sample_loop): per-step scalars live in device
+    // tables indexed by a device cursor, so ONE captured launch sequence serves every step.
+    int use_graph = 0;                 // CMDI_GRAPH=1 / cmdi_set_graph
+    StepCoef* coef_dev = nullptr;      // [n_steps] for the (sampler, eta) of the running chain
+    int64_t* tmap_dev = nullptr;       // [n_steps] timestep_map
+    int* cursor_dev = nullptr;         // current respaced step index
+    int table_cap = 0;
+    hipGraphExec_t graph_exec[2] = {nullptr, nullptr};   // [reconstruction guidance active?]
+    bool graph_warm[2] = {false, false};
+    hipStream_t graph_stream = nullptr;
+    hipStream_t own_stream = nullptr;   // capture cannot start on the legacy default stream
+    hipEvent_t own_ev[2] = {nullptr, nullptr};
+    uint64_t graph_seed = 0;
+    int64_t graph_first = 0;
+    float* graph_x = nullptr;
+
     // optional live timing of the in_proj GEMM (bench.py roofline leg)
     bool profile = false;
     std::vector<hipEvent_t> ev_pool;
@@ -136,6 +152,14 @@ int falloc(cmdi_engine* e, Tp** p, size_t count) {
         int _rc = falloc(e, &(ptr), (count));   \
         if (_rc != CMDI_OK) return _rc;         \
     } while (0)
+
+void drop_graphs(cmdi_engine* e) {
+    for (int i = 0; i < 2; ++i) {
+        if (e->graph_exec[i]) (void)hipGraphExecDestroy(e->graph_exec[i]);
+        e->graph_exec[i] = nullptr;
+        e->graph_warm[i] = false;
+    }
+}
 
 GemmParams gp(const float* A, const float* W, const float* bias, float* C, int M, int N, int K,
               int lda, int ldw, int ldc) {
@@ -309,12 +333,13 @@ int for_groups(cmdi_engine* e, int n_seq, hipStream_t s, Fn fn) {
 
 // ---- forward pass of MDM trans_enc (model/mdm.py:239-306) over n_seq = B or 2B sequences --------
 int mdm_forward(cmdi_engine* e, const float* x, const int64_t* t_dev, int64_t t_scalar,
-                float* out_buf, bool keep, hipStream_t s) {
+                float* out_buf, bool keep, hipStream_t s, bool tables = false) {
     const int B = e->B, T = e->T, S = T + 1, d = e->d, C = e->C;
     const int n_seq = e->cfg ? 2 * B : B;
 
     HIPCHK(launch_token0(e->tokA, e->time_table, e->have_text ? e->text_term : nullptr, e->pe, t_dev,
-                         t_scalar, n_seq, B, S, d, e->n_time_rows, s));
+                         t_scalar, n_seq, B, S, d, e->n_time_rows, s, tables ? e->tmap_dev : nullptr,
+                         tables ? e->cursor_dev : nullptr));
     {   // InputProcess + sequence_pos_encoder for the frame tokens (mdm.py:271,279-280)
         GemmParams p = gp(x, e->w_in_pad, e->b_in, e->tokA, B * T, d, e->Cpad, 0, e->Cpad, d);
         p.pe = e->pe; p.T = T; p.S = S; p.Cf = C; p.Bdup = e->cfg ? B : 0;
@@ -552,6 +577,7 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
     e->tile_ffn2 = env_int("CMDI_TILE_FFN2", e->gemm_tile);
     e->n_groups = env_int("CMDI_GROUPS", 0);  // 0 = automatic
     e->io_pipe = env_int("CMDI_IO_PIPE", 0);
+    e->use_graph = env_int("CMDI_GRAPH", 0);
     {
         int prec = desc->precision;
         if (prec == CMDI_PREC_DEFAULT) {
@@ -666,6 +692,9 @@ int cmdi_profile_read(cmdi_handle e, double* total_ms, int64_t* launches, int32_
 
 int cmdi_destroy(cmdi_handle h) {
     if (!h) return CMDI_OK;
+    drop_graphs(h);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    for (hipEvent_t ev : h->own_ev) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : h->ev_pool) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : h->gevents) (void)hipEventDestroy(ev);
     for (hipStream_t st : h->gstreams) (void)hipStreamDestroy(st);
@@ -801,6 +830,7 @@ int cmdi_set_schedule(cmdi_handle e, const cmdi_schedule* sc) {
     for (int i = 0; i < n; ++i)
         if (e->tmap[i] < 0) return fail(CMDI_E_INVALID, "negative timestep in timestep_map");
     e->have_schedule = true;
+    drop_graphs(e);
     return CMDI_OK;
 }
 
@@ -849,6 +879,7 @@ int cmdi_set_condition(cmdi_handle e, const cmdi_condition* c, cmdi_stream strea
     }
     e->have_cond = true;
     e->stash_valid = false;
+    drop_graphs(e);
     return CMDI_OK;
 }
 
@@ -916,24 +947,14 @@ int cmdi_sampler_update(cmdi_handle e, int32_t sampler, int32_t step, float eta,
     return CMDI_OK;
 }
 
-int cmdi_step(cmdi_handle e, int32_t sampler, int32_t step, float eta, float* d_x,
-              float* d_pred_xstart, const float* d_noise, uint64_t seed, int64_t first_sample,
-              cmdi_stream stream) {
-    int rc = check_ready(e, true);
-    if (rc != CMDI_OK) return rc;
-    if (!d_x) return fail(CMDI_E_INVALID, "null tensor");
-    if (step < 0 || step >= e->n_steps) return fail(CMDI_E_INVALID, "step out of range");
-    hipStream_t s = static_cast<hipStream_t>(stream);
+static int step_impl(cmdi_engine* e, int32_t sampler, int32_t step, float eta, float* d_x,
+                     float* d_pred_xstart, const float* d_noise, uint64_t seed, int64_t first_sample,
+                     hipStream_t s, bool tables) {
     const int64_t per = (int64_t)e->C * e->T;
     const size_t n = (size_t)e->B * per;
     const bool impute = e->imputate && step >= e->stop_imp;
     const bool recon = e->recon && step >= e->stop_rec;
-    if (e->mean_type == CMDI_MEAN_EPSILON && (impute || recon))
-        return fail(CMDI_E_INVALID, "This feature supports only X_start pred for now!");
-    if (e->tmap[step] >= e->n_time_rows)
-        return fail(CMDI_E_STATE, "timestep_map exceeds the finalized time-embedding table");
-
-    rc = mdm_forward(e, d_x, nullptr, e->tmap[step], e->out_raw, recon, s);
+    int rc = mdm_forward(e, d_x, nullptr, e->tmap[step], e->out_raw, recon, s, tables);
     if (rc != CMDI_OK) return rc;
     const float* out_c = e->out_raw;
     const float* out_u = e->cfg ? e->out_raw + n : nullptr;
@@ -953,7 +974,121 @@ int cmdi_step(cmdi_handle e, int32_t sampler, int32_t step, float eta, float* d_
     io.x = d_x; io.out_c = out_c; io.out_u = out_u; io.text_scale = e->text_scale;
     io.mask = e->mask; io.inpaint = e->inpaint; io.grad_c = grad_c; io.grad_u = grad_u;
     io.noise = d_noise; io.pred_xstart = d_pred_xstart;
-    HIPCHK(launch_sampler_step(io, k, e->B, per, seed, first_sample, step, s));
+    HIPCHK(launch_sampler_step(io, k, e->B, per, seed, first_sample, step, s,
+                               tables ? e->coef_dev : nullptr, tables ? e->cursor_dev : nullptr));
+    if (tables) HIPCHK(launch_cursor_add(e->cursor_dev, -1, s));
+    return CMDI_OK;
+}
+
+static int check_step(cmdi_engine* e, int32_t step) {
+    if (step < 0 || step >= e->n_steps) return fail(CMDI_E_INVALID, "step out of range");
+    const bool impute = e->imputate && step >= e->stop_imp;
+    const bool recon = e->recon && step >= e->stop_rec;
+    if (e->mean_type == CMDI_MEAN_EPSILON && (impute || recon))
+        return fail(CMDI_E_INVALID, "This feature supports only X_start pred for now!");
+    if (e->tmap[step] >= e->n_time_rows)
+        return fail(CMDI_E_STATE, "timestep_map exceeds the finalized time-embedding table");
+    return CMDI_OK;
+}
+
+int cmdi_step(cmdi_handle e, int32_t sampler, int32_t step, float eta, float* d_x,
+              float* d_pred_xstart, const float* d_noise, uint64_t seed, int64_t first_sample,
+              cmdi_stream stream) {
+    int rc = check_ready(e, true);
+    if (rc != CMDI_OK) return rc;
+    if (!d_x) return fail(CMDI_E_INVALID, "null tensor");
+    rc = check_step(e, step);
+    if (rc != CMDI_OK) return rc;
+    return step_impl(e, sampler, step, eta, d_x, d_pred_xstart, d_noise, seed, first_sample,
+                     static_cast<hipStream_t>(stream), false);
+}
+
+int cmdi_set_graph(cmdi_handle e, int32_t on) {
+    if (!e) return fail(CMDI_E_INVALID, "null handle");
+    e->use_graph = on != 0;
+    drop_graphs(e);
+    return CMDI_OK;
+}
+
+// The chain [first_step .. last_step] as hipGraph replays: the first step of each kind (with / without
+// reconstruction guidance) runs eagerly (one-time function attributes, stream creation), the second is
+// captured, the rest are replayed.  Every variant launches the same kernels on the same device tables,
+// so eager, captured and replayed steps are bitwise identical.
+static int sample_loop_graph_on(cmdi_engine* e, int32_t sampler, int32_t first_step, int32_t last_step,
+                                float eta, float* d_x, uint64_t seed, int64_t first_sample, hipStream_t s);
+
+static int sample_loop_graph(cmdi_engine* e, int32_t sampler, int32_t first_step, int32_t last_step,
+                             float eta, float* d_x, uint64_t seed, int64_t first_sample, hipStream_t s) {
+    if (s != nullptr)
+        return sample_loop_graph_on(e, sampler, first_step, last_step, eta, d_x, seed, first_sample, s);
+    // the caller is on the legacy default stream, which cannot be captured: run the chain on an
+    // engine-owned stream, ordered after / before the caller's stream with events
+    if (!e->own_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&e->own_ev[0], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&e->own_ev[1], hipEventDisableTiming));
+    }
+    HIPCHK(hipEventRecord(e->own_ev[0], nullptr));
+    HIPCHK(hipStreamWaitEvent(e->own_stream, e->own_ev[0], 0));
+    int rc = sample_loop_graph_on(e, sampler, first_step, last_step, eta, d_x, seed, first_sample, e->own_stream);
+    HIPCHK(hipEventRecord(e->own_ev[1], e->own_stream));
+    HIPCHK(hipStreamWaitEvent(nullptr, e->own_ev[1], 0));
+    return rc;
+}
+
+static int sample_loop_graph_on(cmdi_engine* e, int32_t sampler, int32_t first_step, int32_t last_step,
+                                float eta, float* d_x, uint64_t seed, int64_t first_sample, hipStream_t s) {
+    const int n = e->n_steps;
+    if (e->table_cap < n) {
+        int rc = falloc(e, &e->coef_dev, (size_t)n);
+        if (rc != CMDI_OK) return rc;
+        rc = falloc(e, &e->tmap_dev, (size_t)n);
+        if (rc != CMDI_OK) return rc;
+        if (!e->cursor_dev) { rc = falloc(e, &e->cursor_dev, 1); if (rc != CMDI_OK) return rc; }
+        e->table_cap = n;
+    }
+    std::vector<StepCoef> tab((size_t)n);
+    for (int step = last_step; step <= first_step; ++step) {
+        int rc = check_step(e, step);
+        if (rc != CMDI_OK) return rc;
+        const bool impute = e->imputate && step >= e->stop_imp;
+        const bool recon = e->recon && step >= e->stop_rec;
+        rc = build_coef(e, sampler, step, eta, impute, recon, &tab[(size_t)step]);
+        if (rc != CMDI_OK) return rc;
+    }
+    // one-off uploads per chain (pageable host memory: these copies are synchronous with the host)
+    HIPCHK(hipMemcpyAsync(e->coef_dev, tab.data(), (size_t)n * sizeof(StepCoef), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(e->tmap_dev, e->tmap.data(), (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    const int first = first_step;
+    HIPCHK(hipMemcpyAsync(e->cursor_dev, &first, sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));   // the host vectors above go out of scope
+    if (e->graph_stream != s || e->graph_seed != seed || e->graph_first != first_sample || e->graph_x != d_x) {
+        drop_graphs(e);   // captured pointers / scalars changed
+        e->graph_stream = s; e->graph_seed = seed; e->graph_first = first_sample; e->graph_x = d_x;
+    }
+    for (int step = first_step; step >= last_step; --step) {
+        const int kind = (e->recon && step >= e->stop_rec) ? 1 : 0;
+        if (e->graph_exec[kind]) {
+            HIPCHK(hipGraphLaunch(e->graph_exec[kind], s));
+            continue;
+        }
+        if (!e->graph_warm[kind]) {
+            int rc = step_impl(e, sampler, step, eta, d_x, nullptr, nullptr, seed, first_sample, s, true);
+            if (rc != CMDI_OK) return rc;
+            e->graph_warm[kind] = true;
+            continue;
+        }
+        hipGraph_t graph = nullptr;
+        HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        int rc = step_impl(e, sampler, step, eta, d_x, nullptr, nullptr, seed, first_sample, s, true);
+        hipError_t ce = hipStreamEndCapture(s, &graph);
+        if (rc != CMDI_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (ce != hipSuccess) return fail(CMDI_E_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+        hipError_t ie = hipGraphInstantiate(&e->graph_exec[kind], graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ie != hipSuccess) return fail(CMDI_E_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie));
+        HIPCHK(hipGraphLaunch(e->graph_exec[kind], s));
+    }
     return CMDI_OK;
 }
 
@@ -964,6 +1099,10 @@ int cmdi_sample_loop(cmdi_handle e, int32_t sampler, int32_t first_step, int32_t
     if (rc != CMDI_OK) return rc;
     if (first_step < last_step || last_step < 0 || first_step >= e->n_steps)
         return fail(CMDI_E_INVALID, "need n_steps > first_step >= last_step >= 0");
+    if (!d_x) return fail(CMDI_E_INVALID, "null tensor");
+    if (e->use_graph && !d_noise_stream && !e->profile)
+        return sample_loop_graph(e, sampler, first_step, last_step, eta, d_x, seed, first_sample,
+                                 static_cast<hipStream_t>(stream));
     const size_t n = (size_t)e->B * e->C * e->T;
     for (int step = first_step, i = 0; step >= last_step; --step, ++i) {
         const float* nz = d_noise_stream ? d_noise_stream + (size_t)i * n : nullptr;

@@ -160,9 +160,10 @@ hipError_t launch_layernorm_bwd(const float* x, const float* stats, const float*
 __global__ void token0_kernel(float* __restrict__ tok, const float* __restrict__ time_table,
                               const float* __restrict__ text_term, const float* __restrict__ pe,
                               const int64_t* __restrict__ t_dev, int64_t t_scalar, int n_per_pass,
-                              int S, int d, int n_time_rows) {
+                              int S, int d, int n_time_rows, const int64_t* __restrict__ tmap_dev,
+                              const int* __restrict__ cursor) {
     const int b = blockIdx.x;  // sequence index in [0, n_seq); timesteps repeat per CFG pass
-    int64_t t = t_dev ? t_dev[b % n_per_pass] : t_scalar;
+    int64_t t = cursor ? tmap_dev[*cursor] : (t_dev ? t_dev[b % n_per_pass] : t_scalar);
     if (t < 0) t = 0;
     if (t >= n_time_rows) t = n_time_rows - 1;
     for (int n = threadIdx.x; n < d; n += blockDim.x) {
@@ -174,11 +175,12 @@ __global__ void token0_kernel(float* __restrict__ tok, const float* __restrict__
 
 hipError_t launch_token0(float* tok, const float* time_table, const float* text_term,
                          const float* pe, const int64_t* t_dev, int64_t t_scalar, int n_seq,
-                         int n_per_pass, int S, int d, int n_time_rows, hipStream_t stream) {
+                         int n_per_pass, int S, int d, int n_time_rows, hipStream_t stream,
+                         const int64_t* tmap_dev, const int* cursor) {
     // n_seq = B (single pass) or 2B (CFG: conditional rows then unconditional rows); t_dev, when
     // given, holds n_per_pass = B entries shared by both passes.
     hipLaunchKernelGGL(token0_kernel, dim3(n_seq), dim3(256), 0, stream, tok, time_table, text_term,
-                       pe, t_dev, t_scalar, n_per_pass, S, d, n_time_rows);
+                       pe, t_dev, t_scalar, n_per_pass, S, d, n_time_rows, tmap_dev, cursor);
     return hipGetLastError();
 }
 

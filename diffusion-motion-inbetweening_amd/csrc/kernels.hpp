@@ -64,9 +64,11 @@ hipError_t launch_layernorm_bwd(const float* x, const float* stats, const float*
                                 const float* dy, float* dx, _Float16* dx_split /* optional */,
                                 int rows, int d, hipStream_t stream);
 // tok[b*S + 0][:] = time_table[t_b] + text_term[b] + pe[0]
+// tmap_dev / cursor (graph replay): t = tmap_dev[*cursor] for every sequence
 hipError_t launch_token0(float* tok, const float* time_table, const float* text_term,
                          const float* pe, const int64_t* t_dev, int64_t t_scalar, int n_seq,
-                         int n_per_pass, int S, int d, int n_time_rows, hipStream_t stream);
+                         int n_per_pass, int S, int d, int n_time_rows, hipStream_t stream,
+                         const int64_t* tmap_dev = nullptr, const int* cursor = nullptr);
 // text_term[b'] rows: conditional rows get proj[b] (already W·c+b), unconditional rows get bias
 hipError_t launch_fill_rows(float* dst, const float* row, int rows, int d, hipStream_t stream);
 hipError_t launch_add2(float* dst, const float* a, const float* b, int64_t n, hipStream_t stream);
@@ -100,8 +102,12 @@ struct SamplerIO {
     const float* noise;       // injected draw or null (engine RNG)
     float* pred_xstart;       // optional
 };
+// ktab / cursor (both or neither): read the step index from *cursor and the coefficients from
+// ktab[*cursor] instead of the by-value arguments (hipGraph replay of a whole step)
 hipError_t launch_sampler_step(const SamplerIO& io, const StepCoef& k, int batch, int64_t per_sample,
-                               uint64_t seed, int64_t first_sample, int step, hipStream_t stream);
+                               uint64_t seed, int64_t first_sample, int step, hipStream_t stream,
+                               const StepCoef* ktab = nullptr, const int* cursor = nullptr);
+hipError_t launch_cursor_add(int* cursor, int delta, hipStream_t stream);
 // gout_c = s*g, gout_u = (1-s)*g with g = 2*(hat - inpaint)*mask, hat = CFG(out_c, out_u)
 hipError_t launch_recon_gout(const float* out_c, const float* out_u, const float* text_scale,
                              const uint8_t* mask, const float* inpaint, float* gout_c, float* gout_u,

@@ -90,9 +90,15 @@ __device__ __forceinline__ void loadmask4(bool m[4], const uint8_t* p, int n) {
 }
 
 template <bool VEC>
-__global__ __launch_bounds__(256) void sampler_step_kernel(const SamplerIO io, const StepCoef k,
+__global__ __launch_bounds__(256) void sampler_step_kernel(const SamplerIO io, const StepCoef k_arg,
                                                            int64_t per_sample, uint64_t seed,
-                                                           int64_t first_sample, int step) {
+                                                           int64_t first_sample, int step_arg,
+                                                           const StepCoef* __restrict__ ktab,
+                                                           const int* __restrict__ cursor) {
+    // graph replay: the step index and its coefficients come from device memory (same values, same
+    // arithmetic), so one captured launch sequence serves every step of the chain
+    const int step = cursor ? *cursor : step_arg;
+    const StepCoef k = ktab ? ktab[step] : k_arg;
     const int b = blockIdx.y;
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t e0 = 4 * q;
@@ -174,15 +180,22 @@ __global__ __launch_bounds__(256) void sampler_step_kernel(const SamplerIO io, c
 }
 
 hipError_t launch_sampler_step(const SamplerIO& io, const StepCoef& k, int batch, int64_t per_sample,
-                               uint64_t seed, int64_t first_sample, int step, hipStream_t stream) {
+                               uint64_t seed, int64_t first_sample, int step, hipStream_t stream,
+                               const StepCoef* ktab, const int* cursor) {
     const int64_t quads = (per_sample + 3) / 4;
     const dim3 grid((unsigned)((quads + 255) / 256), batch), block(256);
     if (per_sample % 4 == 0)
         hipLaunchKernelGGL(sampler_step_kernel<true>, grid, block, 0, stream, io, k, per_sample, seed,
-                           first_sample, step);
+                           first_sample, step, ktab, cursor);
     else
         hipLaunchKernelGGL(sampler_step_kernel<false>, grid, block, 0, stream, io, k, per_sample,
-                           seed, first_sample, step);
+                           seed, first_sample, step, ktab, cursor);
+    return hipGetLastError();
+}
+
+__global__ void cursor_add_kernel(int* cursor, int delta) { *cursor += delta; }
+hipError_t launch_cursor_add(int* cursor, int delta, hipStream_t stream) {
+    hipLaunchKernelGGL(cursor_add_kernel, dim3(1), dim3(1), 0, stream, cursor, delta);
     return hipGetLastError();
 }
 

@@ -95,6 +95,10 @@ class Engine:
                 "an activation left the f16 range (|x| >= 65504 or non-finite) in the split-f16 GEMM "
                 "path: results are invalid; re-run with precision='f32' (CMDI_PRECISION=f32)")
 
+    def set_graph(self, on: bool):
+        """hipGraph replay of whole denoising steps in sample_loop (bitwise identical results)."""
+        N.check(self.lib.cmdi_set_graph(self._h, int(on)))
+
     def profile_enable(self, on: bool):
         N.check(self.lib.cmdi_profile_enable(self._h, int(on)))
 

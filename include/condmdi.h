@@ -166,6 +166,12 @@ int cmdi_sample_loop(cmdi_handle h, int32_t sampler, int32_t first_step, int32_t
                      float eta, float* d_x, const float* d_noise_stream, uint64_t seed,
                      int64_t first_sample, cmdi_stream stream);
 
+/* hipGraph replay for cmdi_sample_loop (also CMDI_GRAPH=1 in the environment): per-step scalars move to
+ * device tables indexed by a device cursor, one step's launch sequence (all streams) is captured once
+ * per kind (with / without reconstruction guidance) and replayed.  Same kernels, same values: results
+ * are bitwise identical to the eager loop.  Ignored (eager launches) when a noise stream is injected. */
+int cmdi_set_graph(cmdi_handle h, int32_t on);
+
 /* Sampler arithmetic alone, for denoisers that are not the native MDM (any callable model):
  * given the model output (already CFG-combined) apply imputation, the x0/eps conversion and the
  * posterior / DDIM update.  Same semantics as cmdi_step minus the model call; the
