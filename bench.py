@@ -120,10 +120,14 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay each denoising step as a hipGraph")
+    ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch of the config (exploration)")
     ap.add_argument("--precision", default=None, choices=["f32", "f16x3"],
                     help="encoder GEMM arithmetic (include/condmdi.h CMDI_PREC_*); default: the library's")
     args = ap.parse_args()
-    cfg = CONFIGS[args.config]
+    cfg = dict(CONFIGS[args.config])
+    if args.batch > 0:
+        cfg["B"] = args.batch
+        cfg["desc"] += f" [batch overridden to {args.batch}]"
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
