@@ -14,6 +14,7 @@ using H64x128s2 = H3Tile<64, 128, 2, 2, 2, 2>;      // 32x64 per wave
 using H128x128w8s3 = H3Tile<128, 128, 4, 2, 3, 2>;  // 8 waves, 32x64 per wave, 96 KiB
 using H128x128w8s2 = H3Tile<128, 128, 4, 2, 2, 2>;  // 8 waves, 64 KiB, 2 blocks/CU (16 waves)
 using H128x256s2 = H3Tile<128, 256, 2, 4, 2, 2>;    // 8 waves, 64x64 per wave, 96 KiB
+using H64x128w8s2 = H3Tile<64, 128, 2, 4, 2, 2>;    // 8 waves, 32x32 per wave: the tail tile of the mixed grid
 using H64x512ln = H3Tile<64, 512, 2, 4, 2, 2>;      // 8 waves, 32x128 per wave: full rows of d = 512 (LN fused)
 using H256x128w16 = H3Tile<256, 128, 8, 2, 3, 4>;   // 16 waves, 32x64 per wave, 3 stages = 144 KiB
 using H128x256w16 = H3Tile<128, 256, 4, 4, 3, 4>;   // 16 waves, 32x64 per wave
@@ -34,6 +35,38 @@ static hipError_t launch_h3_one(const H3Params& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// 128x128 (8 waves) over a whole number of rounds + 64x128 tiles over the remaining rows
+template <int EPI>
+static hipError_t launch_h3_mixed(const H3Params& p0, hipStream_t stream) {
+    using TB = H128x128w8s2;
+    using TS = H64x128w8s2;
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        slots = 2 * cus;   // two 64-KiB blocks per CU
+    }
+    const int tiles_n = (p0.N + TB::BN - 1) / TB::BN;
+    const int tiles = ((p0.M + TB::BM - 1) / TB::BM) * tiles_n;
+    const int panels = (tiles / slots) * slots / tiles_n;   // big row panels = whole rounds
+    if (panels <= 0 || panels * TB::BM >= p0.M) return launch_h3_one<TB, EPI>(p0, stream);
+    H3Params p = p0;
+    p.m_split = panels * TB::BM;
+    p.n_big = panels * tiles_n;
+    const int n_small = ((p.M - p.m_split + TS::BM - 1) / TS::BM) * ((p.N + TS::BN - 1) / TS::BN);
+    auto kern = gemm_h3_mixed_kernel<TB, TS, EPI>;
+    constexpr size_t lds = TB::LDS_BYTES > TS::LDS_BYTES ? TB::LDS_BYTES : TS::LDS_BYTES;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.n_big + n_small), dim3(TB::NT), lds, stream, p);
+    return hipGetLastError();
+}
+
 template <int EPI>
 static hipError_t launch_h3_tiles(const H3Params& p, int tile, hipStream_t s) {
     switch (tile) {
@@ -48,6 +81,7 @@ static hipError_t launch_h3_tiles(const H3Params& p, int tile, hipStream_t s) {
         case 9: return launch_h3_one<H128x256s2, EPI>(p, s);
         case 10: return launch_h3_one<H256x128w16, EPI>(p, s);
         case 11: return launch_h3_one<H128x256w16, EPI>(p, s);
+        case 20: return launch_h3_mixed<EPI>(p, s);
         default: return hipErrorInvalidValue;
     }
 }

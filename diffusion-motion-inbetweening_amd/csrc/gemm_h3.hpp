@@ -61,19 +61,20 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// One output tile of the row range [m_begin, m_end): block `block_id` of the ceil(rows / BM) x ceil(N / BN)
+// grid laid over that range.
 template <class TC, int EPI>
-__global__ __launch_bounds__(TC::NT, TC::MINW) void gemm_h3_kernel(const H3Params p) {
+__device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, int m_begin, int M, char* lds) {
     constexpr int BM = TC::BM, BN = TC::BN, TM = TC::TM, TN = TC::TN, NW = TC::NW;
     constexpr int STAGE = TC::STAGE, NSTAGE = TC::NSTAGE, PW = TC::PW;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int wm = wave / TC::WN, wn = wave % TC::WN;
 
-    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (M - m_begin + BM - 1) / BM;
+    const int bid = xcd_remap(block_id, tiles_m * tiles_n);
+    const int m0 = m_begin + (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
 
     long long t_start = 0, t_loop = 0, t_loop_end = 0, r_start = 0;
     if (p.dbg & 16) { t_start = __builtin_readcyclecounter(); r_start = __builtin_amdgcn_s_memrealtime(); }
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(TC::NT, TC::MINW) void gemm_h3_kernel(const H3Param
     for (int q = 0; q < BM / 8 / NW; ++q) {
         const int row = (q * NW + wave) * 8 + prow;
         int grow = m0 + row;
-        grow = grow < p.M ? grow : p.M - 1;
+        grow = grow < M ? grow : M - 1;
         a_src[q] = p.A + (size_t)grow * ldk + ((pslot ^ ((row >> 1) & 7)) << 3);
     }
 #pragma unroll
@@ -223,8 +224,8 @@ __global__ __launch_bounds__(TC::NT, TC::MINW) void gemm_h3_kernel(const H3Param
         for (int it = 0; it < NIT; ++it) {
             const int row = it * RPI + rl;
             int m = m0 + wm * 32 + row;
-            const bool mok = m < p.M;
-            m = mok ? m : p.M - 1;
+            const bool mok = m < M;
+            m = mok ? m : M - 1;
             const float4 t = *reinterpret_cast<const float4*>(wl + row * ROWLEN + cl);
             const float4 rr = *reinterpret_cast<const float4*>(p.R + (size_t)m * BN + n);
             x[it][0] = (t.x + bias4.x) + rr.x; x[it][1] = (t.y + bias4.y) + rr.y;
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(TC::NT, TC::MINW) void gemm_h3_kernel(const H3Param
 #pragma unroll
             for (int w = 0; w < TC::WN; ++w) q += red[(TC::WN + w) * BM + row];
             const float rstd = 1.0f / sqrtf(q * inv_n + 1e-5f);
-            if (m >= p.M) continue;
+            if (m >= M) continue;
             if (p.ln_stats && wn == 0 && (lane & 31) == 0) {
                 p.ln_stats[2 * (size_t)m] = mean[it];
                 p.ln_stats[2 * (size_t)m + 1] = rstd;
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(TC::NT, TC::MINW) void gemm_h3_kernel(const H3Param
                 const int row = it * RPI + rl;
                 const int m = m0 + (wm * TM + i) * 32 + row;
                 const float4 t = *reinterpret_cast<const float4*>(wl + row * ROWLEN + cl);
-                if (m >= p.M || !nok) continue;
+                if (m >= M || !nok) continue;
                 float v[4] = {t.x + bias4.x, t.y + bias4.y, t.z + bias4.z, t.w + bias4.w};
                 const size_t off = (size_t)m * p.ldc + n;
                 // (non-temporal stores were measured: faster in isolation, slower in the layer chain —
@@ -361,6 +362,23 @@ __global__ __launch_bounds__(TC::NT, TC::MINW) void gemm_h3_kernel(const H3Param
         o[2] = (o[2] - o[1]);   // loop duration
         o[1] = (long long)(((unsigned long long)xcc << 32) | hwid);
     }
+}
+
+template <class TC, int EPI>
+__global__ __launch_bounds__(TC::NT, TC::MINW) void gemm_h3_kernel(const H3Params p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    gemm_h3_body<TC, EPI>(p, blockIdx.x, 0, p.M, lds);
+}
+
+// Mixed-granularity grid against wave quantization: the first n_big blocks cover rows [0, m_split) with the
+// big tile — a whole number of rounds over the chip's block slots — and the remaining rows get the small
+// tile, so the last, partial round is made of short blocks instead of full-length ones.
+template <class TBig, class TSmall, int EPI>
+__global__ __launch_bounds__(TBig::NT, TBig::MINW) void gemm_h3_mixed_kernel(const H3Params p) {
+    static_assert(TBig::NT == TSmall::NT, "one block size");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    if ((int)blockIdx.x < p.n_big) gemm_h3_body<TBig, EPI>(p, blockIdx.x, 0, p.m_split, lds);
+    else gemm_h3_body<TSmall, EPI>(p, blockIdx.x - p.n_big, p.m_split, p.M, lds);
 }
 
 }  // namespace cmdi

@@ -64,6 +64,7 @@ struct H3Params {
     float* ln_stats;
     int* range_flag;    // set to 1 if a split output leaves the f16 range
     int M, N, K, ldc;
+    int n_big, m_split; // mixed-granularity launch (set by launch_gemm_h3)
     int dbg;            // bench-only ablations: 1 = no in-loop loads, 2 = no epilogue stores, 16 = timestamps
     long long* dbg_buf; // dbg & 16: per block {start, loop start, loop end, end} (s_memtime)
 };

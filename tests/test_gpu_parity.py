@@ -101,8 +101,9 @@ def test_split_f16_roundtrip():
     assert torch.equal(hi_plane.cpu(), x.half())  # hi plane = round-to-nearest f16
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
-@pytest.mark.parametrize("shape", [(333, 512, 512), (197 * 4, 1536, 512), (1000, 512, 1024), (130, 256, 32)])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 20])
+@pytest.mark.parametrize("shape", [(333, 512, 512), (197 * 4, 1536, 512), (1000, 512, 1024), (130, 256, 32),
+                                   (12608, 1536, 64)])
 def test_gemm_h3(tile, shape):
     """Same inputs, same float64 reference and the same 2e-6 bound as the exact-fp32 kernels; the
     split-f16 error must also stay within 1.5x of the fp32-MFMA kernel's own error."""
