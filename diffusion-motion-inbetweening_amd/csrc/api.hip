@@ -91,7 +91,9 @@ struct cmdi_engine {
     _Float16 *tokS = nullptr, *bufHS = nullptr, *attnS = nullptr, *ffnS = nullptr, *qkvS = nullptr;
     _Float16 *dBS = nullptr, *dffnS = nullptr, *dqkvS = nullptr, *dOS = nullptr;  // backward operands (want_grad)
     int* range_flag = nullptr;
-    unsigned* gs_bits = nullptr;   // max|gout| bits -> power-of-two gradient scale (f16x3 backward)
+    unsigned* gs_bits = nullptr;   // max|gout| bits -> power-of-two gradient scale (f16x3 backward); [1 + parts]
+    float* text_term_p = nullptr;  // text_term in the slot order of the independent pipelines (cmdi_sample_loop)
+    int pipelines = 1;             // CMDI_PIPELINES=0: keep the fork/join-per-step schedule in cmdi_sample_loop
     int h3_tile_qkv = 0, h3_tile_proj = 0, h3_tile_ffn1 = 0, h3_tile_ffn2 = 0;
     // f16x3: LayerNorm inside the out_proj / linear2 GEMM epilogue (d_model = 512).  Off by default:
     // the full-row 64x512 tile it needs (197 blocks, 8 waves per CU) loses more in the GEMM than the
@@ -578,6 +580,7 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
     e->n_groups = env_int("CMDI_GROUPS", 0);  // 0 = automatic
     e->io_pipe = env_int("CMDI_IO_PIPE", 0);
     e->use_graph = env_int("CMDI_GRAPH", 0);
+    e->pipelines = env_int("CMDI_PIPELINES", 1);
     {
         int prec = desc->precision;
         if (prec == CMDI_PREC_DEFAULT) {
@@ -616,7 +619,7 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
             ALLOC(w.l1_wT, (size_t)f * d); ALLOC(w.l2_wT, (size_t)d * f);
         }
     }
-    ALLOC(e->text_term, nseq * d); ALLOC(e->text_scale, e->Bmax);
+    ALLOC(e->text_term, nseq * d); ALLOC(e->text_term_p, nseq * d); ALLOC(e->text_scale, e->Bmax);
     ALLOC(e->enc_text, (size_t)e->Bmax * e->clip_dim);
     ALLOC(e->inpaint, (size_t)e->Bmax * C * e->Tmax);
     {
@@ -627,7 +630,7 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
     ALLOC(e->qkv, Mmax * 3 * d); ALLOC(e->attn, Mmax * d); ALLOC(e->ffn, Mmax * f);
     ALLOC(e->out_raw, nseq * C * e->Tmax);
     ALLOC(e->range_flag, 1);
-    ALLOC(e->gs_bits, 1);
+    ALLOC(e->gs_bits, 16);
     HIPCHK(hipMemset(e->range_flag, 0, sizeof(int)));
     if (e->precision == CMDI_PREC_F16X3) {
         for (LayerW& w : e->layers) {
@@ -947,6 +950,182 @@ int cmdi_sampler_update(cmdi_handle e, int32_t sampler, int32_t step, float eta,
     return CMDI_OK;
 }
 
+// ---- independent pipelines -------------------------------------------------------------------------
+// Samples never interact inside a chain, so cmdi_sample_loop can cut the batch into G contiguous parts
+// and run each part's WHOLE chain (input projection, layers, output projection, sampler update, next
+// step ...) on its own stream with no cross-stream dependency until the end: nothing is serialised by
+// the narrow stages before / after the encoder layers, and the parts drift out of phase, so one part's
+// memory-bound stretches (epilogue bursts, LayerNorm) overlap the other's MFMA-bound ones.
+// Sequence slots are laid out per part: [cond rows of the part | uncond rows of the part].
+struct Part {
+    int b0, nb;          // samples [b0, b0 + nb)
+    int slot0, nslot;    // sequence slots [slot0, slot0 + nslot): nslot = nb or 2 nb (CFG)
+    int idx;
+    hipStream_t s;
+};
+
+static int n_parts(const cmdi_engine* e) {
+    const int n_seq = e->cfg ? 2 * e->B : e->B;
+    int G = e->n_groups > 0 ? e->n_groups : ((long)n_seq * (e->T + 1) >= 8192 ? 2 : 1);
+    if (G > e->B) G = e->B;
+    if (G > 15) G = 15;
+    return G < 1 ? 1 : G;
+}
+
+static Part make_part(const cmdi_engine* e, int g, int G) {
+    Part p{};
+    p.b0 = (int)((long)e->B * g / G);
+    p.nb = (int)((long)e->B * (g + 1) / G) - p.b0;
+    p.slot0 = e->cfg ? 2 * p.b0 : p.b0;
+    p.nslot = e->cfg ? 2 * p.nb : p.nb;
+    p.idx = g;
+    return p;
+}
+
+static int part_forward(cmdi_engine* e, const Part& pt, const float* x_part, int64_t t_scalar, bool keep) {
+    const int T = e->T, S = T + 1, d = e->d, C = e->C;
+    hipStream_t s = pt.s;
+    float* tok = e->tokA + (size_t)pt.slot0 * S * d;
+    HIPCHK(launch_token0(tok, e->time_table, e->have_text ? e->text_term_p + (size_t)pt.slot0 * d : nullptr,
+                         e->pe, nullptr, t_scalar, pt.nslot, pt.nb, S, d, e->n_time_rows, s));
+    {
+        GemmParams p = gp(x_part, e->w_in_pad, e->b_in, tok, pt.nb * T, d, e->Cpad, 0, e->Cpad, d);
+        p.pe = e->pe; p.T = T; p.S = S; p.Cf = C; p.Bdup = e->cfg ? pt.nb : 0;
+        HIPCHK(launch_gemm(GK_INPROJ, p, e->io_pipe, s));
+    }
+    int rc = run_layers(e, pt.slot0, pt.nslot, keep, false, s);
+    if (rc != CMDI_OK) return rc;
+    {
+        GemmParams p = gp(e->w_out, tok, e->b_out, e->out_raw + (size_t)pt.slot0 * C * T, C, pt.nslot * T, d, d, d, 0);
+        p.T = T; p.S = S; p.Cf = C;
+        HIPCHK(launch_gemm(GK_OUTPROJ, p, e->io_pipe, s));
+    }
+    return CMDI_OK;
+}
+
+static int part_backward(cmdi_engine* e, const Part& pt) {
+    const int T = e->T, S = T + 1, d = e->d, C = e->C;
+    hipStream_t s = pt.s;
+    const size_t per = (size_t)C * T;
+    const float* gout = e->gout + (size_t)pt.slot0 * per;
+    float* gx = e->gx + (size_t)pt.slot0 * per;
+    float* dA = e->dA + (size_t)pt.slot0 * S * d;
+    unsigned* gs = e->gs_bits + 1 + pt.idx;
+    const bool h3 = e->precision == CMDI_PREC_F16X3;
+    HIPCHK(hipMemsetAsync(dA, 0, (size_t)pt.nslot * S * d * sizeof(float), s));
+    if (h3) {
+        HIPCHK(hipMemsetAsync(gs, 0, sizeof(unsigned), s));
+        HIPCHK(launch_absmax_bits(gout, (int64_t)pt.nslot * per, gs, s));
+    }
+    {
+        GemmParams p = gp(gout, e->w_outT_pad, nullptr, dA, pt.nslot * T, d, e->Cpad, 0, e->Cpad, d);
+        p.T = T; p.S = S; p.Cf = C;
+        p.gs_bits = h3 ? gs : nullptr;
+        HIPCHK(launch_gemm(GK_OUTPROJ_BWD, p, 0, s));
+    }
+    int rc = run_layers_bwd(e, pt.slot0, pt.nslot, s);
+    if (rc != CMDI_OK) return rc;
+    {
+        GemmParams p = gp(e->w_inT, dA, nullptr, gx, C, pt.nslot * T, d, d, d, 0);
+        p.T = T; p.S = S; p.Cf = C;
+        p.gs_bits = h3 ? gs : nullptr;
+        HIPCHK(launch_gemm(GK_OUTPROJ, p, 0, s));
+    }
+    return CMDI_OK;
+}
+
+static int part_step(cmdi_engine* e, const Part& pt, int32_t sampler, int32_t step, float eta, float* d_x,
+                     const float* d_noise, uint64_t seed, int64_t first_sample) {
+    const int64_t per = (int64_t)e->C * e->T;
+    const bool impute = e->imputate && step >= e->stop_imp;
+    const bool recon = e->recon && step >= e->stop_rec;
+    float* x = d_x + (size_t)pt.b0 * per;
+    int rc = part_forward(e, pt, x, e->tmap[step], recon);
+    if (rc != CMDI_OK) return rc;
+    const float* out_c = e->out_raw + (size_t)pt.slot0 * per;
+    const float* out_u = e->cfg ? out_c + (size_t)pt.nb * per : nullptr;
+    const float *grad_c = nullptr, *grad_u = nullptr;
+    if (recon) {
+        float* gc = e->gout + (size_t)pt.slot0 * per;
+        HIPCHK(launch_recon_gout(out_c, out_u, e->text_scale + pt.b0, e->mask + (size_t)pt.b0 * per,
+                                 e->inpaint + (size_t)pt.b0 * per, gc, gc + (size_t)pt.nb * per, pt.nb, per, pt.s));
+        rc = part_backward(e, pt);
+        if (rc != CMDI_OK) return rc;
+        grad_c = e->gx + (size_t)pt.slot0 * per;
+        grad_u = e->cfg ? grad_c + (size_t)pt.nb * per : nullptr;
+    }
+    StepCoef k;
+    rc = build_coef(e, sampler, step, eta, impute, recon, &k);
+    if (rc != CMDI_OK) return rc;
+    SamplerIO io{};
+    io.x = x; io.out_c = out_c; io.out_u = out_u; io.text_scale = e->text_scale + pt.b0;
+    io.mask = e->mask + (size_t)pt.b0 * per; io.inpaint = e->inpaint + (size_t)pt.b0 * per;
+    io.grad_c = grad_c; io.grad_u = grad_u;
+    io.noise = d_noise ? d_noise + (size_t)pt.b0 * per : nullptr; io.pred_xstart = nullptr;
+    HIPCHK(launch_sampler_step(io, k, pt.nb, per, seed, first_sample + pt.b0, step, pt.s));
+    return CMDI_OK;
+}
+
+static int check_step(cmdi_engine* e, int32_t step);
+
+static int sample_loop_pipelines(cmdi_engine* e, int32_t sampler, int32_t first_step, int32_t last_step,
+                                 float eta, float* d_x, const float* d_noise_stream, uint64_t seed,
+                                 int64_t first_sample, hipStream_t s) {
+    const int G = n_parts(e);
+    const int d = e->d;
+    for (int step = last_step; step <= first_step; ++step) {
+        int rc = check_step(e, step);
+        if (rc != CMDI_OK) return rc;
+    }
+    while ((int)e->gstreams.size() < G) {
+        hipStream_t st;
+        HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        e->gstreams.push_back(st);
+    }
+    while ((int)e->gevents.size() < G + 1) {
+        hipEvent_t ev;
+        HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        e->gevents.push_back(ev);
+    }
+    std::vector<Part> parts;
+    for (int g = 0; g < G; ++g) {
+        Part pt = make_part(e, g, G);
+        pt.s = G == 1 ? s : e->gstreams[g];
+        parts.push_back(pt);
+    }
+    // text terms in slot order (cond rows of the part, then its uncond rows)
+    if (e->have_text) {
+        for (const Part& pt : parts) {
+            HIPCHK(hipMemcpyAsync(e->text_term_p + (size_t)pt.slot0 * d, e->text_term + (size_t)pt.b0 * d,
+                                  (size_t)pt.nb * d * sizeof(float), hipMemcpyDeviceToDevice, s));
+            if (e->cfg)
+                HIPCHK(hipMemcpyAsync(e->text_term_p + (size_t)(pt.slot0 + pt.nb) * d,
+                                      e->text_term + (size_t)(e->B + pt.b0) * d,
+                                      (size_t)pt.nb * d * sizeof(float), hipMemcpyDeviceToDevice, s));
+        }
+    }
+    if (G > 1) {
+        HIPCHK(hipEventRecord(e->gevents[0], s));
+        for (const Part& pt : parts) HIPCHK(hipStreamWaitEvent(pt.s, e->gevents[0], 0));
+    }
+    const size_t n = (size_t)e->B * e->C * e->T;
+    for (int step = first_step, i = 0; step >= last_step; --step, ++i) {
+        const float* nz = d_noise_stream ? d_noise_stream + (size_t)i * n : nullptr;
+        for (const Part& pt : parts) {
+            int rc = part_step(e, pt, sampler, step, eta, d_x, nz, seed, first_sample);
+            if (rc != CMDI_OK) return rc;
+        }
+    }
+    if (G > 1) {
+        for (const Part& pt : parts) {
+            HIPCHK(hipEventRecord(e->gevents[1 + pt.idx], pt.s));
+            HIPCHK(hipStreamWaitEvent(s, e->gevents[1 + pt.idx], 0));
+        }
+    }
+    e->stash_valid = false;   // the stash holds slot-ordered rows of the last step: not a cmdi_mdm_forward stash
+    return CMDI_OK;
+}
+
 static int step_impl(cmdi_engine* e, int32_t sampler, int32_t step, float eta, float* d_x,
                      float* d_pred_xstart, const float* d_noise, uint64_t seed, int64_t first_sample,
                      hipStream_t s, bool tables) {
@@ -1103,6 +1282,9 @@ int cmdi_sample_loop(cmdi_handle e, int32_t sampler, int32_t first_step, int32_t
     if (e->use_graph && !d_noise_stream && !e->profile)
         return sample_loop_graph(e, sampler, first_step, last_step, eta, d_x, seed, first_sample,
                                  static_cast<hipStream_t>(stream));
+    if (e->pipelines && !e->profile)
+        return sample_loop_pipelines(e, sampler, first_step, last_step, eta, d_x, d_noise_stream, seed,
+                                     first_sample, static_cast<hipStream_t>(stream));
     const size_t n = (size_t)e->B * e->C * e->T;
     for (int step = first_step, i = 0; step >= last_step; --step, ++i) {
         const float* nz = d_noise_stream ? d_noise_stream + (size_t)i * n : nullptr;
