@@ -14,8 +14,8 @@ B=32 slice; no collective inside the loop, one RCCL all-gather of the samples af
 Prints ONE JSON line on rank 0 (see the task contract) with two extra objects:
   roofline      the dominant kernel = the self-attention in_proj GEMM (fp32 MFMA), timed with HIP
                 events on its own stream inside a second, instrumented pass over the same K steps
-  cpu_baseline  the numpy oracle (a port of the reference's CPU path) on the host cores, a bounded
-                sample of the same workload (1 warm-up + a few full CFG steps at B=32)
+  cpu_baseline  the reference's CPU path restated on torch CPU kernels (oracle/torch_cpu_port.py) on the
+                host cores, a bounded sample of the same workload (1 warm-up + 3 full CFG steps at B=32)
 """
 from __future__ import annotations
 
@@ -68,46 +68,49 @@ def build_model(cfg_on, dev, seed=0):
 
 
 def cpu_baseline(sd, B, n_steps=3):
-    """numpy port of the reference CPU path: full CFG denoising steps at the bench shape.  The BLAS
-    thread count is calibrated first (one conditional pass per candidate; on many-core hosts the
-    oracle's small batched matmuls run faster on fewer threads) and reported as `cores`."""
-    from threadpoolctl import threadpool_limits
-
+    """The reference's CPU path restated on torch CPU kernels (oracle/torch_cpu_port.py: the reference's
+    denoiser IS torch's nn.TransformerEncoder, two sequential CFG passes, then the posterior update) at
+    the bench shape.  The intra-op thread count is calibrated first (one conditional pass per candidate)
+    and reported as `cores`."""
     from oracle import diffusion_oracle as do
-    from oracle.mdm_oracle import MDMOracle
+    from oracle.torch_cpu_port import TorchCpuMDM
     rng = np.random.default_rng(1)
-    m = MDMOracle(sd)
+    m = TorchCpuMDM(sd)
     sch = do.Schedule(do.named_betas("cosine", 1000), do.space_timesteps(1000, [1000]))
     x = rng.standard_normal((B, N_FEATS, 1, T_FRAMES)).astype(np.float32)
-    enc = rng.standard_normal((B, 512)).astype(np.float32)
-    scale = np.full((B,), 2.5, dtype=np.float32)
+    enc = torch.from_numpy(rng.standard_normal((B, 512)).astype(np.float32))
+    scale = torch.full((B,), 2.5)
     nz = rng.standard_normal((n_steps + 1,) + x.shape).astype(np.float32)
-    t999 = np.full((B,), 999, dtype=np.int64)
+    t999 = torch.full((B,), 999, dtype=torch.long)
 
     host = os.cpu_count() or 1
+    prev = torch.get_num_threads()
     best, best_dt = host, None
-    for n in sorted({host, min(host, 64), min(host, 16)}, reverse=True):
-        with threadpool_limits(limits=n):
-            t0 = time.perf_counter()
-            m.forward(x, t999, enc)
-            dt = time.perf_counter() - t0
+    for n in sorted({host, min(host, 64), min(host, 32), min(host, 16)}, reverse=True):
+        torch.set_num_threads(n)
+        m.forward(torch.from_numpy(x), t999, enc)  # warm this thread count
+        t0 = time.perf_counter()
+        m.forward(torch.from_numpy(x), t999, enc)
+        dt = time.perf_counter() - t0
         if best_dt is None or dt < best_dt:
             best, best_dt = n, dt
+    torch.set_num_threads(best)
 
-    def one(i, k):
-        t = np.full((B,), i, dtype=np.int64)
-        hat, _, _ = m.forward_cfg(x, t, enc, scale)
-        return do.step_update(sch, i, x, hat, nz[k])[0]
+    def one(xc, i, k):
+        t = torch.full((B,), i, dtype=torch.long)
+        hat, _, _ = m.forward_cfg(torch.from_numpy(xc), t, enc, scale)
+        return do.step_update(sch, i, xc, hat.numpy(), nz[k])[0]
 
-    with threadpool_limits(limits=best):
-        one(999, 0)  # warm-up
-        t0 = time.perf_counter()
-        for k in range(n_steps):
-            one(998 - k, k + 1)
-        dt = time.perf_counter() - t0
+    xc = one(x, 999, 0)  # warm-up
+    t0 = time.perf_counter()
+    for k in range(n_steps):
+        xc = one(xc, 998 - k, k + 1)
+    dt = time.perf_counter() - t0
+    torch.set_num_threads(prev)
     return {"value": n_steps / dt, "unit": "denoising steps/s", "cores": best, "kind": "port",
             "sample": f"{n_steps} full CFG DDPM steps at B={B}x{T_FRAMES}x{N_FEATS} after 1 warm-up "
-                      f"(oracle/ numpy fp32; {best} BLAS threads picked from a 3-point calibration "
+                      f"(oracle/torch_cpu_port.py: torch {torch.__version__} CPU nn.TransformerEncoder, the "
+                      f"reference's own denoiser arithmetic; {best} intra-op threads picked from a calibration "
                       f"on a host with {host} logical CPUs)"}
 
 

@@ -148,3 +148,17 @@ def test_engine_randn_is_standard_normal():
     # keyed by global sample index: a shard reproduces its slice of the full batch
     part = do.engine_randn(2, 263 * 196, seed=1234, first_sample=2)
     assert np.array_equal(part, z[2:])
+
+
+def test_torch_cpu_port_matches_golden(cases):
+    """bench.py's cpu_baseline model (torch nn.TransformerEncoder on CPU) reproduces the reference."""
+    import torch
+    from oracle.torch_cpu_port import TorchCpuMDM
+    case = cases.CASES["fwd_text"]
+    inp = cases.make_inputs(case)
+    m = TorchCpuMDM(weights.make_state_dict(case["weight_seed"], text=True))
+    g = load_golden("fwd_text")
+    x, t = torch.from_numpy(inp["x"]), torch.from_numpy(inp["t"]).long()
+    cfg, oc, ou = m.forward_cfg(x, t, torch.from_numpy(inp["enc_text"]), torch.from_numpy(inp["text_scale"]))
+    for mine, key in ((oc, "out_cond"), (ou, "out_uncond"), (cfg, "out_cfg")):
+        assert max_abs(mine.numpy(), g[key]) <= 2e-5 and rel_l2(mine.numpy(), g[key]) <= 5e-6, key
