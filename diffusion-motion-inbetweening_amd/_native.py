@@ -70,6 +70,7 @@ SIGNATURES = {
     "cmdi_sampler_update": (C.c_int, [_VP, _I32, _I32, _F, _VP, _VP, _VP, _VP, _VP, _U64, _I64, _VP]),
     "cmdi_q_sample": (C.c_int, [_VP, _I32, _VP, _VP, _VP, _I64, _VP]),
     "cmdi_randn": (C.c_int, [_VP, _VP, _I32, _I64, _U64, _I64, _I32, _VP]),
+    "cmdi_recover_xyz": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _VP]),
     "cmdi_gemm_nt": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _VP]),
     "cmdi_attention_fwd": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _VP]),
     "cmdi_gemm_h3_ln": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _VP]),

@@ -29,6 +29,7 @@ UNITS = {
     "elementwise.hip": [],
     # reference evaluation order, every op rounded separately (see the header of sampler.hip)
     "sampler.hip": ["-ffp-contract=off"],
+    "postprocess.hip": ["-ffp-contract=off"],
 }
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
           "-fno-gpu-rdc"]

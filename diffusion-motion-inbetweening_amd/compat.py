@@ -28,6 +28,8 @@ _ALIASES = {
     "utils.dist_util": "utils.dist_util",
     "utils.fixseed": "utils.fixseed",
 }
+# (the device-side recover_from_ric / sample_to_xyz of data_loaders.humanml.scripts.motion_process is NOT
+# aliased: the reference's module of that name also holds data-preparation code; import it explicitly)
 
 
 def install_reference_aliases(overwrite: bool = False):

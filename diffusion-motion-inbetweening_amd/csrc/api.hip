@@ -1311,6 +1311,18 @@ int cmdi_randn(cmdi_handle, float* d_out, int32_t batch, int64_t per_sample, uin
     return CMDI_OK;
 }
 
+int cmdi_recover_xyz(const float* d_sample, const float* d_mean, const float* d_std, float* d_xyz,
+                     int32_t batch, int32_t n_feats, int32_t n_frames, int32_t n_joints, int32_t abs_3d,
+                     cmdi_stream stream) {
+    if (!d_sample || !d_xyz) return fail(CMDI_E_INVALID, "null tensor");
+    hipError_t err = launch_recover_xyz(d_sample, d_mean, d_std, d_xyz, batch, n_feats, n_frames, n_joints,
+                                        abs_3d, static_cast<hipStream_t>(stream));
+    if (err != hipSuccess)
+        return fail(err == hipErrorInvalidValue ? CMDI_E_INVALID : CMDI_E_HIP,
+                    std::string("cmdi_recover_xyz: ") + hipGetErrorString(err));
+    return CMDI_OK;
+}
+
 int cmdi_gemm_nt(const float* d_a, const float* d_w, const float* d_bias, const float* d_resid,
                  float* d_c, int32_t m, int32_t n, int32_t k, int32_t epi, int32_t tile,
                  cmdi_stream stream) {

@@ -82,6 +82,11 @@ hipError_t launch_pad_copy(float* dst, const float* src, int rows, int cols, int
 hipError_t launch_transpose_pad(float* dst, const float* src, int rows, int cols, int ldd,
                                 hipStream_t stream);
 
+// ---- postprocess.hip ------------------------------------------------------------------------------
+// x [B, n_feats, 1, T] (z-scored if mean/std given) -> joint positions out [B, n_joints, 3, T]
+hipError_t launch_recover_xyz(const float* x, const float* mean, const float* std, float* out, int batch,
+                              int n_feats, int n_frames, int n_joints, int abs_3d, hipStream_t stream);
+
 // ---- sampler.hip ----------------------------------------------------------------------------
 struct StepCoef {
     float c1, c2;          // posterior_mean_coef1/2[i]

@@ -190,6 +190,17 @@ int cmdi_q_sample(cmdi_handle h, int32_t step, const float* d_x0, const float* d
 int cmdi_randn(cmdi_handle h, float* d_out, int32_t batch, int64_t per_sample, uint64_t seed,
                int64_t first_sample, int32_t step, cmdi_stream stream);
 
+/* ---- after the loop -------------------------------------------------------------------------
+ * The step every caller runs right after p_sample_loop (sample/conditional_synthesis.py:229-235,
+ * sample/edit.py, sample/synthesize.py): t2m_dataset.inv_transform (data * std + mean,
+ * data_loaders/humanml/data/dataset.py:378-382) followed by recover_from_ric
+ * (data_loaders/humanml/scripts/motion_process.py:402-441,474-491) and the final permute, on the device:
+ * d_sample [B, n_feats, 1, T] -> d_xyz [B, n_joints, 3, T].  d_mean / d_std [n_feats] device pointers, or
+ * both NULL if the sample is already un-normalised.  abs_3d as in the reference (absolute root yaw / XZ). */
+int cmdi_recover_xyz(const float* d_sample, const float* d_mean, const float* d_std, float* d_xyz,
+                     int32_t batch, int32_t n_feats, int32_t n_frames, int32_t n_joints, int32_t abs_3d,
+                     cmdi_stream stream);
+
 /* ---- introspection for tests / bench --------------------------------------------------------- */
 /* Raw NT GEMM used by every projection: C[M,N] = epi(A[M,K] · W[N,K]^T + bias[N]); fp32 MFMA.
  * epi: 0 = bias, 1 = bias + GELU(erf), 3 = bias + residual d_resid[M,N].  tile selects the block

@@ -89,3 +89,16 @@ def fingerprint(inputs: dict) -> np.ndarray:
     """CRC32 of every input array, in key order (detects a drifted input generator)."""
     return np.asarray([zlib.crc32(np.ascontiguousarray(inputs[k]).tobytes()) for k in sorted(inputs)],
                       dtype=np.int64)
+
+
+# ---- post-sampling step (SURVEY.md §8f rank 2): inv_transform + recover_from_ric ---------------------------
+POST_CASE = dict(B=3, T=196, n_joints=22, seed=201)
+
+
+def make_post_inputs(case: dict = POST_CASE) -> dict:
+    """A z-scored sample [B, 263, 1, T] plus per-feature mean / std (stand-ins for Mean/Std_abs_3d.npy)."""
+    rng = np.random.default_rng(case["seed"])
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    return {"sample": f32(rng.standard_normal((case["B"], N_FEATS, 1, case["T"]))),
+            "mean": f32(0.3 * rng.standard_normal(N_FEATS)),
+            "std": f32(0.05 + rng.random(N_FEATS))}

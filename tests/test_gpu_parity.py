@@ -391,3 +391,24 @@ def test_graph_replay_is_bitwise_identical(precision, sampler):
     eng.set_graph(False)
     assert torch.isfinite(eager).all()
     assert torch.equal(eager, replay) and torch.equal(eager, again)
+
+
+# ---- post-sampling step -----------------------------------------------------------
+@pytest.mark.parametrize("abs_3d", [False, True])
+def test_recover_xyz_vs_reference(cases, abs_3d):
+    """inv_transform + recover_from_ric on the device vs the real reference's output and the numpy oracle."""
+    from oracle.post_oracle import recover_xyz
+    mp = sub("data_loaders.humanml.scripts.motion_process")
+    inp = cases.make_post_inputs()
+    g = load_golden("post_ric")
+    assert np.array_equal(g["fingerprint"], cases.fingerprint(inp))
+    ref = g[f"xyz_abs{int(abs_3d)}"]
+    out = mp.sample_to_xyz(tt(inp["sample"]), inp["mean"], inp["std"], 22, abs_3d).cpu().numpy()
+    tol = 2e-5 * max(1.0, float(np.abs(ref).max()))
+    assert out.shape == ref.shape and max_abs(out, ref) <= tol, max_abs(out, ref)
+    assert max_abs(out, recover_xyz(inp["sample"], inp["mean"], inp["std"], 22, abs_3d)) <= tol
+    # the reference-signature wrapper: un-normalised [B, 1, T, 263] in, [B, 1, T, 22, 3] out
+    data = tt(inp["sample"]).permute(0, 2, 3, 1) * tt(inp["std"]) + tt(inp["mean"])
+    xyz = mp.recover_from_ric(data, 22, abs_3d)
+    assert xyz.shape == (3, 1, 196, 22, 3)
+    assert max_abs(xyz[:, 0].permute(0, 2, 3, 1).cpu().numpy(), ref) <= tol

@@ -162,3 +162,16 @@ def test_torch_cpu_port_matches_golden(cases):
     cfg, oc, ou = m.forward_cfg(x, t, torch.from_numpy(inp["enc_text"]), torch.from_numpy(inp["text_scale"]))
     for mine, key in ((oc, "out_cond"), (ou, "out_uncond"), (cfg, "out_cfg")):
         assert max_abs(mine.numpy(), g[key]) <= 2e-5 and rel_l2(mine.numpy(), g[key]) <= 5e-6, key
+
+
+@pytest.mark.parametrize("abs_3d", [False, True])
+def test_post_sampling_oracle_vs_reference(cases, abs_3d):
+    """inv_transform + recover_from_ric vs the real reference's output."""
+    from oracle.post_oracle import recover_xyz
+    inp = cases.make_post_inputs()
+    g = load_golden("post_ric")
+    assert np.array_equal(g["fingerprint"], cases.fingerprint(inp))
+    out = recover_xyz(inp["sample"], inp["mean"], inp["std"], cases.POST_CASE["n_joints"], abs_3d)
+    ref = g[f"xyz_abs{int(abs_3d)}"]
+    assert out.shape == ref.shape
+    assert max_abs(out, ref) <= 2e-5 * max(1.0, float(np.abs(ref).max())), max_abs(out, ref)
