@@ -1406,6 +1406,26 @@ int cmdi_gemm_h3(const void* d_a_split, const void* d_w_split, const float* d_bi
     return CMDI_OK;
 }
 
+int cmdi_conv_rows_h3(const void* d_a_split, int32_t a_ld, const void* d_w_split, const float* d_bias,
+                      const float* d_resid, float* d_c, void* d_c_split, int32_t m, int32_t n, int32_t cin,
+                      int32_t taps, int32_t pad, int32_t a_row_mul, int32_t c_row_mul, int32_t c_row_add,
+                      int32_t tp, int32_t t_lo, int32_t t_hi, int32_t tile, cmdi_stream stream) {
+    if (!d_a_split || !d_w_split || (!d_c && !d_c_split)) return fail(CMDI_E_INVALID, "null tensor");
+    if (cin % 32 != 0 || n % 32 != 0 || taps < 1 || a_ld < 2 * cin)
+        return fail(CMDI_E_INVALID, "cin and n must be multiples of 32, a_ld >= 2 * cin");
+    H3Params p{};
+    p.A = static_cast<const _Float16*>(d_a_split) - (ptrdiff_t)pad * a_ld;
+    p.W = static_cast<const _Float16*>(d_w_split);
+    p.bias = d_bias; p.C = d_c; p.Cs = static_cast<_Float16*>(d_c_split); p.R = d_resid;
+    p.M = m; p.N = n; p.K = taps * cin; p.ldc = n;
+    p.a_ld = a_ld; p.a_row_mul = a_row_mul; p.taps = taps; p.cpt = cin / 32;
+    p.c_row_mul = c_row_mul; p.c_row_add = c_row_add; p.tp = tp; p.t_lo = t_lo; p.t_hi = t_hi;
+    const int kind = d_c_split ? H3_PLAIN_SPLIT : (d_resid ? H3_RESID : H3_PLAIN);
+    hipError_t err = launch_gemm_h3(kind, p, tile, static_cast<hipStream_t>(stream));
+    if (err != hipSuccess) return fail(CMDI_E_HIP, std::string("launch_gemm_h3: ") + hipGetErrorString(err));
+    return CMDI_OK;
+}
+
 int cmdi_gemm_h3_ln(const void* d_a_split, const void* d_w_split, const float* d_bias,
                     const float* d_resid, const float* d_gamma, const float* d_beta, float* d_y,
                     void* d_y_split, int32_t m, int32_t n, int32_t k, cmdi_stream stream) {

@@ -92,6 +92,8 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
     // bank row.  Slots 0-3 of a row are the hi plane, 4-7 the lo plane.
     const int prow = lane >> 3, pslot = lane & 7;
     const size_t ldk = 2 * (size_t)p.K;
+    const size_t lda = p.a_ld ? (size_t)p.a_ld : ldk;
+    const int a_rmul = p.a_row_mul ? p.a_row_mul : 1;
     const _Float16* a_src[BM / 8 / NW];
     const _Float16* w_src[BN / 8 / NW];
 #pragma unroll
@@ -99,7 +101,7 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
         const int row = (q * NW + wave) * 8 + prow;
         int grow = m0 + row;
         grow = grow < M ? grow : M - 1;
-        a_src[q] = p.A + (size_t)grow * ldk + ((pslot ^ ((row >> 1) & 7)) << 3);
+        a_src[q] = p.A + (size_t)grow * a_rmul * lda + ((pslot ^ ((row >> 1) & 7)) << 3);
     }
 #pragma unroll
     for (int q = 0; q < BN / 8 / NW; ++q) {
@@ -110,10 +112,12 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
     }
     auto issue = [&](int kt, int buf) {
         char* stage = lds + buf * STAGE;
+        // plain GEMM: chunk kt of the row; convolution: tap kt / cpt = one row further, chunk kt % cpt
+        const size_t a_off = p.cpt ? (size_t)(kt / p.cpt) * lda + (size_t)(kt % p.cpt) * 64 : (size_t)kt * 64;
 #pragma unroll
         for (int q = 0; q < BM / 8 / NW; ++q)
             __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(a_src[q] + kt * 64),
+                (const __attribute__((address_space(1))) void*)(a_src[q] + a_off),
                 (__attribute__((address_space(3))) void*)(stage + (q * NW + wave) * 1024), 16, 0, 0);
 #pragma unroll
         for (int q = 0; q < BN / 8 / NW; ++q)
@@ -308,9 +312,14 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
 #pragma unroll
             for (int it = 0; it < 32 / RPI; ++it) {
                 const int row = it * RPI + rl;
-                const int m = m0 + (wm * TM + i) * 32 + row;
+                int m = m0 + (wm * TM + i) * 32 + row;
                 const float4 t = *reinterpret_cast<const float4*>(wl + row * ROWLEN + cl);
                 if (m >= M || !nok) continue;
+                if (p.c_row_mul) m = m * p.c_row_mul + p.c_row_add;        // convolution: output row
+                if (p.tp) {                                                // ... and only frames, not halo
+                    const int pos = m % p.tp;
+                    if (pos < p.t_lo || pos >= p.t_hi) continue;
+                }
                 float v[4] = {t.x + bias4.x, t.y + bias4.y, t.z + bias4.z, t.w + bias4.w};
                 const size_t off = (size_t)m * p.ldc + n;
                 // (non-temporal stores were measured: faster in isolation, slower in the layer chain —

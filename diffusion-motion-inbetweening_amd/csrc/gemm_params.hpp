@@ -65,6 +65,13 @@ struct H3Params {
     int* range_flag;    // set to 1 if a split output leaves the f16 range
     int M, N, K, ldc;
     int n_big, m_split; // mixed-granularity launch (set by launch_gemm_h3)
+    // ---- 1-D convolution as a GEMM over tap-shifted rows (UNET denoiser, unet.hip); all 0 = plain GEMM ----
+    // A row of output row m is row (a_row_mul * m) of a [rows, a_ld halves] split matrix whose pointer the
+    // caller has already moved back by the padding; K = taps * cpt * 32 and K step kt reads tap kt / cpt
+    // (one row further per tap), chunk kt % cpt.  The result goes to row m * c_row_mul + c_row_add, and only
+    // if that row's position inside its tp-row sequence frame lies in [t_lo, t_hi) (halo rows stay zero).
+    int a_ld, a_row_mul, taps, cpt;
+    int c_row_mul, c_row_add, tp, t_lo, t_hi;
     int dbg;            // bench-only ablations: 1 = no in-loop loads, 2 = no epilogue stores, 16 = timestamps
     long long* dbg_buf; // dbg & 16: per block {start, loop start, loop end, end} (s_memtime)
 };

@@ -228,6 +228,15 @@ int cmdi_gemm_h3(const void* d_a_split, const void* d_w_split, const float* d_bi
 /* Self-attention core alone (test / bench hook): d_qkv [n_seq*S, 3*H*128] -> d_out [n_seq*S, H*128]. */
 int cmdi_attention_fwd(const float* d_qkv, float* d_out, int32_t n_seq, int32_t seq_len,
                        int32_t n_heads, cmdi_stream stream);
+/* 1-D convolution over token rows as a split-f16 GEMM (building block of the UNET denoiser, test hook):
+ * activations are rows [.., a_ld halves] in split format, sequences framed by zero halo rows (tp rows per
+ * sequence, valid positions [t_lo, t_hi)); output row m * c_row_mul + c_row_add =
+ * bias + sum_tap W[:, tap*cin : (tap+1)*cin] · A[a_row_mul * m - pad + tap]; weights [n, 2 * taps * cin]
+ * split rows (tap-major K).  Stride-2 convolution: a_row_mul = 2; transposed convolution: c_row_mul = 2. */
+int cmdi_conv_rows_h3(const void* d_a_split, int32_t a_ld, const void* d_w_split, const float* d_bias,
+                      const float* d_resid, float* d_c, void* d_c_split, int32_t m, int32_t n, int32_t cin,
+                      int32_t taps, int32_t pad, int32_t a_row_mul, int32_t c_row_mul, int32_t c_row_add,
+                      int32_t tp, int32_t t_lo, int32_t t_hi, int32_t tile, cmdi_stream stream);
 /* Y = LayerNorm((A · W^T + bias) + resid; gamma, beta, eps 1e-5) with the normalisation fused into the
  * GEMM epilogue (N must be 512 = d_model); d_y fp32 [M,N], d_y_split optional split rows [M,2N]. */
 int cmdi_gemm_h3_ln(const void* d_a_split, const void* d_w_split, const float* d_bias,

@@ -412,3 +412,57 @@ def test_recover_xyz_vs_reference(cases, abs_3d):
     xyz = mp.recover_from_ric(data, 22, abs_3d)
     assert xyz.shape == (3, 1, 196, 22, 3)
     assert max_abs(xyz[:, 0].permute(0, 2, 3, 1).cpu().numpy(), ref) <= tol
+
+
+# ---- convolution over token rows (UNET building block) ------------------------------------------------------
+@pytest.mark.parametrize("kind", ["k5", "k1", "down", "up"])
+def test_conv_rows_h3_vs_torch(kind):
+    """conv1d (k=5 pad 2; k=1), stride-2 conv (k=3, pad 1) and ConvTranspose1d (k=4, s=2, p=1) as split-f16 GEMMs
+    over tap-shifted token rows with zero halo frames, vs torch (float64)."""
+    eng, N = sub("engine"), sub("_native")
+    lib = N.load()
+    g = torch.Generator().manual_seed(hash(kind) % 1000)
+    B, cin, cout = 3, 64, 96
+    T_in, h_in = (56, 4)
+    x = torch.randn(B, cin, T_in, generator=g)
+    if kind in ("k5", "k1"):
+        k, T_out, h_out = (5 if kind == "k5" else 1), T_in, h_in
+        w = torch.randn(cout, cin, k, generator=g) * 0.1
+        ref = torch.nn.functional.conv1d(x.double(), w.double(), padding=k // 2)
+        wg = [w.permute(0, 2, 1).reshape(cout, k * cin)]                    # [n, tap * cin + c]
+        launches = [dict(taps=k, pad=k // 2, a_mul=1, c_mul=0, c_add=0)]
+    elif kind == "down":
+        T_out, h_out = T_in // 2, h_in // 2
+        w = torch.randn(cout, cin, 3, generator=g) * 0.1
+        ref = torch.nn.functional.conv1d(x.double(), w.double(), stride=2, padding=1)
+        wg = [w.permute(0, 2, 1).reshape(cout, 3 * cin)]
+        launches = [dict(taps=3, pad=1, a_mul=2, c_mul=0, c_add=0)]
+    else:
+        T_out, h_out = T_in * 2, h_in * 2
+        w = torch.randn(cin, cout, 4, generator=g) * 0.1                     # ConvTranspose1d weight [in, out, k]
+        ref = torch.nn.functional.conv_transpose1d(x.double(), w.double(), stride=2, padding=1)
+        # out[2j] = x[j-1] W3 + x[j] W1 ; out[2j+1] = x[j] W2 + x[j+1] W0
+        wg = [torch.cat([w[:, :, 3].T, w[:, :, 1].T], dim=1), torch.cat([w[:, :, 2].T, w[:, :, 0].T], dim=1)]
+        launches = [dict(taps=2, pad=1, a_mul=1, c_mul=2, c_add=0), dict(taps=2, pad=0, a_mul=1, c_mul=2, c_add=1)]
+    bias = torch.randn(cout, generator=g)
+    tp_in, tp_out = T_in + 2 * h_in, T_out + 2 * h_out
+    guard = 8
+    rows = torch.zeros(guard + B * tp_in + guard, cin)
+    for b in range(B):
+        rows[guard + b * tp_in + h_in: guard + b * tp_in + h_in + T_in] = x[b].T
+    a_s = eng.split_f16(rows.to(DEV))                                       # [rows, 2 cin]
+    out = torch.zeros(B * tp_out, cout, device=DEV)
+    m_gemm = B * tp_in if kind == "up" else B * tp_out                       # GEMM rows = output (or input, up) rows
+    for wmat, L in zip(wg, launches):
+        w_s = eng.split_f16(wmat.contiguous().to(DEV))
+        a_ptr = a_s.data_ptr() + guard * (2 * cin) * 2
+        with torch.cuda.device(DEV):
+            N.check(lib.cmdi_conv_rows_h3(a_ptr, 2 * cin, N.ptr(w_s), N.ptr(bias.to(DEV)), 0, N.ptr(out), 0,
+                                          m_gemm, cout, cin, L["taps"], L["pad"], L["a_mul"], L["c_mul"],
+                                          L["c_add"], tp_out, h_out, h_out + T_out, 0,
+                                          N.current_stream(torch.device(DEV))))
+    got = out.cpu().view(B, tp_out, cout)
+    assert float(got[:, :h_out].abs().max()) == 0.0 and float(got[:, h_out + T_out:].abs().max()) == 0.0  # halo
+    got = got[:, h_out:h_out + T_out].permute(0, 2, 1)
+    want = ref + bias.double()[None, :, None]
+    assert rel_l2(got.numpy(), want.numpy()) <= 2e-6, rel_l2(got.numpy(), want.numpy())
