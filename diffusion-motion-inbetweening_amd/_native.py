@@ -19,6 +19,7 @@ LIB_PATH = _PKG / "csrc" / "libcondmdi_hip.so"
 CMDI_MEAN_START_X, CMDI_MEAN_EPSILON = 0, 1
 CMDI_SAMPLER_DDPM, CMDI_SAMPLER_DDIM = 0, 1
 CMDI_PREC_DEFAULT, CMDI_PREC_F32, CMDI_PREC_F16X3 = 0, 1, 2
+CMDI_ARCH_TRANS_ENC, CMDI_ARCH_UNET = 0, 1
 PRECISIONS = {None: CMDI_PREC_DEFAULT, "default": CMDI_PREC_DEFAULT, "f32": CMDI_PREC_F32,
               "f16x3": CMDI_PREC_F16X3}
 
@@ -30,7 +31,7 @@ class NativeError(RuntimeError):
 class ModelDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n_layers", "d_model", "d_ff", "n_heads", "n_feats", "max_frames", "max_batch", "pe_rows",
-        "text_cond", "want_grad", "precision")]
+        "text_cond", "want_grad", "precision", "arch", "unet_added")] + [("unet_mults", C.c_int32 * 4)]
 
 
 class Schedule(C.Structure):
@@ -48,6 +49,7 @@ class Condition(C.Structure):
         ("imputate", C.c_int32), ("stop_imputation_at", C.c_int32),
         ("recon_guidance", C.c_int32), ("stop_recguidance_at", C.c_int32),
         ("recon_w", C.POINTER(C.c_float)),
+        ("d_obs_x0", C.c_void_p), ("d_obs_mask", C.c_void_p),
     ]
 
 

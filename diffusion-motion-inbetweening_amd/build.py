@@ -26,6 +26,7 @@ UNITS = {
     "attention_f32.hip": [],
     "attention_h3.hip": [],
     "attention_bwd_f32.hip": [],
+    "unet.hip": [],
     "elementwise.hip": [],
     # reference evaluation order, every op rounded separately (see the header of sampler.hip)
     "sampler.hip": ["-ffp-contract=off"],

@@ -90,6 +90,11 @@ struct cmdi_engine {
     int precision = CMDI_PREC_F16X3;
     _Float16 *tokS = nullptr, *bufHS = nullptr, *attnS = nullptr, *ffnS = nullptr, *qkvS = nullptr;
     _Float16 *dBS = nullptr, *dffnS = nullptr, *dqkvS = nullptr, *dOS = nullptr;  // backward operands (want_grad)
+    UnetModel* unet = nullptr;     // arch = CMDI_ARCH_UNET: the MDM_UNET denoiser (unet.hip)
+    float* uemb = nullptr;          // [2 Bmax, d] time (+ text) embedding per sequence
+    float* obs_x0 = nullptr;        // keyframe conditioning of the UNET (model_kwargs obs_x0 / obs_mask)
+    uint8_t* obs_mask = nullptr;
+    bool have_obs = false;
     int* range_flag = nullptr;
     unsigned* gs_bits = nullptr;   // max|gout| bits -> power-of-two gradient scale (f16x3 backward); [1 + parts]
     float* text_term_p = nullptr;  // text_term in the slot order of the independent pipelines (cmdi_sample_loop)
@@ -338,6 +343,16 @@ int mdm_forward(cmdi_engine* e, const float* x, const int64_t* t_dev, int64_t t_
                 float* out_buf, bool keep, hipStream_t s, bool tables = false) {
     const int B = e->B, T = e->T, S = T + 1, d = e->d, C = e->C;
     const int n_seq = e->cfg ? 2 * B : B;
+    if (e->unet) {   // MDM_UNET.forward (model/mdm_unet.py:766-849)
+        if (keep) return fail(CMDI_E_STATE, "UNET engine: no activation stash / VJP");
+        HIPCHK(launch_unet_emb(e->uemb, e->time_table, e->have_text ? e->text_term : nullptr, t_dev, t_scalar,
+                               n_seq, B, d, e->n_time_rows, s));
+        if (unet_forward(e->unet, x, e->have_obs ? e->obs_x0 : nullptr, e->have_obs ? e->obs_mask : nullptr,
+                         e->uemb, B, n_seq, T, out_buf, s) != 0)
+            return fail(CMDI_E_HIP, std::string("UNET: ") + unet_error(e->unet));
+        e->stash_valid = false;
+        return CMDI_OK;
+    }
 
     HIPCHK(launch_token0(e->tokA, e->time_table, e->have_text ? e->text_term : nullptr, e->pe, t_dev,
                          t_scalar, n_seq, B, S, d, e->n_time_rows, s, tables ? e->tmap_dev : nullptr,
@@ -483,7 +498,7 @@ int mdm_backward(cmdi_engine* e, const float* gout, float* gx, hipStream_t s) {
 
 int check_ready(cmdi_engine* e, bool need_schedule, bool need_model = true) {
     if (!e) return fail(CMDI_E_INVALID, "null handle");
-    if (need_model && e->L == 0) return fail(CMDI_E_STATE, "sampler-only engine has no denoiser");
+    if (need_model && e->L == 0 && !e->unet) return fail(CMDI_E_STATE, "sampler-only engine has no denoiser");
     if (!e->finalized) return fail(CMDI_E_STATE, "weights not finalized (cmdi_finalize_weights)");
     if (!e->have_cond) return fail(CMDI_E_STATE, "condition not set (cmdi_set_condition)");
     if (need_schedule && !e->have_schedule) return fail(CMDI_E_STATE, "schedule not set (cmdi_set_schedule)");
@@ -539,6 +554,45 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
     if (!desc || !out) return fail(CMDI_E_INVALID, "null argument");
     if (desc->n_feats < 1 || desc->max_batch < 1 || desc->max_frames < 1)
         return fail(CMDI_E_INVALID, "bad model geometry");
+    if (desc->arch == CMDI_ARCH_UNET) {
+        // MDM_UNET denoiser: the embedding front end (pe, time_embed, embed_text) of the transformer engine +
+        // the temporal U-Net of unet.hip; the sampler / condition machinery is shared
+        if (desc->d_model != 512 || desc->max_frames > 224 || desc->pe_rows < 1)
+            return fail(CMDI_E_INVALID, "UNET engine: latent_dim must be 512, max_frames <= 224");
+        if (desc->want_grad) return fail(CMDI_E_INVALID, "UNET engine: no VJP (reconstruction guidance) yet");
+        if (desc->precision == CMDI_PREC_F32) return fail(CMDI_E_INVALID, "UNET engine: only the f16x3 precision is built");
+        cmdi_engine* e = new cmdi_engine();
+        e->desc = *desc;
+        e->d = desc->d_model; e->C = desc->n_feats; e->Tmax = desc->max_frames; e->Bmax = desc->max_batch;
+        e->precision = CMDI_PREC_F16X3;
+        *out = e;
+        const int d = e->d;
+        const size_t nseq = 2 * (size_t)e->Bmax;
+        ALLOC(e->pe, (size_t)desc->pe_rows * d);
+        ALLOC(e->t1_w, (size_t)d * d); ALLOC(e->t1_b, d); ALLOC(e->t2_w, (size_t)d * d); ALLOC(e->t2_b, d);
+        if (desc->text_cond) { ALLOC(e->txt_w, (size_t)d * e->clip_dim); ALLOC(e->txt_b, d); }
+        ALLOC(e->text_term, nseq * d); ALLOC(e->text_term_p, nseq * d); ALLOC(e->text_scale, e->Bmax);
+        ALLOC(e->enc_text, (size_t)e->Bmax * e->clip_dim);
+        ALLOC(e->inpaint, (size_t)e->Bmax * e->C * e->Tmax);
+        ALLOC(e->obs_x0, (size_t)e->Bmax * e->C * e->Tmax);
+        {
+            int rc = dalloc(e, reinterpret_cast<void**>(&e->mask), (size_t)e->Bmax * e->C * e->Tmax);
+            if (rc != CMDI_OK) return rc;
+            rc = dalloc(e, reinterpret_cast<void**>(&e->obs_mask), (size_t)e->Bmax * e->C * e->Tmax);
+            if (rc != CMDI_OK) return rc;
+        }
+        ALLOC(e->uemb, nseq * d);
+        ALLOC(e->out_raw, nseq * e->C * e->Tmax);
+        ALLOC(e->range_flag, 1);
+        HIPCHK(hipMemset(e->range_flag, 0, sizeof(int)));
+        ALLOC(e->gs_bits, 16);
+        e->unet = unet_new(desc->n_feats, desc->unet_added, desc->d_model, desc->unet_mults, (int)nseq,
+                           desc->text_cond != 0);
+        if (unet_error(e->unet)[0]) return fail(CMDI_E_INVALID, std::string("UNET: ") + unet_error(e->unet));
+        e->bytes += unet_bytes(e->unet);
+        e->pipelines = 0;
+        return CMDI_OK;
+    }
     if (desc->n_layers == 0) {
         // sampler-only engine: schedule + condition + cmdi_sampler_update / q_sample / randn, for
         // denoisers that are not the native MDM
@@ -696,6 +750,7 @@ int cmdi_profile_read(cmdi_handle e, double* total_ms, int64_t* launches, int32_
 int cmdi_destroy(cmdi_handle h) {
     if (!h) return CMDI_OK;
     drop_graphs(h);
+    if (h->unet) unet_free(h->unet);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     for (hipEvent_t ev : h->own_ev) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : h->ev_pool) (void)hipEventDestroy(ev);
@@ -713,6 +768,11 @@ int cmdi_load_weight(cmdi_handle e, const char* name, const float* d_src, int64_
     if (!e || !name || !d_src) return fail(CMDI_E_INVALID, "null argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int d = e->d, f = e->f, C = e->C;
+    if (e->unet) {
+        const int ur = unet_load_weight(e->unet, name, d_src, numel, s);
+        if (ur == 0) { e->finalized = false; return CMDI_OK; }
+        if (ur < 0) return fail(CMDI_E_INVALID, std::string("UNET: ") + unet_error(e->unet));
+    }
     float* dst = nullptr;
     int64_t want = -1;
     const std::string n(name);
@@ -761,6 +821,11 @@ int cmdi_finalize_weights(cmdi_handle e, int32_t n_time_rows, cmdi_stream stream
     const int d = e->d, f = e->f, C = e->C;
     if (n_time_rows < 1 || n_time_rows > e->desc.pe_rows)
         return fail(CMDI_E_INVALID, "n_time_rows must be in [1, pe_rows]");
+    if (e->unet) {
+        const int ur = unet_finalize(e->unet, s);
+        if (ur == -2) return fail(CMDI_E_RANGE, std::string("UNET: ") + unet_error(e->unet));
+        if (ur != 0) return fail(CMDI_E_HIP, std::string("UNET: ") + unet_error(e->unet));
+    } else
     HIPCHK(launch_pad_copy(e->w_in_pad, e->w_in, d, C, e->Cpad, s));
     if (e->desc.want_grad) {
         HIPCHK(launch_transpose_pad(e->w_inT, e->w_in, d, C, d, s));          // [C][d]
@@ -861,6 +926,19 @@ int cmdi_set_condition(cmdi_handle e, const cmdi_condition* c, cmdi_stream strea
         HIPCHK(hipMemcpyAsync(e->mask, c->d_inpaint_mask, n, hipMemcpyDeviceToDevice, s));
     if (c->d_inpaint_motion)
         HIPCHK(hipMemcpyAsync(e->inpaint, c->d_inpaint_motion, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    e->have_obs = false;
+    if (e->unet) {
+        if (c->recon_guidance) return fail(CMDI_E_INVALID, "UNET engine: reconstruction guidance (VJP) is not built yet");
+        if ((c->d_obs_x0 == nullptr) != (c->d_obs_mask == nullptr))
+            return fail(CMDI_E_INVALID, "with spatial-conditioning, both obs_x0 and obs_mask must be provided");
+        if (e->desc.unet_added && !c->d_obs_x0)
+            return fail(CMDI_E_INVALID, "a keyframe-conditioned UNET needs obs_x0 and obs_mask");
+        if (c->d_obs_x0) {
+            HIPCHK(hipMemcpyAsync(e->obs_x0, c->d_obs_x0, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+            HIPCHK(hipMemcpyAsync(e->obs_mask, c->d_obs_mask, n, hipMemcpyDeviceToDevice, s));
+            e->have_obs = true;
+        }
+    }
     e->recon_w.clear();
     if (c->recon_w) {
         if (!e->have_schedule) return fail(CMDI_E_STATE, "set the schedule before a condition with recon_w");
@@ -1279,10 +1357,10 @@ int cmdi_sample_loop(cmdi_handle e, int32_t sampler, int32_t first_step, int32_t
     if (first_step < last_step || last_step < 0 || first_step >= e->n_steps)
         return fail(CMDI_E_INVALID, "need n_steps > first_step >= last_step >= 0");
     if (!d_x) return fail(CMDI_E_INVALID, "null tensor");
-    if (e->use_graph && !d_noise_stream && !e->profile)
+    if (e->use_graph && !d_noise_stream && !e->profile && !e->unet)
         return sample_loop_graph(e, sampler, first_step, last_step, eta, d_x, seed, first_sample,
                                  static_cast<hipStream_t>(stream));
-    if (e->pipelines && !e->profile)
+    if (e->pipelines && !e->profile && !e->unet)
         return sample_loop_pipelines(e, sampler, first_step, last_step, eta, d_x, d_noise_stream, seed,
                                      first_sample, static_cast<hipStream_t>(stream));
     const size_t n = (size_t)e->B * e->C * e->T;
@@ -1363,6 +1441,11 @@ int cmdi_range_status(cmdi_handle e, int32_t* out_flag, cmdi_stream stream) {
     HIPCHK(hipMemcpyAsync(&flag, e->range_flag, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (flag) HIPCHK(hipMemsetAsync(e->range_flag, 0, sizeof(int), s));
+    if (e->unet) {
+        int uf = 0;
+        if (unet_range_flag(e->unet, &uf, s) != 0) return fail(CMDI_E_HIP, "UNET: range flag read-back failed");
+        flag |= uf;
+    }
     *out_flag = flag;
     return CMDI_OK;
 }

@@ -328,8 +328,21 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
                     *reinterpret_cast<float4*>(p.C + off) = make_float4(v[0], v[1], v[2], v[3]);
                 } else if constexpr (EPI == H3_RESID) {
                     const float4 rr = *reinterpret_cast<const float4*>(p.R + off);
-                    *reinterpret_cast<float4*>(p.C + off) =
-                        make_float4(v[0] + rr.x, v[1] + rr.y, v[2] + rr.z, v[3] + rr.w);
+                    v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+                    if (p.C) *reinterpret_cast<float4*>(p.C + off) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (p.Cs) {
+                        h4 oh, ol;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            _Float16 a, b;
+                            split_f16(v[e], a, b);
+                            oh[e] = a; ol[e] = b;
+                            overflow |= !(fabsf(v[e]) < 65504.0f);
+                        }
+                        _Float16* dst = p.Cs + (size_t)m * (p.cs_ld ? p.cs_ld : 2 * p.N) + npos;
+                        *reinterpret_cast<h4*>(dst) = oh;
+                        *reinterpret_cast<h4*>(dst + 32) = ol;
+                    }
                 } else {
                     if constexpr (EPI == H3_GELUGRAD_SPLIT) {
                         const float4 ax = *reinterpret_cast<const float4*>(p.aux + off);
@@ -350,14 +363,14 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
                         oh[e] = a; ol[e] = b;
                         overflow |= !(fabsf(v[e]) < 65504.0f);
                     }
-                    _Float16* dst = p.Cs + (size_t)m * (2 * p.N) + npos;
+                    _Float16* dst = p.Cs + (size_t)m * (p.cs_ld ? p.cs_ld : 2 * p.N) + npos;
                     *reinterpret_cast<h4*>(dst) = oh;
                     *reinterpret_cast<h4*>(dst + 32) = ol;
                 }
             }
         }
     }
-    if constexpr (EPI == H3_GELU_SPLIT || EPI == H3_PLAIN_SPLIT || EPI == H3_GELUGRAD_SPLIT) {
+    if constexpr (EPI == H3_GELU_SPLIT || EPI == H3_PLAIN_SPLIT || EPI == H3_GELUGRAD_SPLIT || EPI == H3_RESID) {
         if (overflow && p.range_flag) atomicOr(p.range_flag, 1);
     }
     if ((p.dbg & 16) && p.dbg_buf && tid == 0) {

@@ -44,7 +44,7 @@ struct GemmParams {
 enum H3Epi {
     H3_PLAIN = 0,       // C = v + bias[n]                                   (fp32)
     H3_GELU_SPLIT = 1,  // aux = v + bias (optional); Cs = split(gelu_erf(v + bias))
-    H3_RESID = 2,       // C = (v + bias[n]) + R[m][n]                       (fp32)
+    H3_RESID = 2,       // C = (v + bias[n]) + R[m][n]  (fp32; C may be null) and, if Cs != null, Cs = split(C)
     H3_PLAIN_SPLIT = 3, // aux = v + bias (optional fp32 copy); Cs = split(v + bias[n])
     H3_GELUGRAD_SPLIT = 4, // Cs = split(v * gelu'(aux[m][n]))   (backward through linear1's GELU)
     H3_RESID_LN = 5,    // x = (v + bias) + R; aux = x (optional); y = LayerNorm(x) -> C (fp32) and Cs (split,
@@ -72,6 +72,7 @@ struct H3Params {
     // if that row's position inside its tp-row sequence frame lies in [t_lo, t_hi) (halo rows stay zero).
     int a_ld, a_row_mul, taps, cpt;
     int c_row_mul, c_row_add, tp, t_lo, t_hi;
+    int cs_ld;          // halves per row of the split output (0 = 2N); Cs may point at a column block of a wider matrix
     int dbg;            // bench-only ablations: 1 = no in-loop loads, 2 = no epilogue stores, 16 = timestamps
     long long* dbg_buf; // dbg & 16: per block {start, loop start, loop end, end} (s_memtime)
 };

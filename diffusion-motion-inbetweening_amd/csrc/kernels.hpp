@@ -82,6 +82,20 @@ hipError_t launch_pad_copy(float* dst, const float* src, int rows, int cols, int
 hipError_t launch_transpose_pad(float* dst, const float* src, int rows, int cols, int ldd,
                                 hipStream_t stream);
 
+// ---- unet.hip: MDM_UNET denoiser ------------------------------------------------------------------
+struct UnetModel;
+UnetModel* unet_new(int n_feats, int added, int dim, const int mults[4], int max_seq, bool text);
+const char* unet_error(const UnetModel* u);
+int64_t unet_bytes(const UnetModel* u);
+void unet_free(UnetModel* u);
+int unet_load_weight(UnetModel* u, const char* name, const float* d_src, int64_t numel, hipStream_t s);
+int unet_finalize(UnetModel* u, hipStream_t s);
+int unet_forward(UnetModel* u, const float* x, const float* obs, const uint8_t* mask, const float* emb, int B, int nseq,
+                 int T, float* out, hipStream_t s);
+int unet_range_flag(UnetModel* u, int* flag, hipStream_t s);
+hipError_t launch_unet_emb(float* emb, const float* time_table, const float* text_term, const int64_t* t_dev,
+                           int64_t t_scalar, int n_seq, int n_per_pass, int d, int n_time_rows, hipStream_t stream);
+
 // ---- postprocess.hip ------------------------------------------------------------------------------
 // x [B, n_feats, 1, T] (z-scored if mean/std given) -> joint positions out [B, n_joints, 3, T]
 hipError_t launch_recover_xyz(const float* x, const float* mean, const float* std, float* out, int batch,

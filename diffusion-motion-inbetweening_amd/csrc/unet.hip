@@ -1,0 +1,605 @@
+// MDM_UNET denoiser (the "Diffuser-style" temporal U-Net CondMDI trains by default; reference
+// model/mdm_unet.py:214-358 TemporalUnet, :561-849 MDM_UNET) on the f16 matrix pipe.
+//
+// Activations are token rows, sequence-major, one FRAME of Tp = 256 >> level rows per sequence: a zero halo
+// of h = 16 >> level rows, the 224 >> level positions, another halo — so every 1-D convolution is a GEMM over
+// tap-shifted rows (gemm_h3.hpp, H3Params::taps) and the stride-2 / transposed convolutions map row m to
+// 2m (-1) exactly (Tp halves with the resolution).  Rows are carried in split-f16 form for the GEMMs and
+// in fp32 where a residual or a GroupNorm reads them.
+//
+//   x' = obs_x0*m + x*~m ; cat(x', m) -> 526 (-> 544) channels                     mdm_unet.py:779-782
+//   c  = time_mlp(emb) = Linear(Mish(Linear(emb)))                                  :236-241, :321
+//   ResidualTemporalBlock(x, c): Conv5 -> GroupNorm(8) -> *(1+scale)+shift -> Mish -> Conv5 -> GroupNorm(8)
+//        -> Mish, + residual_conv(x) (1x1 if channels change);  (scale, shift) = Linear(Mish(c))   :163-212
+//   downs x4 [RB, RB, (skip), Conv3 stride 2], mid [RB, RB], ups x3 [cat skip, RB, RB, ConvTranspose4 s2],
+//   final Conv5 -> GN -> Mish -> Conv1(1024 -> 263)                                 :323-345
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+#include "gemm_h3.hpp"
+#include "kernels.hpp"
+
+namespace cmdi {
+
+namespace {
+constexpr int NG = 8;          // GroupNorm groups
+constexpr int TPAD = 224;      // the reference pads every sequence to 224 frames (mdm_unet.py:810)
+constexpr int GUARD = 16;      // rows in front of / behind every row buffer (taps of the first / last frame)
+
+__device__ __forceinline__ float mish(float x) {
+    // x * tanh(softplus(x)), softplus with torch's threshold 20 (nn.Mish -> F.mish)
+    const float sp = x > 20.f ? x : log1pf(expf(x));
+    return x * tanhf(sp);
+}
+
+// ---- input frames: x' = obs*m + x*(1-m), cat(x', m), zero channel padding; CFG: both passes get the same rows ----
+// x, obs [B, J, T] (T contiguous), mask u8 [B, J, T]; out split rows [nseq * Tp, 2*Cp]; one block per (seq, frame tile)
+__global__ __launch_bounds__(256) void unet_input_kernel(const float* __restrict__ x, const float* __restrict__ obs,
+                                                         const uint8_t* __restrict__ mask, _Float16* __restrict__ out,
+                                                         int B, int J, int T, int Cp, int Tp, int h, int keyframe) {
+    const int seq = blockIdx.y, b = seq % B;           // sequences: [cond B | uncond B]
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6); // 4 frames per block
+    if (t >= TPAD) return;
+    const int lane = threadIdx.x & 63;
+    _Float16* row = out + ((size_t)seq * Tp + h + t) * (2 * Cp);
+    for (int c = lane; c < Cp; c += 64) {
+        float v = 0.f;
+        if (t < T) {
+            if (c < J) {
+                v = x[((size_t)b * J + c) * T + t];
+                if (keyframe && mask[((size_t)b * J + c) * T + t]) v = obs[((size_t)b * J + c) * T + t];
+            } else if (keyframe && c < 2 * J) {
+                v = mask[((size_t)b * J + (c - J)) * T + t] ? 1.f : 0.f;
+            }
+        }
+        _Float16 a, l;
+        split_f16(v, a, l);
+        row[split_pos(c)] = a;
+        row[split_pos(c) + 32] = l;
+    }
+}
+
+// y = act(x) elementwise, act = Mish
+__global__ void mish_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] = mish(x[i]);
+}
+
+// emb[seq][:] = time_table[t] + text_term[seq]   (MDM_UNET.forward_core: embed_timestep + embed_text(mask_cond))
+__global__ void unet_emb_kernel(float* __restrict__ emb, const float* __restrict__ time_table,
+                                const float* __restrict__ text_term, const int64_t* __restrict__ t_dev,
+                                int64_t t_scalar, int n_per_pass, int d, int n_time_rows) {
+    const int seq = blockIdx.x;
+    int64_t t = t_dev ? t_dev[seq % n_per_pass] : t_scalar;
+    t = t < 0 ? 0 : (t >= n_time_rows ? n_time_rows - 1 : t);
+    for (int n = threadIdx.x; n < d; n += blockDim.x) {
+        float e = time_table[(size_t)t * d + n];
+        if (text_term) e += text_term[(size_t)seq * d + n];
+        emb[(size_t)seq * d + n] = e;
+    }
+}
+
+// ---- GroupNorm statistics: one block per (sequence, group); two-pass mean / biased variance over the
+// (C/8 channels) x (Tv frames) of the group (nn.GroupNorm(8, C), eps 1e-5) --------------------------------
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, float* __restrict__ stats,
+                                                       int C, int Tp, int h, int Tv) {
+    __shared__ float red[4];
+    const int seq = blockIdx.x, g = blockIdx.y, cg = C / NG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* base = x + ((size_t)seq * Tp + h) * C + (size_t)g * cg;
+    const int q4 = cg / 4;                    // float4 per row of the group
+    const int total = Tv * q4;
+    float s = 0.f;
+    for (int i = tid; i < total; i += 256) {
+        const int r = i / q4, c4 = i - r * q4;
+        const float4 v = *reinterpret_cast<const float4*>(base + (size_t)r * C + c4 * 4);
+        s += (v.x + v.y) + (v.z + v.w);
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)(Tv * cg);
+    __syncthreads();
+    float q = 0.f;
+    for (int i = tid; i < total; i += 256) {
+        const int r = i / q4, c4 = i - r * q4;
+        const float4 v = *reinterpret_cast<const float4*>(base + (size_t)r * C + c4 * 4);
+        const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+        q += (a * a + b * b) + (c * c + d * d);
+    }
+    q = wave_sum(q);
+    if (lane == 0) red[wave] = q;
+    __syncthreads();
+    if (tid == 0) {
+        const float var = ((red[0] + red[1]) + (red[2] + red[3])) / (float)(Tv * cg);
+        stats[((size_t)seq * NG + g) * 2] = mean;
+        stats[((size_t)seq * NG + g) * 2 + 1] = 1.0f / sqrtf(var + 1e-5f);
+    }
+}
+
+// y = Mish( GN(x) [* (1 + scale) + shift] ) [+ resid]  -> fp32 (optional) and split rows (optional)
+// one wave per frame row; ss = [nseq][2C] (scale | shift) or null
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ ss, const float* __restrict__ resid,
+                                                       float* __restrict__ yf, _Float16* __restrict__ ys, int ys_ld,
+                                                       int* __restrict__ range_flag, int C, int Tp, int h, int Tv) {
+    const int seq = blockIdx.y;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= Tv) return;
+    const int lane = threadIdx.x & 63;
+    const size_t row = (size_t)seq * Tp + h + t;
+    const int cg = C / NG;
+    bool overflow = false;
+    for (int c = lane * 4; c < C; c += 256) {
+        const int g = c / cg;
+        const float mean = stats[((size_t)seq * NG + g) * 2], rstd = stats[((size_t)seq * NG + g) * 2 + 1];
+        const float4 v = *reinterpret_cast<const float4*>(x + row * C + c);
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+        const float4 be = *reinterpret_cast<const float4*>(beta + c);
+        float y[4] = {(v.x - mean) * rstd * ga.x + be.x, (v.y - mean) * rstd * ga.y + be.y,
+                      (v.z - mean) * rstd * ga.z + be.z, (v.w - mean) * rstd * ga.w + be.w};
+        if (ss) {
+            const float4 sc = *reinterpret_cast<const float4*>(ss + (size_t)seq * 2 * C + c);
+            const float4 sh = *reinterpret_cast<const float4*>(ss + (size_t)seq * 2 * C + C + c);
+            y[0] = y[0] * (1.f + sc.x) + sh.x; y[1] = y[1] * (1.f + sc.y) + sh.y;
+            y[2] = y[2] * (1.f + sc.z) + sh.z; y[3] = y[3] * (1.f + sc.w) + sh.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = mish(y[e]);
+        if (resid) {
+            const float4 r = *reinterpret_cast<const float4*>(resid + row * C + c);
+            y[0] += r.x; y[1] += r.y; y[2] += r.z; y[3] += r.w;
+        }
+        if (yf) *reinterpret_cast<float4*>(yf + row * C + c) = make_float4(y[0], y[1], y[2], y[3]);
+        if (ys) {
+            h4 oh, ol;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                _Float16 a, l;
+                split_f16(y[e], a, l);
+                oh[e] = a; ol[e] = l;
+                overflow |= !(fabsf(y[e]) < 65504.0f);
+            }
+            _Float16* d = ys + row * ys_ld + split_pos(c);
+            *reinterpret_cast<h4*>(d) = oh;
+            *reinterpret_cast<h4*>(d + 32) = ol;
+        }
+    }
+    if (overflow && range_flag) atomicOr(range_flag, 1);
+}
+
+// out[seq][c][t] = rows[(seq*Tp + h + t)][c]  for c < J, t < T   (the crop x[:nframes] and the final permute)
+__global__ void unet_output_kernel(const float* __restrict__ rows, float* __restrict__ out, int J, int T, int N,
+                                   int Tp, int h) {
+    const int seq = blockIdx.z, c = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < T) out[((size_t)seq * J + c) * T + t] = rows[((size_t)seq * Tp + h + t) * N + c];
+}
+
+// conv weight [Cout][Cin][k] -> GEMM weight [Cout][taps * Cin_p] (tap-major K, zero channel padding);
+// transposed-conv weight [Cin][Cout][4] -> the two 2-tap matrices of the even / odd output rows
+__global__ void pack_conv_w_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int Cin_p,
+                                   int k, int mode) {
+    // mode 0: out[n][tap*Cin_p + c] = w[n][c][tap];  mode 1 / 2 (transposed, k = 4): even rows taps (3, 1),
+    // odd rows taps (2, 0): out[n][j*Cin_p + c] = w[c][n][tapsel[j]]
+    const int64_t K = (int64_t)(mode == 0 ? k : 2) * Cin_p;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)Cout * K) return;
+    const int n = (int)(i / K);
+    const int r = (int)(i - (int64_t)n * K), tap = r / Cin_p, c = r - tap * Cin_p;
+    float v = 0.f;
+    if (c < Cin) {
+        if (mode == 0) v = w[((size_t)n * Cin + c) * k + tap];
+        else {
+            const int sel = mode == 1 ? (tap == 0 ? 3 : 1) : (tap == 0 ? 2 : 0);
+            v = w[((size_t)c * Cout + n) * 4 + sel];
+        }
+    }
+    out[i] = v;
+}
+
+struct Conv {
+    int cin = 0, cin_p = 0, cout = 0, k = 0;
+    float *w = nullptr, *b = nullptr;       // fp32 originals (w freed after packing)
+    _Float16 *ws = nullptr, *ws2 = nullptr;  // split GEMM weights (ws2: odd rows of a transposed conv)
+    bool transposed = false;
+};
+struct GN { float *g = nullptr, *b = nullptr; };
+struct ResBlock {
+    Conv c1, c2, res;      // res.w == nullptr: identity residual
+    GN n1, n2;
+    float *tw = nullptr, *tb = nullptr;   // time_mlp.1: Linear(dim, 2*cout)
+    int cin = 0, cout = 0;
+};
+}  // namespace
+
+struct UnetModel {
+    int J = 0, added = 0, dim = 0, C[5] = {0, 0, 0, 0, 0}, Cin0p = 0, Np = 0;
+    int max_seq = 0;
+    bool text = false;
+    std::vector<void*> allocs;
+    int64_t bytes = 0;
+    // weights
+    float *t1w = nullptr, *t1b = nullptr, *t2w = nullptr, *t2b = nullptr;   // unet.time_mlp.{0,2}
+    ResBlock down[4][2], mid[2], up[3][2];
+    Conv downs[3], ups[3], fin, outc;
+    GN fin_n;
+    bool finalized = false;
+    // workspace
+    float *emb_h = nullptr, *cvec = nullptr, *cm = nullptr, *ss = nullptr, *stats = nullptr;
+    float *F1[4] = {}, *F2[4] = {}, *Xa[4] = {}, *Xb[4] = {};
+    _Float16 *in0S = nullptr, *H1S[4] = {}, *Sa[4] = {}, *Sb[4] = {}, *CAT[4] = {}, *S0skip = nullptr;
+    float* outF = nullptr;
+    int* range_flag = nullptr;
+    std::string err;
+};
+
+namespace {
+
+int ualloc(UnetModel* u, void** p, size_t nbytes) {
+    if (nbytes == 0) nbytes = 16;
+    if (hipMalloc(p, nbytes) != hipSuccess) { u->err = "hipMalloc failed"; return -1; }
+    u->allocs.push_back(*p);
+    u->bytes += (int64_t)nbytes;
+    return 0;
+}
+template <class T>
+int ualloc_t(UnetModel* u, T** p, size_t count) { return ualloc(u, reinterpret_cast<void**>(p), count * sizeof(T)); }
+
+// row buffers carry GUARD rows in front and behind and are zero-filled once (halo rows are never written)
+template <class T>
+int alloc_rows(UnetModel* u, T** p, size_t rows, size_t width) {
+    T* raw = nullptr;
+    const size_t n = (rows + 2 * GUARD) * width;
+    if (ualloc_t(u, &raw, n)) return -1;
+    if (hipMemset(raw, 0, n * sizeof(T)) != hipSuccess) { u->err = "hipMemset failed"; return -1; }
+    *p = raw + GUARD * width;
+    return 0;
+}
+
+int conv_alloc(UnetModel* u, Conv& c, int cin, int cout, int k, bool transposed = false) {
+    c.cin = cin; c.cin_p = (cin + 31) / 32 * 32; c.cout = cout; c.k = k; c.transposed = transposed;
+    const size_t np = (size_t)(cout + 31) / 32 * 32;   // output columns are padded to whole 32-chunks: zero rows / bias
+    const size_t kk = (size_t)(transposed ? 2 : k) * c.cin_p;
+    if (ualloc_t(u, &c.b, np) || ualloc_t(u, &c.ws, np * kk * 2)) return -1;
+    if (hipMemset(c.b, 0, np * sizeof(float)) != hipSuccess || hipMemset(c.ws, 0, np * kk * 2 * sizeof(_Float16)) != hipSuccess) {
+        u->err = "hipMemset failed"; return -1;
+    }
+    if (transposed && ualloc_t(u, &c.ws2, np * kk * 2)) return -1;
+    // the fp32 original is a transient allocation (freed by unet_finalize)
+    if (hipMalloc(reinterpret_cast<void**>(&c.w), (size_t)cin * cout * k * sizeof(float)) != hipSuccess) {
+        u->err = "hipMalloc failed"; return -1;
+    }
+    return 0;
+}
+int rb_alloc(UnetModel* u, ResBlock& r, int cin, int cout) {
+    r.cin = cin; r.cout = cout;
+    if (conv_alloc(u, r.c1, cin, cout, 5) || conv_alloc(u, r.c2, cout, cout, 5)) return -1;
+    if (cin != cout && conv_alloc(u, r.res, cin, cout, 1)) return -1;
+    if (ualloc_t(u, &r.n1.g, cout) || ualloc_t(u, &r.n1.b, cout) || ualloc_t(u, &r.n2.g, cout) || ualloc_t(u, &r.n2.b, cout))
+        return -1;
+    if (ualloc_t(u, &r.tw, (size_t)2 * cout * u->dim) || ualloc_t(u, &r.tb, (size_t)2 * cout)) return -1;
+    return 0;
+}
+
+struct Slot { float* dst; int64_t numel; };
+
+bool rb_slot(ResBlock& r, const std::string& s, Slot* o) {
+    auto convw = [&](Conv& c) { *o = {c.w, (int64_t)c.cin * c.cout * c.k}; return c.w != nullptr; };
+    if (s == "blocks.0.block1.0.weight" || s == "blocks.0.block.0.weight") return convw(r.c1);
+    if (s == "blocks.0.block1.0.bias" || s == "blocks.0.block.0.bias") { *o = {r.c1.b, r.cout}; return true; }
+    if (s == "blocks.0.block1.2.weight" || s == "blocks.0.block.2.weight") { *o = {r.n1.g, r.cout}; return true; }
+    if (s == "blocks.0.block1.2.bias" || s == "blocks.0.block.2.bias") { *o = {r.n1.b, r.cout}; return true; }
+    if (s == "blocks.1.block.0.weight") return convw(r.c2);
+    if (s == "blocks.1.block.0.bias") { *o = {r.c2.b, r.cout}; return true; }
+    if (s == "blocks.1.block.2.weight") { *o = {r.n2.g, r.cout}; return true; }
+    if (s == "blocks.1.block.2.bias") { *o = {r.n2.b, r.cout}; return true; }
+    if (s == "time_mlp.1.weight") { *o = {r.tw, (int64_t)2 * r.cout * 512}; return true; }
+    if (s == "time_mlp.1.bias") { *o = {r.tb, (int64_t)2 * r.cout}; return true; }
+    if (s == "residual_conv.weight" && r.res.w) return convw(r.res);
+    if (s == "residual_conv.bias" && r.res.b) { *o = {r.res.b, r.cout}; return true; }
+    return false;
+}
+
+hipError_t pack(UnetModel* u, Conv& c, hipStream_t s) {
+    const int kk = (c.transposed ? 2 : c.k) * c.cin_p;
+    const int n_rows = c.cout;
+    float* tmp = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&tmp), (size_t)n_rows * kk * sizeof(float));
+    if (e != hipSuccess) return e;
+    for (int pass = 0; pass < (c.transposed ? 2 : 1); ++pass) {
+        const int64_t n = (int64_t)n_rows * kk;
+        hipLaunchKernelGGL(pack_conv_w_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c.w, tmp, c.cout,
+                           c.cin, c.cin_p, c.k, c.transposed ? 1 + pass : 0);
+        e = launch_split_f16(tmp, pass ? c.ws2 : c.ws, n_rows, kk, kk, u->range_flag, s);
+        if (e != hipSuccess) break;
+    }
+    hipError_t e2 = hipStreamSynchronize(s);
+    (void)hipFree(tmp);
+    (void)hipFree(c.w);
+    c.w = nullptr;
+    return e != hipSuccess ? e : e2;
+}
+
+}  // namespace
+
+UnetModel* unet_new(int n_feats, int added, int dim, const int mults[4], int max_seq, bool text) {
+    UnetModel* u = new UnetModel();
+    u->J = n_feats; u->added = added; u->dim = dim; u->max_seq = max_seq; u->text = text;
+    u->C[0] = n_feats + added;
+    for (int i = 0; i < 4; ++i) u->C[i + 1] = dim * mults[i];
+    u->Cin0p = (u->C[0] + 31) / 32 * 32;
+    u->Np = (n_feats + 31) / 32 * 32;
+    bool ok = dim == 512;   // time tables / text terms come from the engine at d = 512
+    for (int i = 1; i < 5; ++i) ok = ok && u->C[i] == u->C[1] && u->C[i] % 256 == 0;   // uniform width (xl: 1024)
+    if (!ok) { u->err = "unsupported UNET geometry (need latent_dim 512 and equal dim_mults)"; return u; }
+    const int Cw = u->C[1];
+    int rc = 0;
+    rc |= ualloc_t(u, &u->range_flag, 1);
+    if (!rc) (void)hipMemset(u->range_flag, 0, sizeof(int));
+    rc |= ualloc_t(u, &u->t1w, (size_t)4 * dim * dim) | ualloc_t(u, &u->t1b, (size_t)4 * dim);
+    rc |= ualloc_t(u, &u->t2w, (size_t)4 * dim * dim) | ualloc_t(u, &u->t2b, (size_t)dim);
+    for (int l = 0; l < 4 && !rc; ++l) {
+        rc |= rb_alloc(u, u->down[l][0], l == 0 ? u->C[0] : Cw, Cw);
+        rc |= rb_alloc(u, u->down[l][1], Cw, Cw);
+        if (l < 3) rc |= conv_alloc(u, u->downs[l], Cw, Cw, 3);
+    }
+    rc |= rb_alloc(u, u->mid[0], Cw, Cw) | rb_alloc(u, u->mid[1], Cw, Cw);
+    for (int i = 0; i < 3 && !rc; ++i) {
+        rc |= rb_alloc(u, u->up[i][0], 2 * Cw, Cw) | rb_alloc(u, u->up[i][1], Cw, Cw);
+        rc |= conv_alloc(u, u->ups[i], Cw, Cw, 4, true);
+    }
+    rc |= conv_alloc(u, u->fin, Cw, Cw, 5) | conv_alloc(u, u->outc, Cw, n_feats, 1);
+    rc |= ualloc_t(u, &u->fin_n.g, Cw) | ualloc_t(u, &u->fin_n.b, Cw);
+    // workspace
+    const size_t ns = (size_t)max_seq;
+    rc |= ualloc_t(u, &u->emb_h, ns * 4 * dim) | ualloc_t(u, &u->cvec, ns * dim) | ualloc_t(u, &u->cm, ns * dim);
+    rc |= ualloc_t(u, &u->ss, ns * 2 * Cw) | ualloc_t(u, &u->stats, ns * NG * 2);
+    for (int l = 0; l < 4 && !rc; ++l) {
+        const size_t rows = ns * (size_t)(256 >> l);
+        rc |= alloc_rows(u, &u->F1[l], rows, Cw) | alloc_rows(u, &u->F2[l], rows, Cw);
+        rc |= alloc_rows(u, &u->Xa[l], rows, Cw) | alloc_rows(u, &u->Xb[l], rows, Cw);
+        rc |= alloc_rows(u, &u->H1S[l], rows, 2 * (size_t)Cw) | alloc_rows(u, &u->Sa[l], rows, 2 * (size_t)Cw);
+        rc |= alloc_rows(u, &u->Sb[l], rows, 2 * (size_t)Cw) | alloc_rows(u, &u->CAT[l], rows, 4 * (size_t)Cw);
+    }
+    rc |= alloc_rows(u, &u->in0S, ns * 256, 2 * (size_t)u->Cin0p);
+    rc |= alloc_rows(u, &u->S0skip, ns * 256, 2 * (size_t)Cw);
+    rc |= alloc_rows(u, &u->outF, ns * 256, (size_t)u->Np);
+    if (rc && u->err.empty()) u->err = "allocation failed";
+    return u;
+}
+
+const char* unet_error(const UnetModel* u) { return u->err.c_str(); }
+int64_t unet_bytes(const UnetModel* u) { return u->bytes; }
+
+void unet_free(UnetModel* u) {
+    if (!u) return;
+    auto drop = [](Conv& c) { if (c.w) (void)hipFree(c.w); c.w = nullptr; };
+    for (int l = 0; l < 4; ++l) for (int j = 0; j < 2; ++j) { drop(u->down[l][j].c1); drop(u->down[l][j].c2); drop(u->down[l][j].res); }
+    for (int j = 0; j < 2; ++j) { drop(u->mid[j].c1); drop(u->mid[j].c2); drop(u->mid[j].res); }
+    for (int l = 0; l < 3; ++l) { for (int j = 0; j < 2; ++j) { drop(u->up[l][j].c1); drop(u->up[l][j].c2); drop(u->up[l][j].res); } drop(u->downs[l]); drop(u->ups[l]); }
+    drop(u->fin); drop(u->outc);
+    for (void* p : u->allocs) (void)hipFree(p);
+    delete u;
+}
+
+// returns 0 = loaded, 1 = not a UNET weight name, -1 = error (size mismatch, already finalized)
+int unet_load_weight(UnetModel* u, const char* name, const float* d_src, int64_t numel, hipStream_t s) {
+    const std::string n(name);
+    if (n.rfind("unet.", 0) != 0) return 1;
+    Slot sl{nullptr, 0};
+    int a = -1, b = -1;
+    char rest[128] = {0};
+    bool ok = false;
+    if (n == "unet.time_mlp.0.weight") { sl = {u->t1w, (int64_t)4 * u->dim * u->dim}; ok = true; }
+    else if (n == "unet.time_mlp.0.bias") { sl = {u->t1b, (int64_t)4 * u->dim}; ok = true; }
+    else if (n == "unet.time_mlp.2.weight") { sl = {u->t2w, (int64_t)4 * u->dim * u->dim}; ok = true; }
+    else if (n == "unet.time_mlp.2.bias") { sl = {u->t2b, u->dim}; ok = true; }
+    else if (std::sscanf(name, "unet.downs.%d.%d.%127s", &a, &b, rest) == 3 && a >= 0 && a < 4) {
+        const std::string r(rest);
+        if (b < 2) ok = rb_slot(u->down[a][b], r, &sl);
+        else if (b == 3 && a < 3 && r == "conv.weight" && u->downs[a].w) { sl = {u->downs[a].w, (int64_t)u->downs[a].cin * u->downs[a].cout * 3}; ok = true; }
+        else if (b == 3 && a < 3 && r == "conv.bias") { sl = {u->downs[a].b, u->downs[a].cout}; ok = true; }
+    } else if (std::sscanf(name, "unet.ups.%d.%d.%127s", &a, &b, rest) == 3 && a >= 0 && a < 3) {
+        const std::string r(rest);
+        if (b < 2) ok = rb_slot(u->up[a][b], r, &sl);
+        else if (b == 3 && r == "conv.weight" && u->ups[a].w) { sl = {u->ups[a].w, (int64_t)u->ups[a].cin * u->ups[a].cout * 4}; ok = true; }
+        else if (b == 3 && r == "conv.bias") { sl = {u->ups[a].b, u->ups[a].cout}; ok = true; }
+    } else if (std::sscanf(name, "unet.mid_block%d.%127s", &a, rest) == 2 && (a == 1 || a == 2)) {
+        ok = rb_slot(u->mid[a - 1], rest, &sl);
+    } else if (n == "unet.final_conv.0.block.0.weight" && u->fin.w) { sl = {u->fin.w, (int64_t)u->fin.cin * u->fin.cout * 5}; ok = true; }
+    else if (n == "unet.final_conv.0.block.0.bias") { sl = {u->fin.b, u->fin.cout}; ok = true; }
+    else if (n == "unet.final_conv.0.block.2.weight") { sl = {u->fin_n.g, u->fin.cout}; ok = true; }
+    else if (n == "unet.final_conv.0.block.2.bias") { sl = {u->fin_n.b, u->fin.cout}; ok = true; }
+    else if (n == "unet.final_conv.1.weight" && u->outc.w) { sl = {u->outc.w, (int64_t)u->outc.cin * u->outc.cout}; ok = true; }
+    else if (n == "unet.final_conv.1.bias") { sl = {u->outc.b, u->outc.cout}; ok = true; }
+    if (!ok || !sl.dst) { u->err = "unknown or already packed UNET weight: " + n; return -1; }
+    if (sl.numel != numel) {
+        u->err = n + ": expected " + std::to_string(sl.numel) + " elements, got " + std::to_string(numel);
+        return -1;
+    }
+    if (hipMemcpyAsync(sl.dst, d_src, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
+        u->err = "hipMemcpyAsync failed"; return -1;
+    }
+    return 0;
+}
+
+// packs every convolution into split GEMM weights (frees the fp32 originals); -2: a weight is out of f16 range
+int unet_finalize(UnetModel* u, hipStream_t s) {
+    if (u->finalized) return 0;
+    std::vector<Conv*> convs;
+    auto rb = [&](ResBlock& r) { convs.push_back(&r.c1); convs.push_back(&r.c2); if (r.res.w) convs.push_back(&r.res); };
+    for (int l = 0; l < 4; ++l) { rb(u->down[l][0]); rb(u->down[l][1]); if (l < 3) convs.push_back(&u->downs[l]); }
+    rb(u->mid[0]); rb(u->mid[1]);
+    for (int i = 0; i < 3; ++i) { rb(u->up[i][0]); rb(u->up[i][1]); convs.push_back(&u->ups[i]); }
+    convs.push_back(&u->fin); convs.push_back(&u->outc);
+    for (Conv* c : convs) {
+        if (!c->w) { u->err = "UNET weights already packed"; return -1; }
+        if (pack(u, *c, s) != hipSuccess) { u->err = "packing a convolution failed"; return -1; }
+    }
+    int flag = 0;
+    if (hipMemcpy(&flag, u->range_flag, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { u->err = "hipMemcpy failed"; return -1; }
+    if (flag) { u->err = "a UNET weight is not finite or exceeds the f16 range"; return -2; }
+    u->finalized = true;
+    return 0;
+}
+
+namespace {
+
+struct Lvl { int Tp, h, Tv; };
+inline Lvl lvl(int l) { return {256 >> l, 16 >> l, TPAD >> l}; }
+
+#define UCHK(expr)                                                                \
+    do {                                                                          \
+        hipError_t _e = (expr);                                                   \
+        if (_e != hipSuccess) {                                                   \
+            u->err = std::string(#expr) + ": " + hipGetErrorString(_e);           \
+            return -1;                                                            \
+        }                                                                         \
+    } while (0)
+
+// conv as GEMM over rows; `a` points at row 0 of the input frame buffer (column block already applied)
+int conv_rows(UnetModel* u, const Conv& c, const _Float16* ws, const _Float16* a, int a_ld, int m_rows, int level_out,
+              int taps, int pad, int a_mul, int c_mul, int c_add, float* out_f, _Float16* out_s, int cs_ld,
+              const float* resid, hipStream_t s) {
+    const Lvl lo = lvl(level_out);
+    H3Params p{};
+    p.A = a - (ptrdiff_t)pad * a_ld;
+    p.W = ws; p.bias = c.b;
+    p.M = m_rows; p.N = (c.cout + 31) / 32 * 32; p.K = taps * c.cin_p; p.ldc = p.N;
+    p.a_ld = a_ld; p.a_row_mul = a_mul; p.taps = taps; p.cpt = c.cin_p / 32;
+    p.c_row_mul = c_mul; p.c_row_add = c_add; p.tp = lo.Tp; p.t_lo = lo.h; p.t_hi = lo.h + lo.Tv;
+    p.cs_ld = cs_ld; p.range_flag = u->range_flag;
+    int kind;
+    if (resid) { kind = H3_RESID; p.R = resid; p.C = out_f; p.Cs = out_s; }
+    else if (out_s) { kind = H3_PLAIN_SPLIT; p.Cs = out_s; p.aux = out_f; }
+    else { kind = H3_PLAIN; p.C = out_f; }
+    UCHK(launch_gemm_h3(kind, p, 0, s));
+    return 0;
+}
+
+int group_norm(UnetModel* u, const float* x, const GN& n, const float* ss, const float* resid, float* yf, _Float16* ys,
+               int ys_ld, int nseq, int level, hipStream_t s) {
+    const Lvl L = lvl(level);
+    const int C = u->C[1];
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nseq, NG), dim3(256), 0, s, x, u->stats, C, L.Tp, L.h, L.Tv);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((L.Tv + 3) / 4, nseq), dim3(256), 0, s, x, u->stats, n.g, n.b, ss, resid, yf,
+                       ys, ys_ld, u->range_flag, C, L.Tp, L.h, L.Tv);
+    UCHK(hipGetLastError());
+    return 0;
+}
+
+// ResidualTemporalBlock: xs = input rows (split, a_ld halves per row), xf = the same in fp32 (identity residual only)
+int res_block(UnetModel* u, const ResBlock& r, const _Float16* xs, int a_ld, const float* xf, int nseq, int level,
+              float* out_f, _Float16* out_s, int out_ld, hipStream_t s) {
+    const Lvl L = lvl(level);
+    const int rows = nseq * L.Tp, C = r.cout;
+    {   // (scale | shift) = Linear(Mish(c))
+        GemmParams p{};
+        p.A = u->cm; p.W = r.tw; p.bias = r.tb; p.C = u->ss;
+        p.M = nseq; p.N = 2 * C; p.K = u->dim; p.lda = u->dim; p.ldw = u->dim; p.ldc = 2 * C; p.out_scale = 1.f;
+        UCHK(launch_gemm(GK_PLAIN, p, 4, s));
+    }
+    if (conv_rows(u, r.c1, r.c1.ws, xs, a_ld, rows, level, 5, 2, 1, 0, 0, u->F1[level], nullptr, 0, nullptr, s)) return -1;
+    if (group_norm(u, u->F1[level], r.n1, u->ss, nullptr, nullptr, u->H1S[level], 2 * C, nseq, level, s)) return -1;
+    if (conv_rows(u, r.c2, r.c2.ws, u->H1S[level], 2 * C, rows, level, 5, 2, 1, 0, 0, u->F2[level], nullptr, 0, nullptr, s)) return -1;
+    if (!r.res.ws) {   // identity residual, added behind the Mish
+        return group_norm(u, u->F2[level], r.n2, nullptr, xf, out_f, out_s, out_ld, nseq, level, s);
+    }
+    if (group_norm(u, u->F2[level], r.n2, nullptr, nullptr, u->F1[level], nullptr, 0, nseq, level, s)) return -1;
+    return conv_rows(u, r.res, r.res.ws, xs, a_ld, rows, level, 1, 0, 1, 0, 0, out_f, out_s, out_ld, u->F1[level], s);
+}
+
+}  // namespace
+
+// x, obs [B, J, T] fp32, mask u8 (obs / mask may be null when added == 0), emb [nseq, dim] fp32 (time embedding +
+// text term per sequence), out [nseq, J, T].  nseq = B or 2B (CFG: [cond | uncond], same input rows).
+int unet_forward(UnetModel* u, const float* x, const float* obs, const uint8_t* mask, const float* emb, int B, int nseq,
+                 int T, float* out, hipStream_t s) {
+    if (!u->finalized) { u->err = "UNET weights not finalized"; return -1; }
+    if (nseq > u->max_seq || T > TPAD || T < 1) { u->err = "batch / frames exceed the UNET workspace"; return -1; }
+    if (u->added && (!obs || !mask)) { u->err = "a keyframe-conditioned UNET needs obs_x0 and obs_mask"; return -1; }
+    const int Cw = u->C[1], dim = u->dim;
+    {   // c = time_mlp(emb), cm = Mish(c)
+        GemmParams p{};
+        p.A = emb; p.W = u->t1w; p.bias = u->t1b; p.C = u->emb_h;
+        p.M = nseq; p.N = 4 * dim; p.K = dim; p.lda = dim; p.ldw = dim; p.ldc = 4 * dim; p.out_scale = 1.f;
+        UCHK(launch_gemm(GK_PLAIN, p, 4, s));
+        const int64_t n1 = (int64_t)nseq * 4 * dim;
+        hipLaunchKernelGGL(mish_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, u->emb_h, u->emb_h, n1);
+        GemmParams q{};
+        q.A = u->emb_h; q.W = u->t2w; q.bias = u->t2b; q.C = u->cvec;
+        q.M = nseq; q.N = dim; q.K = 4 * dim; q.lda = 4 * dim; q.ldw = 4 * dim; q.ldc = dim; q.out_scale = 1.f;
+        UCHK(launch_gemm(GK_PLAIN, q, 4, s));
+        const int64_t n2 = (int64_t)nseq * dim;
+        hipLaunchKernelGGL(mish_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, u->cvec, u->cm, n2);
+    }
+    hipLaunchKernelGGL(unet_input_kernel, dim3(TPAD / 4, nseq), dim3(256), 0, s, x, obs, mask, u->in0S, B, u->J, T,
+                       u->Cin0p, 256, 16, u->added ? 1 : 0);
+    UCHK(hipGetLastError());
+
+    // ---- down path: the second block of each level is the skip (h.append(x)) and feeds the downsample ----
+    const _Float16* xs = u->in0S;
+    int xs_ld = 2 * u->Cin0p;
+    const float* xf = nullptr;
+    for (int l = 0; l < 4; ++l) {
+        if (res_block(u, u->down[l][0], xs, xs_ld, xf, nseq, l, u->Xa[l], u->Sa[l], 2 * Cw, s)) return -1;
+        // skip of level l >= 1 goes straight into the right half of that level's concat buffer
+        _Float16* skip = l == 0 ? u->S0skip : u->CAT[l] + 2 * Cw;
+        const int skip_ld = l == 0 ? 2 * Cw : 4 * Cw;
+        if (res_block(u, u->down[l][1], u->Sa[l], 2 * Cw, u->Xa[l], nseq, l, l == 3 ? u->Xb[3] : nullptr, skip, skip_ld, s))
+            return -1;
+        if (l < 3) {   // Downsample1d: Conv1d(dim, dim, 3, 2, 1)
+            const int rows_out = nseq * lvl(l + 1).Tp;
+            if (conv_rows(u, u->downs[l], u->downs[l].ws, skip, skip_ld, rows_out, l + 1, 3, 1, 2, 0, 0, u->Xb[l + 1],
+                          u->Sb[l + 1], 2 * Cw, nullptr, s)) return -1;
+            xs = u->Sb[l + 1]; xs_ld = 2 * Cw; xf = u->Xb[l + 1];
+        }
+    }
+    // ---- middle -------------------------------------------------------------------------------------------
+    if (res_block(u, u->mid[0], u->CAT[3] + 2 * Cw, 4 * Cw, u->Xb[3], nseq, 3, u->Xa[3], u->Sa[3], 2 * Cw, s)) return -1;
+    if (res_block(u, u->mid[1], u->Sa[3], 2 * Cw, u->Xa[3], nseq, 3, nullptr, u->CAT[3], 4 * Cw, s)) return -1;
+    // ---- up path: cat(x, skip) is the [left | right] halves of CAT[l] --------------------------------------
+    for (int i = 0; i < 3; ++i) {
+        const int l = 3 - i;
+        if (res_block(u, u->up[i][0], u->CAT[l], 4 * Cw, nullptr, nseq, l, u->Xa[l], u->Sa[l], 2 * Cw, s)) return -1;
+        if (res_block(u, u->up[i][1], u->Sa[l], 2 * Cw, u->Xa[l], nseq, l, nullptr, u->Sb[l], 2 * Cw, s)) return -1;
+        // Upsample1d: ConvTranspose1d(dim, dim, 4, 2, 1): even rows taps (x[j-1] W3, x[j] W1), odd (x[j] W2, x[j+1] W0)
+        _Float16* dst = l - 1 >= 1 ? u->CAT[l - 1] : u->Sa[0];
+        const int dst_ld = l - 1 >= 1 ? 4 * Cw : 2 * Cw;
+        const int rows_in = nseq * lvl(l).Tp;
+        if (conv_rows(u, u->ups[i], u->ups[i].ws, u->Sb[l], 2 * Cw, rows_in, l - 1, 2, 1, 1, 2, 0, nullptr, dst, dst_ld, nullptr, s)) return -1;
+        if (conv_rows(u, u->ups[i], u->ups[i].ws2, u->Sb[l], 2 * Cw, rows_in, l - 1, 2, 0, 1, 2, 1, nullptr, dst, dst_ld, nullptr, s)) return -1;
+    }
+    // ---- final_conv: Conv1dBlock(k=5) then Conv1d(dim, J, 1) -------------------------------------------------
+    const int rows0 = nseq * 256;
+    if (conv_rows(u, u->fin, u->fin.ws, u->Sa[0], 2 * Cw, rows0, 0, 5, 2, 1, 0, 0, u->F1[0], nullptr, 0, nullptr, s)) return -1;
+    if (group_norm(u, u->F1[0], u->fin_n, nullptr, nullptr, nullptr, u->H1S[0], 2 * Cw, nseq, 0, s)) return -1;
+    if (conv_rows(u, u->outc, u->outc.ws, u->H1S[0], 2 * Cw, rows0, 0, 1, 0, 1, 0, 0, u->outF, nullptr, 0, nullptr, s)) return -1;
+    hipLaunchKernelGGL(unet_output_kernel, dim3((T + 255) / 256, u->J, nseq), dim3(256), 0, s, u->outF, out, u->J, T, u->Np,
+                       256, 16);
+    UCHK(hipGetLastError());
+    return 0;
+}
+
+int unet_range_flag(UnetModel* u, int* flag, hipStream_t s) {
+    *flag = 0;
+    if (hipMemcpyAsync(flag, u->range_flag, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return -1;
+    if (hipStreamSynchronize(s) != hipSuccess) return -1;
+    if (*flag) (void)hipMemsetAsync(u->range_flag, 0, sizeof(int), s);
+    return 0;
+}
+
+hipError_t launch_unet_emb(float* emb, const float* time_table, const float* text_term, const int64_t* t_dev,
+                           int64_t t_scalar, int n_seq, int n_per_pass, int d, int n_time_rows, hipStream_t stream) {
+    hipLaunchKernelGGL(unet_emb_kernel, dim3(n_seq), dim3(256), 0, stream, emb, time_table, text_term, t_dev, t_scalar,
+                       n_per_pass, d, n_time_rows);
+    return hipGetLastError();
+}
+
+}  // namespace cmdi

@@ -104,11 +104,23 @@ def _unwrap_model(model):
     """(mdm, cfg_wrapper_or_None) if `model` is the native denoiser, else (None, None)."""
     from ..model.cfg_sampler import ClassifierFreeSampleModel
     from ..model.mdm import MDM
-    if isinstance(model, ClassifierFreeSampleModel) and isinstance(model.model, MDM):
+    from ..model.mdm_unet import MDM_UNET
+    native = (MDM, MDM_UNET)
+    if isinstance(model, ClassifierFreeSampleModel) and isinstance(model.model, native):
         return model.model, model
-    if isinstance(model, MDM):
+    if isinstance(model, native):
         return model, None
     return None, None
+
+
+def _add_observations(cond, mdm, model_kwargs, B, n_feats, T):
+    """MDM_UNET with keyframe conditioning consumes model_kwargs['obs_x0'] / ['obs_mask'], which
+    sample/conditional_synthesis.py:159-162 passes next to 'y' (reference mdm_unet.py:766-782)."""
+    if mdm is not None and getattr(mdm, 'arch', '') == 'unet' and getattr(mdm, 'keyframe_conditioned', False):
+        if 'obs_x0' not in model_kwargs or 'obs_mask' not in model_kwargs:
+            raise KeyError("a keyframe-conditioned MDM_UNET needs model_kwargs['obs_x0'] and ['obs_mask']")
+        cond['obs_x0'] = model_kwargs['obs_x0'].reshape(B, n_feats, 1, T)
+        cond['obs_mask'] = model_kwargs['obs_mask'].reshape(B, n_feats, 1, T)
 
 
 class GaussianDiffusion:
@@ -260,6 +272,7 @@ class GaussianDiffusion:
         use_recon = bool(y.get('reconstruction_guidance', False))
         eng = self._engine_for(model, device, B, J * F, T, want_grad=use_recon and mdm is not None)
         cond = self._condition_from_kwargs(y, mdm, cfg, B, J * F, T, device)
+        _add_observations(cond, mdm, model_kwargs, B, J * F, T)
         eng.set_condition(**cond)
 
         seed = _fresh_seed()
@@ -444,7 +457,9 @@ class GaussianDiffusion:
         mdm, cfg = _unwrap_model(model)
         use_recon = bool(y.get('reconstruction_guidance', False))
         eng = self._engine_for(model, x.device, B, J * F, T, want_grad=use_recon and mdm is not None)
-        eng.set_condition(**self._condition_from_kwargs(y, mdm, cfg, B, J * F, T, x.device))
+        cond = self._condition_from_kwargs(y, mdm, cfg, B, J * F, T, x.device)
+        _add_observations(cond, mdm, model_kwargs, B, J * F, T)
+        eng.set_condition(**cond)
         out = x.detach().float().contiguous().clone()
         pred = torch.empty_like(out)
         sid = N.CMDI_SAMPLER_DDIM if sampler == "ddim" else N.CMDI_SAMPLER_DDPM

@@ -32,7 +32,8 @@ class Engine:
 
     def __init__(self, *, n_layers: int, d_model: int, d_ff: int, n_heads: int, n_feats: int,
                  max_frames: int, max_batch: int, pe_rows: int = 5000, text_cond: bool = False,
-                 want_grad: bool = False, precision: Optional[str] = None, device="cuda"):
+                 want_grad: bool = False, precision: Optional[str] = None, arch: str = "trans_enc",
+                 unet_added: int = 0, unet_mults=(2, 2, 2, 2), device="cuda"):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise N.NativeError(
@@ -42,7 +43,10 @@ class Engine:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.lib = N.load()
         self.desc = N.ModelDesc(n_layers, d_model, d_ff, n_heads, n_feats, max_frames, max_batch,
-                                pe_rows, int(text_cond), int(want_grad), N.PRECISIONS[precision])
+                                pe_rows, int(text_cond), int(want_grad), N.PRECISIONS[precision],
+                                N.CMDI_ARCH_UNET if arch == "unet" else N.CMDI_ARCH_TRANS_ENC, int(unet_added),
+                                (C.c_int32 * 4)(*[int(m) for m in unet_mults]))
+        self.arch = arch
         self.n_feats, self.max_frames, self.max_batch = n_feats, max_frames, max_batch
         self.want_grad = bool(want_grad)
         self.text_cond = bool(text_cond)
@@ -51,7 +55,7 @@ class Engine:
             N.check(self.lib.cmdi_create(C.byref(self.desc), C.byref(self._h)))
         # "f32" (exact fp32 MFMA) or "f16x3" (fp32-equivalent split-f16 MFMA); None = library default
         self.precision = {N.CMDI_PREC_F32: "f32", N.CMDI_PREC_F16X3: "f16x3"}.get(
-            self.lib.cmdi_precision(self._h), "f32") if n_layers > 0 else "f32"
+            self.lib.cmdi_precision(self._h), "f32") if (n_layers > 0 or arch == "unet") else "f32"
         self.n_steps = 0
         self.batch = 0
         self.n_frames = 0
@@ -151,7 +155,8 @@ class Engine:
                       inpaint_motion: Optional[torch.Tensor] = None,
                       imputate: bool = False, stop_imputation_at: int = 0,
                       recon_guidance: bool = False, stop_recguidance_at: int = 0,
-                      recon_w: Optional[np.ndarray] = None):
+                      recon_w: Optional[np.ndarray] = None,
+                      obs_x0: Optional[torch.Tensor] = None, obs_mask: Optional[torch.Tensor] = None):
         dev = self.device
         keep = []
         if enc_text is not None:
@@ -170,6 +175,14 @@ class Engine:
             inpaint_motion = _require_device_f32(inpaint_motion, "inpaint_motion", dev)
             assert inpaint_motion.numel() == batch * self.n_feats * n_frames
             keep.append(inpaint_motion)
+        if obs_x0 is not None:
+            obs_x0 = _require_device_f32(obs_x0, "obs_x0", dev)
+            assert obs_x0.numel() == batch * self.n_feats * n_frames, obs_x0.shape
+            keep.append(obs_x0)
+        if obs_mask is not None:
+            obs_mask = obs_mask.to(dev).to(torch.uint8).contiguous()
+            assert obs_mask.numel() == batch * self.n_feats * n_frames, obs_mask.shape
+            keep.append(obs_mask)
         rw = None
         if recon_w is not None:
             rw = np.ascontiguousarray(recon_w, dtype=np.float32)
@@ -177,7 +190,7 @@ class Engine:
         cond = N.Condition(batch, n_frames, int(cfg), N.ptr(enc_text), N.ptr(text_scale),
                            N.ptr(inpaint_mask), N.ptr(inpaint_motion), int(imputate),
                            int(stop_imputation_at), int(recon_guidance), int(stop_recguidance_at),
-                           _as_f32_ptr(rw) if rw is not None else None)
+                           _as_f32_ptr(rw) if rw is not None else None, N.ptr(obs_x0), N.ptr(obs_mask))
         with torch.cuda.device(dev):
             N.check(self.lib.cmdi_set_condition(self._h, C.byref(cond), self.stream))
         self.batch, self.n_frames, self.cfg = batch, n_frames, bool(cfg)

@@ -27,4 +27,6 @@ class ClassifierFreeSampleModel(nn.Module):
 
     def forward(self, x, timesteps, y=None, obs_x0=None, obs_mask=None, **kwargs):
         assert self.model.cond_mode in ['text', 'action']
+        if getattr(self.model, 'arch', '') == 'unet':   # MDM_UNET consumes the keyframe observations
+            return self.model._forward_native(x, timesteps, y, cfg=True, obs_x0=obs_x0, obs_mask=obs_mask)
         return self.model._forward_native(x, timesteps, y, cfg=True)

@@ -1,0 +1,208 @@
+"""MDM_UNET denoiser ("Diffuser-style" temporal U-Net), MI355X-native.
+
+Mirror of the reference's ``model/mdm_unet.py`` for the configuration CondMDI trains and releases
+(``configs/model.py:27-36,65-67``: arch='unet', latent_dim 512, unet_adagn, unet_zero, dim_mults with equal
+entries, e.g. (2, 2, 2, 2); hml_vec data; optional keyframe conditioning that concatenates the keyframe mask).
+The module holds parameters under the reference's state-dict names and shapes, so checkpoints load unchanged,
+but ``forward`` does no torch arithmetic: the whole network (reference :766-849, TemporalUnet :214-358) runs as
+hand-written gfx950 kernels (csrc/unet.hip: every 1-D convolution is a split-f16 GEMM over tap-shifted rows).
+
+Not provided (reference-only): attention=True, adagn=False, 'unet_large', xz_only / traj models,
+train_keypoint_mask variants, action conditioning, reconstruction guidance through the U-Net (needs its VJP).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import _native as N
+from .mdm import MDM, PositionalEncoding, TimestepEmbedder
+from .rotation2xyz import Rotation2xyz
+
+
+def _conv_gn(cin, cout, k, with_mish):
+    mods = [nn.Conv1d(cin, cout, k, padding=k // 2), nn.Identity(), nn.GroupNorm(8, cout), nn.Identity()]
+    if with_mish:
+        mods.append(nn.Mish())
+    return nn.Sequential(*mods)
+
+
+class _Conv1dAdaGNBlock(nn.Module):   # reference :70-101 (parameter holder)
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.block1 = _conv_gn(cin, cout, k, with_mish=False)
+        self.block2 = nn.Mish()
+
+
+class _Conv1dBlock(nn.Module):        # reference :34-67
+    def __init__(self, cin, cout, k, zero=False):
+        super().__init__()
+        self.block = _conv_gn(cin, cout, k, with_mish=True)
+        if zero:
+            nn.init.zeros_(self.block[0].weight)
+            nn.init.zeros_(self.block[0].bias)
+
+
+class _ResidualTemporalBlock(nn.Module):   # reference :163-212
+    def __init__(self, cin, cout, embed_dim, zero):
+        super().__init__()
+        self.blocks = nn.ModuleList([_Conv1dAdaGNBlock(cin, cout, 5), _Conv1dBlock(cout, cout, 5, zero=zero)])
+        self.time_mlp = nn.Sequential(nn.Mish(), nn.Linear(embed_dim, cout * 2), nn.Identity())
+        nn.init.zeros_(self.time_mlp[1].weight)
+        nn.init.zeros_(self.time_mlp[1].bias)
+        self.residual_conv = nn.Conv1d(cin, cout, 1) if cin != cout else nn.Identity()
+
+
+class _Down(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.conv = nn.Conv1d(dim, dim, 3, 2, 1)
+
+
+class _Up(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.conv = nn.ConvTranspose1d(dim, dim, 4, 2, 1)
+
+
+class TemporalUnet(nn.Module):   # reference :214-358 (parameter holder; the arithmetic lives in csrc/unet.hip)
+    def __init__(self, input_dim, cond_dim, dim, dim_mults, zero, added_input_channels):
+        super().__init__()
+        dims = [input_dim, *[int(dim * m) for m in dim_mults]]
+        in_out = list(zip(dims[:-1], dims[1:]))
+        self.time_mlp = nn.Sequential(nn.Linear(cond_dim, dim * 4), nn.Mish(), nn.Linear(dim * 4, dim))
+        self.downs, self.ups = nn.ModuleList([]), nn.ModuleList([])
+        n_res = len(in_out)
+        for ind, (din, dout) in enumerate(in_out):
+            last = ind >= n_res - 1
+            self.downs.append(nn.ModuleList([
+                _ResidualTemporalBlock(din + added_input_channels * (ind == 0), dout, dim, zero),
+                _ResidualTemporalBlock(dout, dout, dim, zero), nn.Identity(),
+                _Down(dout) if not last else nn.Identity()]))
+        mid = dims[-1]
+        self.mid_block1 = _ResidualTemporalBlock(mid, mid, dim, zero)
+        self.mid_attn = nn.Identity()
+        self.mid_block2 = _ResidualTemporalBlock(mid, mid, dim, zero)
+        for ind, (din, dout) in enumerate(reversed(in_out[1:])):
+            self.ups.append(nn.ModuleList([
+                _ResidualTemporalBlock(dout * 2, din, dim, zero), _ResidualTemporalBlock(din, din, dim, zero),
+                nn.Identity(), _Up(din)]))
+        self.final_conv = nn.Sequential(_Conv1dBlock(din, din, 5), nn.Conv1d(din, input_dim, 1))
+        if zero:
+            nn.init.zeros_(self.final_conv[1].weight)
+            nn.init.zeros_(self.final_conv[1].bias)
+
+
+class MDM_UNET(nn.Module):
+    def __init__(self, modeltype='', njoints=263, nfeats=1, num_actions=1, translation=True, pose_rep='rot6d',
+                 glob=True, glob_rot=True, latent_dim=512, dim_mults=(2, 2, 2, 2), attention=False, ablation=None,
+                 legacy=False, data_rep='hml_vec', dataset='humanml', clip_dim=512, emb_trans_dec=False,
+                 clip_version=None, adagn=True, zero=True, arch='unet', unet_out_mult=8, xz_only=False,
+                 train_keypoint_mask='none', keyframe_conditioned=False, keyframe_selection_scheme='in-between',
+                 zero_keyframe_loss=False, **kwargs):
+        super().__init__()
+        if arch != 'unet' or attention or not adagn or xz_only or train_keypoint_mask != 'none':
+            raise ValueError("the MI355X engine implements arch='unet' with adagn=True, attention=False, "
+                             "xz_only=False, train_keypoint_mask='none' (the CondMDI configuration)")
+        if latent_dim != 512 or len(dim_mults) != 4 or len(set(dim_mults)) != 1 or int(latent_dim * dim_mults[0]) % 256:
+            raise ValueError("the MI355X engine needs latent_dim=512 and four equal dim_mults (e.g. (2, 2, 2, 2))")
+        if dataset != 'humanml' or data_rep != 'hml_vec':
+            raise ValueError("only the humanml / hml_vec data representation is implemented")
+        self.legacy, self.modeltype = legacy, modeltype
+        self.njoints, self.nfeats, self.num_actions = njoints, nfeats, num_actions
+        self.data_rep, self.dataset = data_rep, dataset
+        self.pose_rep, self.glob, self.glob_rot, self.translation = pose_rep, glob, glob_rot, translation
+        self.latent_dim, self.dim_mults, self.attention = latent_dim, tuple(dim_mults), attention
+        self.ablation, self.clip_dim = ablation, clip_dim
+        self.keyframe_conditioned = keyframe_conditioned
+        self.zero_keyframe_loss = zero_keyframe_loss
+        self.train_keypoint_mask, self.xz_only = train_keypoint_mask, xz_only
+        self.input_feats = njoints * nfeats
+        self.cond_mode = kwargs.get('cond_mode', 'no_cond')
+        self.cond_mask_prob = kwargs.get('cond_mask_prob', 0.)
+        self.arch = arch
+        if 'action' in self.cond_mode:
+            raise ValueError("action conditioning is reference-only")
+        added = self.input_feats if keyframe_conditioned else 0
+        self.added_channels = added
+        self.sequence_pos_encoder = PositionalEncoding(latent_dim, dropout=0)
+        self.unet = TemporalUnet(self.input_feats, latent_dim, latent_dim, self.dim_mults, zero, added)
+        self.embed_timestep = TimestepEmbedder(latent_dim, self.sequence_pos_encoder)
+        self.clip_version = clip_version
+        self.clip_model = None
+        if 'text' in self.cond_mode:
+            self.embed_text = nn.Linear(clip_dim, latent_dim)
+            self.clip_model = self.load_and_freeze_clip(clip_version)
+        self.rot2xyz = Rotation2xyz(device='cpu', dataset=dataset)
+        self._engine = None
+        self._engine_key = None
+
+    # shared with the transformer denoiser (same semantics in the reference: mdm_unet.py:706-764)
+    parameters_wo_clip = MDM.parameters_wo_clip
+    load_and_freeze_clip = MDM.load_and_freeze_clip
+    mask_cond = MDM.mask_cond
+    encode_text = MDM.encode_text
+    text_embedding = MDM.text_embedding
+    _weights_key = MDM._weights_key
+    invalidate_engine = MDM.invalidate_engine
+
+    def engine(self, device, max_batch, max_frames, want_grad=False, n_time_rows=1000):
+        """The native engine holding this module's weights on `device` (built / grown lazily)."""
+        from ..engine import Engine
+        if want_grad:
+            raise NotImplementedError("reconstruction guidance through the UNET needs its VJP (not built yet); "
+                                      "keyframes reach this denoiser through obs_x0 / obs_mask and imputation")
+        device = torch.device(device)
+        if device.type == 'cuda' and device.index is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        pe_rows = self.sequence_pos_encoder.pe.shape[0]
+        n_time_rows = min(int(n_time_rows), pe_rows)
+        eng = self._engine
+        need_new = (eng is None or eng.device != device or eng.max_batch < max_batch or eng.max_frames < max_frames
+                    or self._engine_key != self._weights_key(n_time_rows))
+        if need_new:
+            if eng is not None:
+                max_batch, max_frames = max(max_batch, eng.max_batch), max(max_frames, eng.max_frames)
+                eng.close()
+            eng = Engine(n_layers=0, d_model=self.latent_dim, d_ff=0, n_heads=0, n_feats=self.input_feats,
+                         max_frames=max_frames, max_batch=max_batch, pe_rows=pe_rows,
+                         text_cond='text' in self.cond_mode, arch="unet", unet_added=self.added_channels,
+                         unet_mults=self.dim_mults, device=device)
+            sd = {k: v for k, v in self.state_dict().items() if not k.startswith('clip_model.')}
+            eng.load_state_dict(sd, n_time_rows=n_time_rows)
+            self._engine = eng
+            self._engine_key = self._weights_key(n_time_rows)
+        return eng
+
+    def _forward_native(self, x, timesteps, y, cfg, obs_x0=None, obs_mask=None):
+        if y is None:
+            raise TypeError("MDM_UNET.forward needs y (a dict), as in the reference (mdm_unet.py:794)")
+        if self.training:
+            raise NotImplementedError("the native denoiser is inference-only: call model.eval()")
+        assert (obs_x0 is None) == (obs_mask is None), \
+            'with spatial-conditioning, both obs_x0 and obs_mask must be provided'
+        device = next(self.parameters()).device
+        if device.type != 'cuda':
+            raise N.NativeError("MDM_UNET runs on a HIP device only (no CPU path): call model.to('cuda')")
+        B, J, F, T = x.shape
+        assert J * F == self.input_feats
+        eng = self.engine(device, max_batch=B, max_frames=T, n_time_rows=self.sequence_pos_encoder.pe.shape[0])
+        cond = dict(batch=B, n_frames=T, cfg=cfg)
+        if 'text' in self.cond_mode and not y.get('uncond', False):
+            cond['enc_text'] = self.text_embedding(y, B, device)
+        if cfg:
+            cond['text_scale'] = torch.as_tensor(y['text_scale'], dtype=torch.float32).reshape(-1)
+        if self.keyframe_conditioned:
+            cond['obs_x0'], cond['obs_mask'] = obs_x0, obs_mask
+        eng.set_condition(**cond)
+        xin = x.detach().to(device=device, dtype=torch.float32).contiguous()
+        return eng.mdm_forward(xin, timesteps.to(device))
+
+    def forward(self, x, timesteps, y=None, obs_x0=None, obs_mask=None, **kwargs):
+        """x [B, njoints, nfeats, T], timesteps [B] (ORIGINAL scale), obs_x0 / obs_mask [B, njoints, nfeats, T]
+        (used iff keyframe_conditioned) -> [B, njoints, nfeats, T]   (reference :766-849)."""
+        return self._forward_native(x, timesteps, y, cfg=False, obs_x0=obs_x0, obs_mask=obs_mask)
+
+    def train(self, mode=True):
+        super().train(mode)
+        return self

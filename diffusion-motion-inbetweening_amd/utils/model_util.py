@@ -11,6 +11,7 @@ import torch
 from ..diffusion import gaussian_diffusion as gd
 from ..diffusion.respace import DiffusionConfig, SpacedDiffusion, space_timesteps
 from ..model.mdm import MDM
+from ..model.mdm_unet import MDM_UNET
 
 
 def load_model_wo_clip(model, state_dict):
@@ -21,11 +22,14 @@ def load_model_wo_clip(model, state_dict):
 
 def create_model_and_diffusion(args, data=None):
     arch = getattr(args, 'arch', 'trans_enc')
-    if arch.startswith('dit') or arch.startswith('unet'):
+    if arch.startswith('dit') or arch == 'unet_large':
         raise NotImplementedError(
-            f"arch={arch!r}: MDM_DiT / MDM_UNET are outside the MI355X hot path (SURVEY.md §8f); "
+            f"arch={arch!r}: MDM_DiT / TemporalUnetLarge are outside the MI355X hot path (SURVEY.md §8f); "
             "any torch denoiser can still be sampled through diffusion.p_sample_loop")
-    model = MDM(**get_model_args(args, data))
+    if arch == 'unet':   # reference utils/model_util.py:31-33
+        model = MDM_UNET(**get_model_args(args, data))
+    else:
+        model = MDM(**get_model_args(args, data))
     diffusion = create_gaussian_diffusion(args)
     return model, diffusion
 
@@ -63,6 +67,9 @@ def get_model_args(args, data=None):
         'emb_trans_dec': getattr(args, 'emb_trans_dec', False),
         'clip_version': 'ViT-B/32', 'dataset': dataset,
         'keyframe_conditioned': getattr(args, 'keyframe_conditioned', False),
+        # UNET-only (reference utils/model_util.py:96-117)
+        'dim_mults': tuple(getattr(args, 'dim_mults', (2, 2, 2, 2))), 'adagn': getattr(args, 'unet_adagn', True),
+        'zero': getattr(args, 'unet_zero', True), 'xz_only': getattr(args, 'xz_only', False),
     }
 
 

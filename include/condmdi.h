@@ -47,6 +47,7 @@ enum {
  *                    (checked: CMDI_E_RANGE at cmdi_finalize_weights, cmdi_range_status after a run).
  *   CMDI_PREC_DEFAULT  F16X3 unless the environment variable CMDI_PRECISION=f32 is set. */
 enum { CMDI_PREC_DEFAULT = 0, CMDI_PREC_F32 = 1, CMDI_PREC_F16X3 = 2 };
+enum { CMDI_ARCH_TRANS_ENC = 0, CMDI_ARCH_UNET = 1 };
 
 /* Model geometry.  Replaces the keyword arguments of MDM.__init__ (model/mdm.py:11-36) that the
  * trans_enc / hml_vec path reads, as produced by get_model_args (utils/model_util.py:40-119). */
@@ -62,6 +63,10 @@ typedef struct {
     int32_t text_cond;   /* 1 if cond_mode contains 'text' (embed_text exists) */
     int32_t want_grad;   /* 1: allocate the activation stash for cmdi_mdm_vjp  */
     int32_t precision;   /* CMDI_PREC_*                                        */
+    int32_t arch;        /* CMDI_ARCH_TRANS_ENC (MDM, model/mdm.py) or CMDI_ARCH_UNET (MDM_UNET, model/mdm_unet.py:561-849;
+                            n_layers / d_ff / n_heads unused, d_model = latent_dim = 512)                        */
+    int32_t unet_added;  /* UNET: extra input channels = n_feats if keyframe_conditioned (cat(x, obs_mask)) else 0 */
+    int32_t unet_mults[4]; /* UNET: dim_mults (channels = d_model * mult; the built configuration has equal mults) */
 } cmdi_model_desc;
 
 /* Model-output → x0 conventions (diffusion/gaussian_diffusion.py:74-95). */
@@ -129,6 +134,8 @@ typedef struct {
     int32_t recon_guidance;          /* y['reconstruction_guidance']                           */
     int32_t stop_recguidance_at;     /* y['stop_recguidance_at']                               */
     const float* recon_w;            /* HOST [n_steps]: grad_ws[i]*reconstruction_weight, or NULL */
+    const float* d_obs_x0;           /* UNET: model_kwargs['obs_x0'] [B,J,1,T] or NULL (mdm_unet.py:766-782)  */
+    const uint8_t* d_obs_mask;       /* UNET: model_kwargs['obs_mask'] [B,J,1,T] (0/1) or NULL                */
 } cmdi_condition;
 int cmdi_set_condition(cmdi_handle h, const cmdi_condition* c, cmdi_stream stream);
 

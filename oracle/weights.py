@@ -59,3 +59,25 @@ def make_state_dict(seed: int = 0, *, n_layers: int = 8, d: int = 512, f: int = 
 def to_torch(sd: dict):
     import torch
     return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
+
+
+def fill_like(shapes: dict, seed: int = 0) -> dict:
+    """Deterministic synthetic values for ANY state dict given as {name: shape} (used for MDM_UNET, whose
+    reference initialisation zeroes half of its convolutions — useless for parity tests): names are visited
+    in sorted order; '*.weight' of rank >= 2 ~ U(-1/sqrt(fan_in), 1/sqrt(fan_in)), rank-1 '*.weight'
+    (GroupNorm) ~ 1 + 0.1 N(0,1), biases ~ 0.1 N(0,1); positional tables ('*.pe') are not produced."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for name in sorted(shapes):
+        shape = tuple(shapes[name])
+        if name.endswith(".pe"):
+            continue
+        if name.endswith(".weight") and len(shape) >= 2:
+            fan_in = int(np.prod(shape[1:]))
+            k = 1.0 / np.sqrt(fan_in)
+            out[name] = rng.uniform(-k, k, size=shape).astype(np.float32)
+        elif name.endswith(".weight"):
+            out[name] = (1.0 + 0.1 * rng.standard_normal(shape)).astype(np.float32)
+        else:
+            out[name] = (0.1 * rng.standard_normal(shape)).astype(np.float32)
+    return out

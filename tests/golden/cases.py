@@ -102,3 +102,18 @@ def make_post_inputs(case: dict = POST_CASE) -> dict:
     return {"sample": f32(rng.standard_normal((case["B"], N_FEATS, 1, case["T"]))),
             "mean": f32(0.3 * rng.standard_normal(N_FEATS)),
             "std": f32(0.05 + rng.random(N_FEATS))}
+
+
+# ---- MDM_UNET denoiser -------------------------------------------------------------
+UNET_CASE = dict(B=2, T=196, t=[500, 3], seed=301, weight_seed=31, dim_mults=(1, 1, 1, 1),
+                 text_scale=[2.5, 0.0], mask_prob=0.1)
+
+
+def make_unet_inputs(case: dict = UNET_CASE) -> dict:
+    rng = np.random.default_rng(case["seed"])
+    B, T = case["B"], case["T"]
+    shape = (B, N_FEATS, 1, T)
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    return {"x": f32(rng.standard_normal(shape)), "t": np.asarray(case["t"], dtype=np.int64),
+            "obs_x0": f32(rng.standard_normal(shape)), "obs_mask": rng.random(shape) < case["mask_prob"],
+            "enc_text": f32(rng.standard_normal((B, 512))), "text_scale": f32(case["text_scale"])}

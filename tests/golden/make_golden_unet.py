@@ -1,0 +1,48 @@
+"""Golden vectors of the MDM_UNET denoiser, produced by the REAL reference on CPU (model/mdm_unet.py:561-849,
+TemporalUnet :214-358, through model/cfg_sampler.py for the guided output).   python tests/golden/make_golden_unet.py
+Weights: oracle.weights.fill_like over the reference module's own state-dict shapes (the tests rebuild the same
+values from the shapes of OUR module and assert that names and shapes coincide)."""
+import sys
+from pathlib import Path
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+REPO = HERE.parent.parent
+sys.path.insert(0, str(REPO))
+sys.path.insert(0, str(HERE))
+import cases  # noqa: E402
+from oracle import ref_shims, weights  # noqa: E402
+
+ref = ref_shims.import_reference()
+import model.mdm as ref_mdm  # noqa: E402
+import model.mdm_unet as ref_unet  # noqa: E402
+ref_unet.Rotation2xyz = ref_mdm.Rotation2xyz   # identity shim (SMPL files absent)
+
+case = cases.UNET_CASE
+inp = cases.make_unet_inputs()
+args = ref_shims.default_args(arch='unet', keyframe_conditioned=True, abs_3d=True, latent_dim=512,
+                              dim_mults=case["dim_mults"], cond_mask_prob=0.1)
+model, _ = ref.model_util.create_model_and_diffusion(args, SimpleNamespace(dataset=SimpleNamespace()))
+shapes = {k: tuple(v.shape) for k, v in model.state_dict().items() if not k.startswith("clip_model.")}
+sd = weights.fill_like(shapes, case["weight_seed"])
+missing, unexpected = model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+assert not unexpected and all(k.startswith("clip_model.") or k.endswith(".pe") for k in missing), (missing, unexpected)
+model.eval()
+
+t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+x, ts = t(inp["x"]), t(inp["t"])
+obs, m = t(inp["obs_x0"]), t(inp["obs_mask"])
+ref_shims.set_text_embedding(t(inp["enc_text"]))
+y = {"text": ["a"] * case["B"], "mask": torch.ones(case["B"], 1, 1, case["T"], dtype=torch.bool)}
+with torch.no_grad():
+    oc = model(x, ts, y=dict(y), obs_x0=obs, obs_mask=m)
+    ou = model(x, ts, y=dict(y, uncond=True), obs_x0=obs, obs_mask=m)
+    wrapped = ref.cfg.ClassifierFreeSampleModel(model)
+    cfg = wrapped(x, ts, y=dict(y, text_scale=t(inp["text_scale"])), obs_x0=obs, obs_mask=m)
+out = {"out_cond": oc.numpy(), "out_uncond": ou.numpy(), "out_cfg": cfg.numpy(), "fingerprint": cases.fingerprint(inp),
+       "names": np.asarray(sorted(shapes))}
+np.savez_compressed(HERE / "unet_fwd.npz", **out)
+print({k: getattr(v, "shape", None) for k, v in out.items()}, float(np.abs(out["out_cond"]).mean()))

@@ -466,3 +466,36 @@ def test_conv_rows_h3_vs_torch(kind):
     got = got[:, h_out:h_out + T_out].permute(0, 2, 1)
     want = ref + bias.double()[None, :, None]
     assert rel_l2(got.numpy(), want.numpy()) <= 2e-6, rel_l2(got.numpy(), want.numpy())
+
+
+# ---- MDM_UNET denoiser -------------------------------------------------------------
+def make_unet(cases):
+    mu = sub("utils.model_util")
+    case = cases.UNET_CASE
+    args = SimpleNamespace(dataset="humanml", arch="unet", keyframe_conditioned=True, dim_mults=case["dim_mults"],
+                           cond_mask_prob=0.1)
+    model, _ = mu.create_model_and_diffusion(args, None)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    g = load_golden("unet_fwd")
+    assert sorted(shapes) == list(g["names"]), "state-dict names differ from the reference's MDM_UNET"
+    mu.load_model_wo_clip(model, weights.to_torch(weights.fill_like(shapes, case["weight_seed"])) |
+                          {k: v for k, v in model.state_dict().items() if k.endswith(".pe")})
+    return model.to(DEV).eval(), g
+
+
+def test_unet_forward_vs_reference(cases):
+    """MDM_UNET (keyframe-conditioned, text, CFG) on the device vs the real reference's CPU outputs."""
+    inp = cases.make_unet_inputs()
+    model, g = make_unet(cases)
+    assert np.array_equal(g["fingerprint"], cases.fingerprint(inp))
+    x, t = tt(inp["x"]), tt(inp["t"])
+    kw = dict(obs_x0=tt(inp["obs_x0"]), obs_mask=tt(inp["obs_mask"]))
+    y = {"text_embed": tt(inp["enc_text"])}
+    oc = model(x, t, y=y, **kw).cpu().numpy()
+    ou = model(x, t, y=dict(y, uncond=True), **kw).cpu().numpy()
+    wrapped = sub("model.cfg_sampler").ClassifierFreeSampleModel(model)
+    cfg = wrapped(x, t, y=dict(y, text_scale=tt(inp["text_scale"])), **kw).cpu().numpy()
+    for mine, key in ((oc, "out_cond"), (ou, "out_uncond"), (cfg, "out_cfg")):
+        assert np.isfinite(mine).all()
+        assert max_abs(mine, g[key]) <= 2e-4 and rel_l2(mine, g[key]) <= 2e-5, \
+            (key, max_abs(mine, g[key]), rel_l2(mine, g[key]))

@@ -121,7 +121,14 @@ def test_model_factory_state_dict_names_match_reference():
     with pytest.raises(AssertionError):
         sub("model.cfg_sampler").ClassifierFreeSampleModel(SimpleNamespace(cond_mask_prob=0.0))
     with pytest.raises(NotImplementedError):
-        mu.create_model_and_diffusion(SimpleNamespace(dataset="humanml", arch="unet"), None)
+        mu.create_model_and_diffusion(SimpleNamespace(dataset="humanml", arch="unet_large"), None)
+    # the UNET denoiser: the reference's state-dict names (tests/golden/unet_fwd.npz holds them)
+    unet, _ = mu.create_model_and_diffusion(SimpleNamespace(dataset="humanml", arch="unet", keyframe_conditioned=True,
+                                                            dim_mults=(1, 1, 1, 1)), None)
+    assert type(unet).__name__ == "MDM_UNET" and unet.keyframe_conditioned
+    assert sorted(unet.state_dict()) == list(load_golden("unet_fwd")["names"])
+    with pytest.raises(ValueError):
+        mu.create_model_and_diffusion(SimpleNamespace(dataset="humanml", arch="unet", dim_mults=(1, 2, 4, 8)), None)
 
 
 def test_no_cpu_fallback():
