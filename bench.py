@@ -48,6 +48,10 @@ CONFIGS = {
                desc="benchmark_sparse imputation + reconstruction guidance, 1000-step DDPM, B=32/GPU, CFG"),
     "c4": dict(B=256, respacing="ddim100", sampler="ddim", cfg=True, edit=False,
                desc="DDIM-100 respaced, B=256/GPU, text CFG"),
+    # the denoiser CondMDI trains / releases (configs/model.py motion_unet_adagn_xl)
+    "unet": dict(B=32, respacing=[1000], sampler="ddpm", cfg=True, edit=False, unet=True,
+                 desc="MDM_UNET (dim_mults 2,2,2,2, keyframe-conditioned), HumanML3D 196x263, 1000-step DDPM, "
+                      "B=32/GPU, text CFG, sparse keyframes observed + imputed"),
 }
 
 
@@ -55,6 +59,37 @@ def flops_per_sample_eval(T=T_FRAMES, J=N_FEATS, d=512, f=1024, L=8):
     S = T + 1
     layer = 2 * S * d * 3 * d + 4 * S * S * d + 2 * S * d * d + 4 * S * d * f
     return 2 * T * J * d + L * layer + 2 * T * d * J + 4 * d * d + 2 * 512 * d
+
+
+def unet_flops_per_sample_eval(J=N_FEATS, dim=512, mult=2, keyframe=True):
+    """2*MACs of one MDM_UNET evaluation (reference model/mdm_unet.py TemporalUnet, 224 padded frames)."""
+    C, Tl = dim * mult, [224, 112, 56, 28]
+    conv = lambda T, k, cin, cout: 2.0 * T * k * cin * cout
+    rb = lambda T, cin, cout: conv(T, 5, cin, cout) + conv(T, 5, cout, cout) + (conv(T, 1, cin, cout) if cin != cout else 0) \
+        + 2.0 * dim * 2 * cout
+    cin0 = J * (2 if keyframe else 1)
+    f = 2.0 * dim * 4 * dim * 2
+    for l, T in enumerate(Tl):
+        f += rb(T, cin0 if l == 0 else C, C) + rb(T, C, C)
+        if l < 3:
+            f += conv(Tl[l + 1], 3, C, C)
+    f += 2 * rb(Tl[3], C, C)
+    for l in (3, 2, 1):
+        f += rb(Tl[l], 2 * C, C) + rb(Tl[l], C, C) + conv(Tl[l - 1], 2, C, C)   # transposed conv: 2 taps per output row
+    return f + conv(224, 5, C, C) + conv(224, 1, C, J)
+
+
+def build_unet(dev, seed=0):
+    from oracle import weights
+    mu = sub("utils.model_util")
+    args = SimpleNamespace(dataset="humanml", arch="unet", keyframe_conditioned=True, dim_mults=(2, 2, 2, 2),
+                           cond_mask_prob=0.1)
+    model, _ = mu.create_model_and_diffusion(args, None)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = weights.to_torch(weights.fill_like(shapes, seed))
+    sd.update({k: v for k, v in model.state_dict().items() if k.endswith(".pe")})
+    mu.load_model_wo_clip(model, sd)
+    return model.to(dev).eval(), None
 
 
 def build_model(cfg_on, dev, seed=0):
@@ -148,13 +183,14 @@ def main():
     B, K, W = cfg["B"], args.steps, args.warmup
     gd, rs, du = sub("diffusion.gaussian_diffusion"), sub("diffusion.respace"), sub("utils.dist_util")
     N = sub("_native")
-    model, sd = build_model(cfg["cfg"], dev)
+    model, sd = build_unet(dev) if cfg.get("unet") else build_model(cfg["cfg"], dev)
     diffusion = rs.SpacedDiffusion(rs.space_timesteps(1000, cfg["respacing"]),
                                    gd.DiffusionConfig(betas=gd.get_named_beta_schedule("cosine", 1000)))
     n_chain = diffusion.num_timesteps
     assert K + W <= n_chain, f"steps + warmup must be <= {n_chain}"
     model.native_precision = args.precision
     eng = model.engine(dev, max_batch=B, max_frames=T_FRAMES, want_grad=cfg["edit"])
+    is_unet = bool(cfg.get("unet"))
     split = eng.precision == "f16x3"
     eng.set_graph(args.graph)
     eng.set_schedule(diffusion.engine_tables(), key="bench")
@@ -164,6 +200,12 @@ def main():
     enc = torch.randn(B, 512, generator=g).to(dev)
     scale = torch.full((B,), 2.5, device=dev)
     cond = dict(batch=B, n_frames=T_FRAMES, cfg=cfg["cfg"], enc_text=enc, text_scale=scale)
+    if is_unet:   # sparse keyframes (every 5th frame, all features): observed by the U-Net and imputed
+        x0 = torch.randn(B, N_FEATS, 1, T_FRAMES, generator=g).to(dev)
+        mask = torch.zeros(B, N_FEATS, 1, T_FRAMES, dtype=torch.bool)
+        mask[..., ::5] = True
+        cond.update(inpaint_mask=mask.to(dev), inpaint_motion=x0, imputate=True, stop_imputation_at=1,
+                    obs_x0=x0, obs_mask=mask.to(dev))
     if cfg["edit"]:
         x0 = torch.randn(B, N_FEATS, 1, T_FRAMES, generator=g).to(dev)
         mask = torch.zeros(B, N_FEATS, 1, T_FRAMES, dtype=torch.bool)
@@ -206,6 +248,8 @@ def main():
     steps_per_s = world * K / elapsed
     passes = 2 if cfg["cfg"] else 1
     flop_step = B * passes * flops_per_sample_eval() * (30.68 / 14.706 if cfg["edit"] else 1.0)
+    if is_unet:
+        flop_step = B * passes * unet_flops_per_sample_eval()
     out = {
         "metric": "diffusion denoising steps/sec", "value": steps_per_s, "unit": "steps/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
@@ -223,7 +267,7 @@ def main():
         "allgather_ms": gather_ms,
     }
 
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline and not is_unet:
         # instrumented second pass over the same K steps: HIP events around every in_proj GEMM
         eng.profile_enable(True)
         eng.sample_loop(x, K - 1, 0, sampler=sampler, seed=seed, first_sample=first)
@@ -259,7 +303,7 @@ def main():
             }
     if world > 1:
         dist.barrier()
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu and not is_unet:
         out["cpu_baseline"] = cpu_baseline(sd, B)
         out["gpu_over_cpu"] = steps_per_s / out["cpu_baseline"]["value"]
     if rank == 0:

@@ -117,3 +117,25 @@ def make_unet_inputs(case: dict = UNET_CASE) -> dict:
     return {"x": f32(rng.standard_normal(shape)), "t": np.asarray(case["t"], dtype=np.int64),
             "obs_x0": f32(rng.standard_normal(shape)), "obs_mask": rng.random(shape) < case["mask_prob"],
             "enc_text": f32(rng.standard_normal((B, 512))), "text_scale": f32(case["text_scale"])}
+
+UNET_CHAIN = dict(B=2, T=196, seed=302, weight_seed=31, dim_mults=(1, 1, 1, 1), respacing=[6],
+                  text_scale=[2.5, 2.5], trans_length=5, stop_imputation_at=1, lengths=[196, 150])
+
+
+def make_unet_chain_inputs(case: dict = UNET_CHAIN) -> dict:
+    """conditional_synthesis-style chain: sparse keyframes observed (obs_x0 / obs_mask) AND imputed."""
+    rng = np.random.default_rng(case["seed"])
+    B, T = case["B"], case["T"]
+    shape = (B, N_FEATS, 1, T)
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    lengths = np.asarray(case["lengths"], dtype=np.int64)
+    n = len(space_steps(case["respacing"]))
+    return {"x_T": f32(rng.standard_normal(shape)), "noise": f32(rng.standard_normal((n,) + shape)),
+            "x0": f32(rng.standard_normal(shape)), "lengths": lengths,
+            "len_mask": (np.arange(T)[None, :] < lengths[:, None]).reshape(B, 1, 1, T),
+            "obs_mask": sparse_keyframe_mask(lengths, T, case["trans_length"]),
+            "enc_text": f32(rng.standard_normal((B, 512))), "text_scale": f32(case["text_scale"])}
+
+
+def space_steps(respacing):
+    return list(range(respacing[0]))

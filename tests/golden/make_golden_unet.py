@@ -46,3 +46,24 @@ out = {"out_cond": oc.numpy(), "out_uncond": ou.numpy(), "out_cfg": cfg.numpy(),
        "names": np.asarray(sorted(shapes))}
 np.savez_compressed(HERE / "unet_fwd.npz", **out)
 print({k: getattr(v, "shape", None) for k, v in out.items()}, float(np.abs(out["out_cond"]).mean()))
+
+
+# ---- a short sampling chain through the reference's own p_sample_loop (the conditional_synthesis.py call) ----
+cc = cases.UNET_CHAIN
+ci = cases.make_unet_chain_inputs()
+betas = ref.gd.get_named_beta_schedule("cosine", 1000)
+diffusion = ref.respace.SpacedDiffusion(use_timesteps=ref.respace.space_timesteps(1000, cc["respacing"]),
+                                        conf=ref.gd.DiffusionConfig(betas=betas))
+ref_shims.set_text_embedding(t(ci["enc_text"]))
+obs_mask = t(ci["obs_mask"])
+y = {"mask": t(ci["len_mask"]), "lengths": t(ci["lengths"]), "text": ["a"] * cc["B"], "text_scale": t(ci["text_scale"]),
+     "inpainting_mask": obs_mask, "inpainted_motion": t(ci["x0"]), "imputate": True,
+     "stop_imputation_at": cc["stop_imputation_at"], "replacement_distribution": "conditional",
+     "reconstruction_guidance": False, "diffusion_steps": 1000}
+kw = dict(noise=t(ci["x_T"]), clip_denoised=False, device=torch.device("cpu"),
+          model_kwargs={"y": y, "obs_x0": t(ci["x0"]), "obs_mask": obs_mask})
+stream = [t(ci["noise"][k]) for k in range(diffusion.num_timesteps)]
+with ref_shims.injected_noise(stream):
+    final = diffusion.p_sample_loop(wrapped, ci["x_T"].shape, **kw)
+np.savez_compressed(HERE / "unet_chain.npz", final=final.detach().numpy(), fingerprint=cases.fingerprint(ci))
+print("chain", final.shape, float(final.abs().mean()))

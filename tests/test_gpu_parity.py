@@ -499,3 +499,24 @@ def test_unet_forward_vs_reference(cases):
         assert np.isfinite(mine).all()
         assert max_abs(mine, g[key]) <= 2e-4 and rel_l2(mine, g[key]) <= 2e-5, \
             (key, max_abs(mine, g[key]), rel_l2(mine, g[key]))
+
+
+def test_unet_chain_vs_reference(cases):
+    """The conditional_synthesis.py call (p_sample_loop, CFG wrapper, obs_x0 / obs_mask, imputation) with the
+    native MDM_UNET vs the real reference's chain on the same injected noise."""
+    cc = cases.UNET_CHAIN
+    ci = cases.make_unet_chain_inputs()
+    g = load_golden("unet_chain")
+    assert np.array_equal(g["fingerprint"], cases.fingerprint(ci))
+    model, _ = make_unet(cases)
+    wrapped = sub("model.cfg_sampler").ClassifierFreeSampleModel(model)
+    diffusion = make_diffusion(cc["respacing"])
+    obs_mask = tt(ci["obs_mask"])
+    y = {"mask": tt(ci["len_mask"]), "lengths": tt(ci["lengths"]), "text_embed": tt(ci["enc_text"]),
+         "text_scale": tt(ci["text_scale"]), "inpainting_mask": obs_mask, "inpainted_motion": tt(ci["x0"]),
+         "imputate": True, "stop_imputation_at": cc["stop_imputation_at"], "replacement_distribution": "conditional",
+         "reconstruction_guidance": False, "diffusion_steps": 1000}
+    diffusion.injected_noise = tt(ci["noise"])
+    final = diffusion.p_sample_loop(wrapped, ci["x_T"].shape, noise=tt(ci["x_T"]), clip_denoised=False,
+                                    model_kwargs={"y": y, "obs_x0": tt(ci["x0"]), "obs_mask": obs_mask}).cpu().numpy()
+    assert rel_l2(final, g["final"]) <= 1e-4, rel_l2(final, g["final"])
