@@ -82,6 +82,7 @@ static hipError_t launch_h3_tiles(const H3Params& p, int tile, hipStream_t s) {
         case 10: return launch_h3_one<H256x128w16, EPI>(p, s);
         case 11: return launch_h3_one<H128x256w16, EPI>(p, s);
         case 20: return launch_h3_mixed<EPI>(p, s);
+        case 21: return launch_h3_one<H64x128w8s2, EPI>(p, s);
         default: return hipErrorInvalidValue;
     }
 }
@@ -89,8 +90,10 @@ static hipError_t launch_h3_tiles(const H3Params& p, int tile, hipStream_t s) {
 // Measured on MI355X at the denoiser's shapes (M = 12,608; tools/gemm_bench.py): 128x128 with 8 waves
 // (32x64 per wave), 2 stages, 2 blocks = 16 waves per CU wins every projection.
 int gemm_h3_auto_tile(int M, int N) {
-    (void)M; (void)N;
-    return 8;
+    // fewer than ~3/4 of the chip's 512 block slots with 128x128 tiles (the coarse levels of the U-Net):
+    // halve the tile height so twice as many blocks share the work
+    const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+    return tiles < 384 ? 21 : 8;
 }
 
 hipError_t launch_gemm_h3(int epi, const H3Params& p, int tile, hipStream_t s) {

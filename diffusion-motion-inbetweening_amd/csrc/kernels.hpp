@@ -26,7 +26,8 @@ int gemm_auto_tile(int M, int N);
 // ---- gemm_h3.hip (split-f16, fp32-equivalent) ---------------------------------------------------
 // epi: H3Epi; tile: 0 auto, 1 = 128x128 (2 stages), 2 = 256x128 8 waves (3 stages), 3 = same (2 stages),
 // 4 = 128x64 (2), 5 = 128x64 (3), 6 = 64x128 (2), 7 = 128x128 8 waves (3), 8 = same (2), 9 = 128x256 8 waves (2),
-// 10 / 11 = 256x128 / 128x256 16 waves (3), 20 = mixed grid: 128x128 8 waves for whole rounds + 64x128 tail
+// 10 / 11 = 256x128 / 128x256 16 waves (3), 20 = mixed grid: 128x128 8 waves for whole rounds + 64x128 tail,
+// 21 = 64x128 8 waves (2)
 hipError_t launch_gemm_h3(int epi, const H3Params& p, int tile, hipStream_t stream);
 int gemm_h3_auto_tile(int M, int N);
 // fp32 [rows][cols] (row stride ld_src) -> split rows [rows][2*cols] halves (format: gemm_h3.hpp)

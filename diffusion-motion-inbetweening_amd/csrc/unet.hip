@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ ss, const float* __restrict__ resid,
                                                        float* __restrict__ yf, _Float16* __restrict__ ys, int ys_ld,
-                                                       int* __restrict__ range_flag, int C, int Tp, int h, int Tv) {
+                                                       int* __restrict__ range_flag, int C, int Tp, int h, int Tv, int ss_ld) {
     const int seq = blockIdx.y;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= Tv) return;
@@ -144,8 +144,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
         float y[4] = {(v.x - mean) * rstd * ga.x + be.x, (v.y - mean) * rstd * ga.y + be.y,
                       (v.z - mean) * rstd * ga.z + be.z, (v.w - mean) * rstd * ga.w + be.w};
         if (ss) {
-            const float4 sc = *reinterpret_cast<const float4*>(ss + (size_t)seq * 2 * C + c);
-            const float4 sh = *reinterpret_cast<const float4*>(ss + (size_t)seq * 2 * C + C + c);
+            const float4 sc = *reinterpret_cast<const float4*>(ss + (size_t)seq * ss_ld + c);
+            const float4 sh = *reinterpret_cast<const float4*>(ss + (size_t)seq * ss_ld + C + c);
             y[0] = y[0] * (1.f + sc.x) + sh.x; y[1] = y[1] * (1.f + sc.y) + sh.y;
             y[2] = y[2] * (1.f + sc.z) + sh.z; y[3] = y[3] * (1.f + sc.w) + sh.w;
         }
@@ -213,7 +213,8 @@ struct GN { float *g = nullptr, *b = nullptr; };
 struct ResBlock {
     Conv c1, c2, res;      // res.w == nullptr: identity residual
     GN n1, n2;
-    float *tw = nullptr, *tb = nullptr;   // time_mlp.1: Linear(dim, 2*cout)
+    float *tw = nullptr, *tb = nullptr;   // time_mlp.1: Linear(dim, 2*cout) (slices of UnetModel::tw_all / tb_all)
+    int ss_off = 0;                       // column offset of this block's (scale | shift) in the stacked output
     int cin = 0, cout = 0;
 };
 }  // namespace
@@ -232,6 +233,8 @@ struct UnetModel {
     bool finalized = false;
     // workspace
     float *emb_h = nullptr, *cvec = nullptr, *cm = nullptr, *ss = nullptr, *stats = nullptr;
+    float *tw_all = nullptr, *tb_all = nullptr;   // the 16 time_mlp.1 Linears stacked: ONE GEMM per evaluation
+    int ss_ld = 0;
     float *F1[4] = {}, *F2[4] = {}, *Xa[4] = {}, *Xb[4] = {};
     _Float16 *in0S = nullptr, *H1S[4] = {}, *Sa[4] = {}, *Sb[4] = {}, *CAT[4] = {}, *S0skip = nullptr;
     float* outF = nullptr;
@@ -283,7 +286,10 @@ int rb_alloc(UnetModel* u, ResBlock& r, int cin, int cout) {
     if (cin != cout && conv_alloc(u, r.res, cin, cout, 1)) return -1;
     if (ualloc_t(u, &r.n1.g, cout) || ualloc_t(u, &r.n1.b, cout) || ualloc_t(u, &r.n2.g, cout) || ualloc_t(u, &r.n2.b, cout))
         return -1;
-    if (ualloc_t(u, &r.tw, (size_t)2 * cout * u->dim) || ualloc_t(u, &r.tb, (size_t)2 * cout)) return -1;
+    r.ss_off = u->ss_ld;
+    r.tw = u->tw_all + (size_t)u->ss_ld * u->dim;
+    r.tb = u->tb_all + u->ss_ld;
+    u->ss_ld += 2 * cout;
     return 0;
 }
 
@@ -299,7 +305,7 @@ bool rb_slot(ResBlock& r, const std::string& s, Slot* o) {
     if (s == "blocks.1.block.0.bias") { *o = {r.c2.b, r.cout}; return true; }
     if (s == "blocks.1.block.2.weight") { *o = {r.n2.g, r.cout}; return true; }
     if (s == "blocks.1.block.2.bias") { *o = {r.n2.b, r.cout}; return true; }
-    if (s == "time_mlp.1.weight") { *o = {r.tw, (int64_t)2 * r.cout * 512}; return true; }
+    if (s == "time_mlp.1.weight") { *o = {r.tw, (int64_t)2 * r.cout * 512}; return true; }   // slice of tw_all
     if (s == "time_mlp.1.bias") { *o = {r.tb, (int64_t)2 * r.cout}; return true; }
     if (s == "residual_conv.weight" && r.res.w) return convw(r.res);
     if (s == "residual_conv.bias" && r.res.b) { *o = {r.res.b, r.cout}; return true; }
@@ -344,6 +350,7 @@ UnetModel* unet_new(int n_feats, int added, int dim, const int mults[4], int max
     if (!rc) (void)hipMemset(u->range_flag, 0, sizeof(int));
     rc |= ualloc_t(u, &u->t1w, (size_t)4 * dim * dim) | ualloc_t(u, &u->t1b, (size_t)4 * dim);
     rc |= ualloc_t(u, &u->t2w, (size_t)4 * dim * dim) | ualloc_t(u, &u->t2b, (size_t)dim);
+    rc |= ualloc_t(u, &u->tw_all, (size_t)16 * 2 * Cw * dim) | ualloc_t(u, &u->tb_all, (size_t)16 * 2 * Cw);
     for (int l = 0; l < 4 && !rc; ++l) {
         rc |= rb_alloc(u, u->down[l][0], l == 0 ? u->C[0] : Cw, Cw);
         rc |= rb_alloc(u, u->down[l][1], Cw, Cw);
@@ -359,7 +366,7 @@ UnetModel* unet_new(int n_feats, int added, int dim, const int mults[4], int max
     // workspace
     const size_t ns = (size_t)max_seq;
     rc |= ualloc_t(u, &u->emb_h, ns * 4 * dim) | ualloc_t(u, &u->cvec, ns * dim) | ualloc_t(u, &u->cm, ns * dim);
-    rc |= ualloc_t(u, &u->ss, ns * 2 * Cw) | ualloc_t(u, &u->stats, ns * NG * 2);
+    rc |= ualloc_t(u, &u->ss, ns * 16 * 2 * Cw) | ualloc_t(u, &u->stats, ns * NG * 2);
     for (int l = 0; l < 4 && !rc; ++l) {
         const size_t rows = ns * (size_t)(256 >> l);
         rc |= alloc_rows(u, &u->F1[l], rows, Cw) | alloc_rows(u, &u->F2[l], rows, Cw);
@@ -489,7 +496,7 @@ int group_norm(UnetModel* u, const float* x, const GN& n, const float* ss, const
     const int C = u->C[1];
     hipLaunchKernelGGL(gn_stats_kernel, dim3(nseq, NG), dim3(256), 0, s, x, u->stats, C, L.Tp, L.h, L.Tv);
     hipLaunchKernelGGL(gn_apply_kernel, dim3((L.Tv + 3) / 4, nseq), dim3(256), 0, s, x, u->stats, n.g, n.b, ss, resid, yf,
-                       ys, ys_ld, u->range_flag, C, L.Tp, L.h, L.Tv);
+                       ys, ys_ld, u->range_flag, C, L.Tp, L.h, L.Tv, u->ss_ld);
     UCHK(hipGetLastError());
     return 0;
 }
@@ -499,14 +506,9 @@ int res_block(UnetModel* u, const ResBlock& r, const _Float16* xs, int a_ld, con
               float* out_f, _Float16* out_s, int out_ld, hipStream_t s) {
     const Lvl L = lvl(level);
     const int rows = nseq * L.Tp, C = r.cout;
-    {   // (scale | shift) = Linear(Mish(c))
-        GemmParams p{};
-        p.A = u->cm; p.W = r.tw; p.bias = r.tb; p.C = u->ss;
-        p.M = nseq; p.N = 2 * C; p.K = u->dim; p.lda = u->dim; p.ldw = u->dim; p.ldc = 2 * C; p.out_scale = 1.f;
-        UCHK(launch_gemm(GK_PLAIN, p, 4, s));
-    }
+    const float* ss = u->ss + r.ss_off;   // (scale | shift) = Linear(Mish(c)), computed for all blocks up front
     if (conv_rows(u, r.c1, r.c1.ws, xs, a_ld, rows, level, 5, 2, 1, 0, 0, u->F1[level], nullptr, 0, nullptr, s)) return -1;
-    if (group_norm(u, u->F1[level], r.n1, u->ss, nullptr, nullptr, u->H1S[level], 2 * C, nseq, level, s)) return -1;
+    if (group_norm(u, u->F1[level], r.n1, ss, nullptr, nullptr, u->H1S[level], 2 * C, nseq, level, s)) return -1;
     if (conv_rows(u, r.c2, r.c2.ws, u->H1S[level], 2 * C, rows, level, 5, 2, 1, 0, 0, u->F2[level], nullptr, 0, nullptr, s)) return -1;
     if (!r.res.ws) {   // identity residual, added behind the Mish
         return group_norm(u, u->F2[level], r.n2, nullptr, xf, out_f, out_s, out_ld, nseq, level, s);
@@ -538,6 +540,11 @@ int unet_forward(UnetModel* u, const float* x, const float* obs, const uint8_t* 
         UCHK(launch_gemm(GK_PLAIN, q, 4, s));
         const int64_t n2 = (int64_t)nseq * dim;
         hipLaunchKernelGGL(mish_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, u->cvec, u->cm, n2);
+        // every block's (scale | shift) = time_mlp.1(Mish(c)) in one GEMM over the stacked weights
+        GemmParams r{};
+        r.A = u->cm; r.W = u->tw_all; r.bias = u->tb_all; r.C = u->ss;
+        r.M = nseq; r.N = u->ss_ld; r.K = dim; r.lda = dim; r.ldw = dim; r.ldc = u->ss_ld; r.out_scale = 1.f;
+        UCHK(launch_gemm(GK_PLAIN, r, 4, s));
     }
     hipLaunchKernelGGL(unet_input_kernel, dim3(TPAD / 4, nseq), dim3(256), 0, s, x, obs, mask, u->in0S, B, u->J, T,
                        u->Cin0p, 256, 16, u->added ? 1 : 0);
