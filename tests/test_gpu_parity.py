@@ -501,6 +501,26 @@ def test_unet_forward_vs_reference(cases):
             (key, max_abs(mine, g[key]), rel_l2(mine, g[key]))
 
 
+@pytest.mark.parametrize("B,T", [(3, 100), (1, 224), (2, 17)])
+def test_unet_vs_oracle_other_shapes(cases, B, T):
+    """Frame counts other than the golden 196 (right-padded to 224 inside the model) vs the numpy oracle."""
+    from oracle.unet_oracle import UnetOracle
+    model, _ = make_unet(cases)
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    rng = np.random.default_rng(1000 + 7 * B + T)
+    shape = (B, 263, 1, T)
+    x = rng.standard_normal(shape).astype(np.float32)
+    obs = rng.standard_normal(shape).astype(np.float32)
+    m = rng.random(shape) < 0.2
+    t = rng.integers(0, 1000, B)
+    enc = rng.standard_normal((B, 512)).astype(np.float32)
+    scale = np.full(B, 2.5, np.float32)
+    want, _, _ = UnetOracle(sd).forward_cfg(x, t, enc, scale, obs, m)
+    wrapped = sub("model.cfg_sampler").ClassifierFreeSampleModel(model)
+    got = wrapped(tt(x), tt(t), y={"text_embed": tt(enc), "text_scale": tt(scale)}, obs_x0=tt(obs), obs_mask=tt(m)).cpu().numpy()
+    assert max_abs(got, want) <= 2e-4 and rel_l2(got, want) <= 2e-5, (max_abs(got, want), rel_l2(got, want))
+
+
 def test_unet_chain_vs_reference(cases):
     """The conditional_synthesis.py call (p_sample_loop, CFG wrapper, obs_x0 / obs_mask, imputation) with the
     native MDM_UNET vs the real reference's chain on the same injected noise."""
