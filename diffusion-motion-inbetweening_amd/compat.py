@@ -9,11 +9,16 @@ sample/edit.py, sample/synthesize.py) resolve
     from utils import dist_util ; from utils.fixseed import fixseed
 
 to the MI355X implementations.  Only hot-path modules are aliased; anything else (data loaders,
-parsers, plotting) is still imported from wherever the caller's sys.path finds it.
+parsers, plotting) is still imported from wherever the caller's sys.path finds it.  A name an aliased module
+does not define (e.g. ``utils.editing_util.load_fixed_dataset``, a fixture loader) falls through to the
+caller's own file of that module name: ``from utils.editing_util import get_keyframes_mask, load_fixed_dataset``
+(sample/conditional_synthesis.py:21) takes the first from here and the second from the reference tree.
 """
 from __future__ import annotations
 
 import importlib
+import importlib.util
+import os
 import sys
 import types
 
@@ -32,6 +37,39 @@ _ALIASES = {
 # aliased: the reference's module of that name also holds data-preparation code; import it explicitly)
 
 
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+_fallbacks: dict = {}
+
+
+def _callers_module(ref_name: str):
+    """The caller tree's own ``<ref_name>.py`` (first hit on sys.path outside this package), loaded once under a
+    private name; None when there is none (this repo used standalone)."""
+    if ref_name in _fallbacks:
+        return _fallbacks[ref_name]
+    rel = os.path.join(*ref_name.split(".")) + ".py"
+    mod = None
+    for base in sys.path:
+        cand = os.path.abspath(os.path.join(base or ".", rel))
+        if os.path.isfile(cand) and not cand.startswith(_PKG_DIR + os.sep):
+            spec = importlib.util.spec_from_file_location("_condmdi_caller_." + ref_name, cand)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            break
+    _fallbacks[ref_name] = mod
+    return mod
+
+
+def _fall_through(ref_name: str, ours):
+    def __getattr__(name):   # PEP 562: only consulted for names `ours` does not define
+        if name.startswith("__"):
+            raise AttributeError(name)
+        other = _callers_module(ref_name)
+        if other is None or not hasattr(other, name):
+            raise AttributeError(f"module '{ref_name}' (MI355X path: {ours.__name__}) has no attribute '{name}'")
+        return getattr(other, name)
+    return __getattr__
+
+
 def install_reference_aliases(overwrite: bool = False):
     pkg = __name__.rsplit(".", 1)[0]
     installed = []
@@ -45,6 +83,8 @@ def install_reference_aliases(overwrite: bool = False):
             parent = types.ModuleType(parent_name)
             parent.__path__ = []  # namespace-like: lets `import utils.x` fall through for non-aliased x
             sys.modules[parent_name] = parent
+        if "__getattr__" not in vars(mod):
+            mod.__getattr__ = _fall_through(ref_name, mod)
         sys.modules[ref_name] = mod
         setattr(parent, ref_name.split(".")[1], mod)
         installed.append(ref_name)

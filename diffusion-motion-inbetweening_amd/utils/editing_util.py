@@ -5,9 +5,10 @@ Mirror of the part of the reference's ``utils/editing_util.py`` that the sampler
 step); all samples of a batch share the step index, so here the gates are plain integers handed to
 the engine once (``cmdi_condition``), and the per-step weights are a precomputed table.
 
-Keyframe-mask CONSTRUCTION (``get_keyframes_mask`` :56-229) runs once per batch on the host and
-stays with the caller; `joint_to_full_mask` and the HumanML3D joint→feature matrices are provided
-because mask semantics are part of the path's contract.
+Keyframe-mask CONSTRUCTION (``get_keyframes_mask`` :56-229) is the step right before
+the loop: the reference fills the mask sample by sample after ``lengths.cpu()`` (a host sync and B small
+device writes); here the inference modes are one broadcast expression on the data's device.  The modes that
+draw from ``np.random`` consume it in the reference's order, so a seeded call gives the same mask.
 """
 from __future__ import annotations
 
@@ -51,6 +52,67 @@ def joint_to_full_mask(joint_mask, mode='pos_rot_vel'):
     jm = joint_mask.bool().permute(0, 2, 3, 1)                                     # [B, 1, T, 22]
     full = (jm.unsqueeze(-1) & sel).any(dim=-2)                                    # [B, 1, T, 263]
     return full.permute(0, 3, 1, 2)
+
+
+# reference data_loaders/humanml_utils.py:1-37 (joint order of HML_JOINT_NAMES)
+HML_LOWER_BODY_JOINTS = (0, 1, 2, 4, 5, 7, 8, 10, 11)   # pelvis, hips, knees, ankles, feet
+HML_PELVIS_FEET = (0, 10, 11)
+HML_PELVIS_VR = (0, 20, 21, 15)                         # pelvis, wrists, head
+_JOINT_MODES = {'right_wrist': (0, 21), 'lower_body': HML_LOWER_BODY_JOINTS, 'pelvis_feet': HML_PELVIS_FEET,
+                'pelvis_vr': HML_PELVIS_VR, 'pelvis': (0,)}
+
+
+def get_keyframes_mask(data, lengths, edit_mode='benchmark_sparse', trans_length=10, feature_mode='pos_rot_vel',
+                       get_joint_mask=False, n_keyframes=5):
+    """Observation mask [B, 263, 1, T] (and the joint mask [B, 22, 1, T] if ``get_joint_mask``) of the
+    reference's ``get_keyframes_mask`` (utils/editing_util.py:56-229) for HumanML3D data, built on
+    ``data.device`` without a host round trip for the deterministic modes:
+      benchmark_sparse  every trans_length-th frame below the sequence length          (:85-91)
+      benchmark_clip    everything but the middle trans_length frames                  (:93-100)
+      uncond            nothing                                                        (:102-105)
+      right_wrist / lower_body / pelvis_feet / pelvis_vr / pelvis   joint trajectories (:107-148)
+      gmd_keyframes / random_frames   n_keyframes / 20 frames drawn with np.random.choice per sample (:150-167)
+    The training-only modes ('random_joints', 'random') and AMASS data (764 features) are not part of the path."""
+    import torch
+    B, n_joints, n_features, T = data.shape
+    if n_joints != N_FEATS:
+        raise ValueError('Unknown number of joints: {}'.format(n_joints)) if n_joints != 764 else \
+            NotImplementedError('AMASS keyframe masks are outside the sampling path')
+    dev = data.device
+    lengths = torch.as_tensor(lengths, device=dev).long().view(B, 1)
+    frame = torch.arange(T, device=dev).view(1, T)
+    valid = frame < lengths                                                   # [B, T]
+    joints = torch.ones(N_JOINTS, dtype=torch.bool, device=dev)
+    if edit_mode == 'benchmark_sparse':
+        frames = valid & (frame % int(trans_length) == 0)
+    elif edit_mode == 'benchmark_clip':
+        end = torch.div(lengths - int(trans_length), 2, rounding_mode='floor')
+        frames = valid & ((frame < end) | (frame >= end + int(trans_length)))
+    elif edit_mode == 'uncond':
+        frames = torch.zeros_like(valid)
+    elif edit_mode in _JOINT_MODES:
+        frames = valid
+        joints = torch.zeros_like(joints)
+        joints[list(_JOINT_MODES[edit_mode])] = True
+    elif edit_mode in ('gmd_keyframes', 'random_frames'):
+        n = int(n_keyframes) if edit_mode == 'gmd_keyframes' else 20
+        picks = np.zeros((B, T), dtype=bool)
+        for i, length in enumerate(lengths.view(-1).cpu().numpy()):           # same np.random stream as the reference
+            picks[i, np.random.choice(range(int(length)), n, replace=False)] = True
+        frames = torch.from_numpy(picks).to(dev)
+    elif edit_mode in ('random_joints', 'random'):
+        raise NotImplementedError(f"edit_mode '{edit_mode}' is a training-time augmentation, not part of the sampling path")
+    else:
+        raise ValueError(f'unknown edit_mode: {edit_mode}')   # (the reference silently returns an empty mask)
+    joint_mask = (joints.view(1, N_JOINTS, 1, 1) & frames.view(B, 1, 1, T)).expand(B, N_JOINTS, n_features, T)
+    assert feature_mode in ('pos', 'pos_rot', 'pos_rot_vel')
+    mats = [MAT_POS, MAT_CNT] + ([MAT_ROT] if feature_mode != 'pos' else []) + ([MAT_VEL] if feature_mode == 'pos_rot_vel' else [])
+    sel = torch.from_numpy(np.any(np.stack(mats), axis=0)).to(dev)            # [22, 263]
+    feats = (sel & joints.view(N_JOINTS, 1)).any(dim=0)                       # [263]
+    full = (feats.view(1, N_FEATS, 1, 1) & frames.view(B, 1, 1, T)).expand(B, N_FEATS, n_features, T).contiguous()
+    if get_joint_mask:
+        return full, joint_mask.contiguous()
+    return full
 
 
 def get_gradient_schedule(schedule_name=None, num_diffusion_steps=1000, scale=.05):

@@ -139,3 +139,15 @@ def make_unet_chain_inputs(case: dict = UNET_CHAIN) -> dict:
 
 def space_steps(respacing):
     return list(range(respacing[0]))
+
+
+# ---- keyframe masks (get_keyframes_mask, the step before the loop) ----------------------
+KEYFRAME_CASE = dict(B=5, T=196, lengths=[196, 150, 41, 7, 100], seed=401)
+KEYFRAME_MODES = [  # (edit_mode, trans_length, feature_mode, n_keyframes)
+    ("benchmark_sparse", 5, "pos_rot_vel", 5), ("benchmark_sparse", 20, "pos", 5), ("benchmark_sparse", 1, "pos_rot", 5),
+    ("benchmark_clip", 10, "pos_rot_vel", 5), ("benchmark_clip", 60, "pos_rot", 5), ("uncond", 10, "pos_rot_vel", 5),
+    ("right_wrist", 10, "pos_rot_vel", 5), ("lower_body", 10, "pos", 5), ("pelvis_feet", 10, "pos_rot_vel", 5),
+    ("pelvis_vr", 10, "pos_rot", 5), ("pelvis", 10, "pos_rot_vel", 5),
+    ("gmd_keyframes", 10, "pos_rot_vel", 5), ("gmd_keyframes", 10, "pos", 3),
+]
+KEYFRAME_RANDOM_FRAMES = dict(B=3, T=196, lengths=[196, 150, 41], seed=402)   # random_frames draws 20 frames

@@ -540,3 +540,19 @@ def test_unet_chain_vs_reference(cases):
     final = diffusion.p_sample_loop(wrapped, ci["x_T"].shape, noise=tt(ci["x_T"]), clip_denoised=False,
                                     model_kwargs={"y": y, "obs_x0": tt(ci["x0"]), "obs_mask": obs_mask}).cpu().numpy()
     assert rel_l2(final, g["final"]) <= 1e-4, rel_l2(final, g["final"])
+
+
+def test_keyframes_mask_built_on_device(cases):
+    """get_keyframes_mask with device inputs: built on the device (no per-sample host loop), bit-exact vs the reference."""
+    eu = sub("utils.editing_util")
+    g = load_golden("keyframe_masks")
+    kc = cases.KEYFRAME_CASE
+    data = torch.zeros(kc["B"], 263, 1, kc["T"], device=DEV)
+    lengths = torch.tensor(kc["lengths"], device=DEV)
+    for i, (mode, trans, feat, nk) in enumerate(cases.KEYFRAME_MODES):
+        np.random.seed(kc["seed"] + i)
+        full, joint = eu.get_keyframes_mask(data, lengths, edit_mode=mode, trans_length=trans, feature_mode=feat,
+                                            get_joint_mask=True, n_keyframes=nk)
+        assert full.device.type == "cuda" and full.is_contiguous()
+        assert np.array_equal(np.packbits(full.cpu().numpy()), g[f"full.{i}"]), (mode, trans, feat)
+        assert np.array_equal(np.packbits(joint.cpu().numpy()), g[f"joint.{i}"]), (mode, trans, feat)
