@@ -240,10 +240,13 @@ int run_layers(cmdi_engine* e, int seq0, int nseq, bool keep, bool prof, hipStre
                 p.ln_stats = keep ? st->stats1 + r0 * 2 : nullptr;
                 HIPCHK(launch_gemm_h3(H3_RESID_LN, p, 0, s));
             } else {
+                // the residual stream lives in split rows only: LayerNorm writes them for the next GEMM and
+                // the residual epilogue reads the same rows back (hi + lo * 2^-11, 22 bits) — 8 instead of
+                // 12 bytes per element through each LayerNorm
                 H3Params p = hp(attnS, w.out_ws, w.out_b, pre1, nullptr, d, d);
-                p.R = tokA;
+                p.Rs = tokS;
                 HIPCHK(launch_gemm_h3(H3_RESID, p, e->h3_tile_proj, s));
-                HIPCHK(launch_layernorm(pre1, w.n1_g, w.n1_b, bufH, bufHS, e->range_flag,
+                HIPCHK(launch_layernorm(pre1, w.n1_g, w.n1_b, nullptr, bufHS, e->range_flag,
                                         keep ? st->stats1 + r0 * 2 : nullptr, M, d, s));
             }
             {
@@ -259,9 +262,10 @@ int run_layers(cmdi_engine* e, int seq0, int nseq, bool keep, bool prof, hipStre
                 HIPCHK(launch_gemm_h3(H3_RESID_LN, p, 0, s));
             } else {
                 H3Params p = hp(ffnS, w.l2_ws, w.l2_b, pre2, nullptr, d, f);
-                p.R = bufH;
+                p.Rs = bufHS;
                 HIPCHK(launch_gemm_h3(H3_RESID, p, e->h3_tile_ffn2, s));
-                HIPCHK(launch_layernorm(pre2, w.n2_g, w.n2_b, tokA, l + 1 < e->L ? tokS : nullptr,
+                const bool last = l + 1 == e->L;   // the output projection (fp32 GEMM) reads fp32 rows
+                HIPCHK(launch_layernorm(pre2, w.n2_g, w.n2_b, last ? tokA : nullptr, last ? nullptr : tokS,
                                         e->range_flag, keep ? st->stats2 + r0 * 2 : nullptr, M, d, s));
             }
             continue;
@@ -1478,7 +1482,8 @@ int cmdi_gemm_h3(const void* d_a_split, const void* d_w_split, const float* d_bi
         case 0: kind = d_c_split ? H3_PLAIN_SPLIT : H3_PLAIN; break;
         case 1: kind = H3_GELU_SPLIT; break;
         case 3: kind = H3_RESID; break;
-        default: return fail(CMDI_E_INVALID, "epi must be 0 (bias), 1 (bias+gelu, split output) or 3 (bias+residual)");
+        case 4: kind = H3_RESID; p.R = nullptr; p.Rs = reinterpret_cast<const _Float16*>(d_resid); break;
+        default: return fail(CMDI_E_INVALID, "epi must be 0 (bias), 1 (bias+gelu, split output), 3 (bias+residual) or 4 (bias + split-rows residual)");
     }
     if ((kind == H3_PLAIN || kind == H3_RESID) && !d_c) return fail(CMDI_E_INVALID, "fp32 output needs d_c");
     if ((kind == H3_GELU_SPLIT || kind == H3_PLAIN_SPLIT) && !d_c_split)

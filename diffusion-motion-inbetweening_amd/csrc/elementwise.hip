@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         o.y = (v[i].y - mean) * rstd * g.y + bb.y;
         o.z = (v[i].z - mean) * rstd * g.z + bb.z;
         o.w = (v[i].w - mean) * rstd * g.w + bb.w;
-        *reinterpret_cast<float4*>(yr + i * 256 + lane * 4) = o;
+        if (y) *reinterpret_cast<float4*>(yr + i * 256 + lane * 4) = o;
         if (ys) {
             const float ov[4] = {o.x, o.y, o.z, o.w};
             h4 oh, ol;

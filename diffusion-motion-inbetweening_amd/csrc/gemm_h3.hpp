@@ -327,8 +327,15 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
                 if constexpr (EPI == H3_PLAIN) {
                     *reinterpret_cast<float4*>(p.C + off) = make_float4(v[0], v[1], v[2], v[3]);
                 } else if constexpr (EPI == H3_RESID) {
-                    const float4 rr = *reinterpret_cast<const float4*>(p.R + off);
-                    v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+                    if (p.Rs) {
+                        const _Float16* rs = p.Rs + (size_t)m * (2 * p.N) + npos;
+                        const h4 rh = *reinterpret_cast<const h4*>(rs), rl = *reinterpret_cast<const h4*>(rs + 32);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)rh[e] + (float)rl[e] * kLoInv;
+                    } else {
+                        const float4 rr = *reinterpret_cast<const float4*>(p.R + off);
+                        v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+                    }
                     if (p.C) *reinterpret_cast<float4*>(p.C + off) = make_float4(v[0], v[1], v[2], v[3]);
                     if (p.Cs) {
                         h4 oh, ol;

@@ -44,7 +44,8 @@ struct GemmParams {
 enum H3Epi {
     H3_PLAIN = 0,       // C = v + bias[n]                                   (fp32)
     H3_GELU_SPLIT = 1,  // aux = v + bias (optional); Cs = split(gelu_erf(v + bias))
-    H3_RESID = 2,       // C = (v + bias[n]) + R[m][n]  (fp32; C may be null) and, if Cs != null, Cs = split(C)
+    H3_RESID = 2,       // C = (v + bias[n]) + R[m][n]  (fp32; C may be null) and, if Cs != null, Cs = split(C);
+                        // R fp32, or Rs: the split rows a LayerNorm already wrote for the next GEMM
     H3_PLAIN_SPLIT = 3, // aux = v + bias (optional fp32 copy); Cs = split(v + bias[n])
     H3_GELUGRAD_SPLIT = 4, // Cs = split(v * gelu'(aux[m][n]))   (backward through linear1's GELU)
     H3_RESID_LN = 5,    // x = (v + bias) + R; aux = x (optional); y = LayerNorm(x) -> C (fp32) and Cs (split,
@@ -58,6 +59,7 @@ struct H3Params {
     float* C;           // fp32 output [M][ldc]
     _Float16* Cs;       // split output [M][2N]
     const float* R;     // residual [M][ldc]
+    const _Float16* Rs; // H3_RESID: the residual as split rows [M][2N] instead (R = hi + lo * 2^-11)
     float* aux;         // optional pre-activation stash [M][ldc]
     const float* ln_g;  // H3_RESID_LN: LayerNorm weight / bias [N], optional (mean, rstd) [M][2]
     const float* ln_b;

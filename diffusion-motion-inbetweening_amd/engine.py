@@ -323,7 +323,8 @@ def gemm_h3(a_split: torch.Tensor, w_split: torch.Tensor, bias: Optional[torch.T
             tile: int = 0, epi: int = 0, resid: Optional[torch.Tensor] = None,
             split_out: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """C = epi(A · Wᵀ + bias) on the split-f16 path (test / bench hook); operands from split_f16().
-    epi 0 = bias, 1 = bias + GELU (always split output), 3 = bias + residual."""
+    epi 0 = bias, 1 = bias + GELU (always split output), 3 = bias + fp32 residual, 4 = bias + residual given
+    as split rows."""
     lib = N.load()
     assert a_split.dtype == torch.float16 and w_split.dtype == torch.float16
     m, k2 = a_split.shape

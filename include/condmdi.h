@@ -227,7 +227,8 @@ int cmdi_range_status(cmdi_handle h, int32_t* out_flag, cmdi_stream stream);
  * f16((x - hi) * 2^11); cols % 32 == 0.
  * cmdi_gemm_h3: C[M,N] = epi(A[M,K] · W[N,K]^T + bias[N]) with A, W in split rows; epi as in
  * cmdi_gemm_nt (1 = bias + GELU writes split rows to d_c_split; 0 writes fp32 to d_c, or split rows
- * if d_c_split != NULL); K % 32 == 0, N % 32 == 0. */
+ * if d_c_split != NULL; 3 adds the fp32 residual d_resid [M,N]; 4 adds a residual given as split rows [M,2N] in
+ * d_resid's place); K % 32 == 0, N % 32 == 0. */
 int cmdi_split_f16(const float* d_src, void* d_dst, int64_t rows, int32_t cols, cmdi_stream stream);
 int cmdi_gemm_h3(const void* d_a_split, const void* d_w_split, const float* d_bias,
                  const float* d_resid, float* d_c, void* d_c_split, int32_t m, int32_t n, int32_t k,

@@ -122,6 +122,11 @@ def test_gemm_h3(tile, shape):
     assert e_h3 <= 2e-6 and e_h3 <= 1.5 * e_f32 + 1e-8, (e_h3, e_f32)
     out = eng.gemm_h3(a_s, w_s, b.to(DEV), tile=tile, epi=3, resid=r.to(DEV)).cpu()
     assert rel_l2(out.numpy(), (ref + r.double()).numpy()) <= 2e-6
+    if n % 32 == 0:   # the residual handed over as split rows (what LayerNorm leaves behind for the next GEMM)
+        r_s = eng.split_f16(r.to(DEV))
+        out = eng.gemm_h3(a_s, w_s, b.to(DEV), tile=tile, epi=4, resid=r_s).cpu()
+        assert rel_l2(out.numpy(), (ref + eng.unsplit_f16(r_s).cpu().double()).numpy()) <= 2e-6
+        assert rel_l2(out.numpy(), (ref + r.double()).numpy()) <= 2e-6
     out = eng.unsplit_f16(eng.gemm_h3(a_s, w_s, b.to(DEV), tile=tile, epi=1)).cpu()
     assert rel_l2(out.numpy(), torch.nn.functional.gelu(ref).numpy()) <= 2e-6
     out = eng.unsplit_f16(eng.gemm_h3(a_s, w_s, b.to(DEV), tile=tile, split_out=True)).cpu()
