@@ -105,6 +105,10 @@ struct cmdi_engine {
     // saved LayerNorm pass returns (B=32 CFG: 2.60 vs 2.29 ms per step on MI355X).
     int ln_fuse = 0;
     int io_pipe = 0;   // 1: software-pipelined input / output projection GEMMs
+    // f16x3: input / output projections on the f16 pipe too (frame rows split by pose_rows_split_kernel, token and
+    // motion-layout epilogues in gemm_h3.hpp); CMDI_IO_H3=0 keeps them on the fp32 MFMA kernels
+    int io_h3 = 0;
+    _Float16 *w_in_s = nullptr, *w_out_s = nullptr, *xS = nullptr;
     int gemm_tile = 0;
     int tile_inproj = 0, tile_proj = 0, tile_ffn1 = 0, tile_ffn2 = 0;  // per-GEMM overrides (0 = auto)
 
@@ -199,7 +203,7 @@ int run_layers(cmdi_engine* e, int seq0, int nseq, bool keep, bool prof, hipStre
         p.M = M; p.N = N; p.K = K; p.ldc = N;
         return p;
     };
-    if (h3)  // layer 0 reads the tokens assembled by token0 + the input projection (fp32)
+    if (h3 && !e->io_h3)  // layer 0 reads the tokens assembled by token0 + the input projection (fp32)
         HIPCHK(launch_split_f16(tokA, tokS, M, d, d, e->range_flag, s));
     for (int l = 0; l < e->L; ++l) {
         const LayerW& w = e->layers[l];
@@ -264,7 +268,7 @@ int run_layers(cmdi_engine* e, int seq0, int nseq, bool keep, bool prof, hipStre
                 H3Params p = hp(ffnS, w.l2_ws, w.l2_b, pre2, nullptr, d, f);
                 p.Rs = bufHS;
                 HIPCHK(launch_gemm_h3(H3_RESID, p, e->h3_tile_ffn2, s));
-                const bool last = l + 1 == e->L;   // the output projection (fp32 GEMM) reads fp32 rows
+                const bool last = l + 1 == e->L && !e->io_h3;   // an fp32 output projection reads fp32 rows
                 HIPCHK(launch_layernorm(pre2, w.n2_g, w.n2_b, last ? tokA : nullptr, last ? nullptr : tokS,
                                         e->range_flag, keep ? st->stats2 + r0 * 2 : nullptr, M, d, s));
             }
@@ -342,6 +346,31 @@ int for_groups(cmdi_engine* e, int n_seq, hipStream_t s, Fn fn) {
     return CMDI_OK;
 }
 
+// Input / output projections on the f16 pipe.  x [nb][C][T] -> frame rows (split, K padded to Cpad) -> token rows
+// 1..T of tok_split (+ the same rows for sequence b + dup: the unconditional half sees the same frames).
+static int input_projection_h3(cmdi_engine* e, const float* x, _Float16* xs, _Float16* tok_split, int nb, int dup,
+                               hipStream_t s) {
+    const int T = e->T;
+    HIPCHK(launch_pose_rows_split(x, xs, nb, e->C, T, e->Cpad, e->range_flag, s));
+    H3Params p{};
+    p.A = xs; p.W = e->w_in_s; p.bias = e->b_in; p.Cs = tok_split; p.range_flag = e->range_flag;
+    p.M = nb * T; p.N = e->d; p.K = e->Cpad; p.ldc = e->d;
+    p.pe = e->pe; p.tok_T = T; p.tok_S = T + 1; p.tok_dup = dup;
+    HIPCHK(launch_gemm_h3(H3_TOKENS, p, 0, s));
+    return CMDI_OK;
+}
+
+// out[n][c][t] = W_out[c] · tok[n*S + 1 + t] + b_out[c]: weight rows take the A role so that the stores run along T
+static int output_projection_h3(cmdi_engine* e, const _Float16* tok_split, float* out, int nseq, hipStream_t s) {
+    const int T = e->T;
+    H3Params p{};
+    p.A = e->w_out_s; p.W = tok_split; p.bias = e->b_out; p.C = out;
+    p.M = e->C; p.N = nseq * (T + 1); p.K = e->d; p.ldc = 0;
+    p.tok_T = T; p.tok_S = T + 1;
+    HIPCHK(launch_gemm_h3(H3_MOTION, p, 0, s));
+    return CMDI_OK;
+}
+
 // ---- forward pass of MDM trans_enc (model/mdm.py:239-306) over n_seq = B or 2B sequences --------
 int mdm_forward(cmdi_engine* e, const float* x, const int64_t* t_dev, int64_t t_scalar,
                 float* out_buf, bool keep, hipStream_t s, bool tables = false) {
@@ -360,8 +389,12 @@ int mdm_forward(cmdi_engine* e, const float* x, const int64_t* t_dev, int64_t t_
 
     HIPCHK(launch_token0(e->tokA, e->time_table, e->have_text ? e->text_term : nullptr, e->pe, t_dev,
                          t_scalar, n_seq, B, S, d, e->n_time_rows, s, tables ? e->tmap_dev : nullptr,
-                         tables ? e->cursor_dev : nullptr));
-    {   // InputProcess + sequence_pos_encoder for the frame tokens (mdm.py:271,279-280)
+                         tables ? e->cursor_dev : nullptr, e->io_h3 ? e->tokS : nullptr, e->range_flag));
+    // InputProcess + sequence_pos_encoder for the frame tokens (mdm.py:271,279-280)
+    if (e->io_h3) {
+        int rc = input_projection_h3(e, x, e->xS, e->tokS, B, e->cfg ? B : 0, s);
+        if (rc != CMDI_OK) return rc;
+    } else {
         GemmParams p = gp(x, e->w_in_pad, e->b_in, e->tokA, B * T, d, e->Cpad, 0, e->Cpad, d);
         p.pe = e->pe; p.T = T; p.S = S; p.Cf = C; p.Bdup = e->cfg ? B : 0;
         HIPCHK(launch_gemm(GK_INPROJ, p, e->io_pipe, s));
@@ -370,7 +403,11 @@ int mdm_forward(cmdi_engine* e, const float* x, const int64_t* t_dev, int64_t t_
         return run_layers(e, seq0, nseq, keep, e->profile, gs);
     });
     if (rc != CMDI_OK) return rc;
-    {   // OutputProcess on tokens 1..T, stored straight into [n_seq, C, 1, T] (mdm.py:284,304,412-422)
+    // OutputProcess on tokens 1..T, stored straight into [n_seq, C, 1, T] (mdm.py:284,304,412-422)
+    if (e->io_h3) {
+        int rc2 = output_projection_h3(e, e->tokS, out_buf, n_seq, s);
+        if (rc2 != CMDI_OK) return rc2;
+    } else {
         GemmParams p = gp(e->w_out, e->tokA, e->b_out, out_buf, C, n_seq * T, d, d, d, 0);
         p.T = T; p.S = S; p.Cf = C;
         HIPCHK(launch_gemm(GK_OUTPROJ, p, e->io_pipe, s));
@@ -656,6 +693,7 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
     e->h3_tile_ffn1 = env_int("CMDI_H3_TILE_FFN1", env_int("CMDI_H3_TILE", 0));
     e->h3_tile_ffn2 = env_int("CMDI_H3_TILE_FFN2", env_int("CMDI_H3_TILE", 0));
     e->ln_fuse = env_int("CMDI_LN_FUSE", 0) && desc->d_model == 512;
+    e->io_h3 = e->precision == CMDI_PREC_F16X3 && !e->ln_fuse && env_int("CMDI_IO_H3", 1);
     const int d = e->d, f = e->f, C = e->C;
     const size_t nseq = 2 * (size_t)e->Bmax, Smax = e->Tmax + 1, Mmax = nseq * Smax;
     *out = e;  // so that cmdi_destroy can free a half-built engine
@@ -695,6 +733,8 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
             ALLOC(w.in_ws, (size_t)3 * d * d * 2); ALLOC(w.out_ws, (size_t)d * d * 2);
             ALLOC(w.l1_ws, (size_t)f * d * 2); ALLOC(w.l2_ws, (size_t)d * f * 2);
         }
+        ALLOC(e->w_in_s, (size_t)d * e->Cpad * 2); ALLOC(e->w_out_s, (size_t)C * d * 2);
+        ALLOC(e->xS, (size_t)e->Bmax * e->Tmax * e->Cpad * 2);
         ALLOC(e->tokS, Mmax * d * 2); ALLOC(e->bufHS, Mmax * d * 2);
         ALLOC(e->attnS, Mmax * d * 2); ALLOC(e->ffnS, Mmax * f * 2); ALLOC(e->qkvS, Mmax * 3 * d * 2);
         if (desc->want_grad) {
@@ -843,6 +883,10 @@ int cmdi_finalize_weights(cmdi_handle e, int32_t n_time_rows, cmdi_stream stream
     }
     if (e->precision == CMDI_PREC_F16X3) {
         HIPCHK(hipMemsetAsync(e->range_flag, 0, sizeof(int), s));
+        if (!e->unet) {
+            HIPCHK(launch_split_f16(e->w_in_pad, e->w_in_s, d, e->Cpad, e->Cpad, e->range_flag, s));
+            HIPCHK(launch_split_f16(e->w_out, e->w_out_s, C, d, d, e->range_flag, s));
+        }
         for (LayerW& w : e->layers) {
             HIPCHK(launch_split_f16(w.in_w, w.in_ws, 3 * d, d, d, e->range_flag, s));
             HIPCHK(launch_split_f16(w.out_w, w.out_ws, d, d, d, e->range_flag, s));
@@ -1068,17 +1112,27 @@ static int part_forward(cmdi_engine* e, const Part& pt, const float* x_part, int
     const int T = e->T, S = T + 1, d = e->d, C = e->C;
     hipStream_t s = pt.s;
     float* tok = e->tokA + (size_t)pt.slot0 * S * d;
+    _Float16* tok_s = e->io_h3 ? e->tokS + (size_t)pt.slot0 * S * 2 * d : nullptr;
     HIPCHK(launch_token0(tok, e->time_table, e->have_text ? e->text_term_p + (size_t)pt.slot0 * d : nullptr,
-                         e->pe, nullptr, t_scalar, pt.nslot, pt.nb, S, d, e->n_time_rows, s));
-    {
+                         e->pe, nullptr, t_scalar, pt.nslot, pt.nb, S, d, e->n_time_rows, s, nullptr, nullptr,
+                         tok_s, e->range_flag));
+    if (e->io_h3) {
+        int rc0 = input_projection_h3(e, x_part, e->xS + (size_t)pt.b0 * T * 2 * e->Cpad, tok_s, pt.nb,
+                                      e->cfg ? pt.nb : 0, s);
+        if (rc0 != CMDI_OK) return rc0;
+    } else {
         GemmParams p = gp(x_part, e->w_in_pad, e->b_in, tok, pt.nb * T, d, e->Cpad, 0, e->Cpad, d);
         p.pe = e->pe; p.T = T; p.S = S; p.Cf = C; p.Bdup = e->cfg ? pt.nb : 0;
         HIPCHK(launch_gemm(GK_INPROJ, p, e->io_pipe, s));
     }
     int rc = run_layers(e, pt.slot0, pt.nslot, keep, false, s);
     if (rc != CMDI_OK) return rc;
-    {
-        GemmParams p = gp(e->w_out, tok, e->b_out, e->out_raw + (size_t)pt.slot0 * C * T, C, pt.nslot * T, d, d, d, 0);
+    float* out = e->out_raw + (size_t)pt.slot0 * C * T;
+    if (e->io_h3) {
+        rc = output_projection_h3(e, tok_s, out, pt.nslot, s);
+        if (rc != CMDI_OK) return rc;
+    } else {
+        GemmParams p = gp(e->w_out, tok, e->b_out, out, C, pt.nslot * T, d, d, d, 0);
         p.T = T; p.S = S; p.Cf = C;
         HIPCHK(launch_gemm(GK_OUTPROJ, p, e->io_pipe, s));
     }

@@ -161,7 +161,8 @@ __global__ void token0_kernel(float* __restrict__ tok, const float* __restrict__
                               const float* __restrict__ text_term, const float* __restrict__ pe,
                               const int64_t* __restrict__ t_dev, int64_t t_scalar, int n_per_pass,
                               int S, int d, int n_time_rows, const int64_t* __restrict__ tmap_dev,
-                              const int* __restrict__ cursor) {
+                              const int* __restrict__ cursor, _Float16* __restrict__ tok_split,
+                              int* __restrict__ range_flag) {
     const int b = blockIdx.x;  // sequence index in [0, n_seq); timesteps repeat per CFG pass
     int64_t t = cursor ? tmap_dev[*cursor] : (t_dev ? t_dev[b % n_per_pass] : t_scalar);
     if (t < 0) t = 0;
@@ -169,18 +170,69 @@ __global__ void token0_kernel(float* __restrict__ tok, const float* __restrict__
     for (int n = threadIdx.x; n < d; n += blockDim.x) {
         float e = time_table[(size_t)t * d + n];
         if (text_term) e += text_term[(size_t)b * d + n];
-        tok[(size_t)b * S * d + n] = e + pe[n];
+        const float v = e + pe[n];
+        if (tok_split) {   // split rows (gemm_h3.hpp): the f16-pipe layers read nothing else
+            _Float16 h, l;
+            split_f16(v, h, l);
+            _Float16* dst = tok_split + (size_t)b * S * (2 * d) + split_pos(n);
+            dst[0] = h; dst[32] = l;
+            if (!(fabsf(v) < 65504.0f) && range_flag) atomicOr(range_flag, 1);
+        } else {
+            tok[(size_t)b * S * d + n] = v;
+        }
     }
+}
+
+// Frame rows for the input projection on the f16 pipe: x [nb][C][T] (T contiguous) -> split rows
+// [nb*T][2*Kp] (Kp = C rounded up to 32, zero padded).  A block transposes 32 frames of one sequence
+// through LDS: reads run along T, writes along the features.
+__global__ __launch_bounds__(256) void pose_rows_split_kernel(const float* __restrict__ x, _Float16* __restrict__ xs,
+                                                             int C, int T, int Kp, int* __restrict__ range_flag) {
+    extern __shared__ float tile[];   // [Kp][33]
+    const int b = blockIdx.y, t0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 frames x 8 feature lanes
+    const float* xb = x + (size_t)b * C * T;
+    bool overflow = false;
+    for (int c = ty; c < Kp; c += 8) {
+        float v = 0.f;
+        if (c < C && t0 + tx < T) v = xb[(size_t)c * T + t0 + tx];
+        overflow |= !(fabsf(v) < 65504.0f);
+        tile[c * 33 + tx] = v;
+    }
+    __syncthreads();
+    const int chunks = Kp >> 3;   // 8 consecutive features per thread-item
+    for (int it = threadIdx.x; it < 32 * chunks; it += 256) {
+        const int fr = it / chunks, c = (it - fr * chunks) * 8;
+        if (t0 + fr >= T) continue;
+        h8 oh, ol;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            _Float16 h, l;
+            split_f16(tile[(c + e) * 33 + fr], h, l);
+            oh[e] = h; ol[e] = l;
+        }
+        _Float16* dst = xs + ((size_t)b * T + t0 + fr) * (2 * Kp) + split_pos(c);
+        *reinterpret_cast<h8*>(dst) = oh;
+        *reinterpret_cast<h8*>(dst + 32) = ol;
+    }
+    if (overflow && range_flag) atomicOr(range_flag, 1);
+}
+
+hipError_t launch_pose_rows_split(const float* x, _Float16* xs, int nb, int C, int T, int Kp, int* range_flag,
+                                  hipStream_t stream) {
+    hipLaunchKernelGGL(pose_rows_split_kernel, dim3((T + 31) / 32, nb), dim3(256), (size_t)Kp * 33 * sizeof(float),
+                       stream, x, xs, C, T, Kp, range_flag);
+    return hipGetLastError();
 }
 
 hipError_t launch_token0(float* tok, const float* time_table, const float* text_term,
                          const float* pe, const int64_t* t_dev, int64_t t_scalar, int n_seq,
                          int n_per_pass, int S, int d, int n_time_rows, hipStream_t stream,
-                         const int64_t* tmap_dev, const int* cursor) {
+                         const int64_t* tmap_dev, const int* cursor, _Float16* tok_split, int* range_flag) {
     // n_seq = B (single pass) or 2B (CFG: conditional rows then unconditional rows); t_dev, when
     // given, holds n_per_pass = B entries shared by both passes.
     hipLaunchKernelGGL(token0_kernel, dim3(n_seq), dim3(256), 0, stream, tok, time_table, text_term,
-                       pe, t_dev, t_scalar, n_per_pass, S, d, n_time_rows, tmap_dev, cursor);
+                       pe, t_dev, t_scalar, n_per_pass, S, d, n_time_rows, tmap_dev, cursor, tok_split, range_flag);
     return hipGetLastError();
 }
 

@@ -97,12 +97,21 @@ int gemm_h3_auto_tile(int M, int N) {
 }
 
 hipError_t launch_gemm_h3(int epi, const H3Params& p, int tile, hipStream_t s) {
-    if (p.K % 32 != 0 || p.N % 8 != 0 || p.M <= 0 || p.N <= 0) return hipErrorInvalidValue;
+    if (p.K % 32 != 0 || (p.N % 8 != 0 && epi != H3_MOTION) || p.M <= 0 || p.N <= 0) return hipErrorInvalidValue;
     if (epi == H3_RESID_LN) {
         if (p.N != 512 || !p.R || !p.ln_g || !p.ln_b || !p.C) return hipErrorInvalidValue;
         return launch_h3_one<H64x512ln, H3_RESID_LN>(p, s);
     }
     if (tile == 0) tile = gemm_h3_auto_tile(p.M, p.N);
+    if (epi == H3_TOKENS || epi == H3_MOTION) {   // the two I/O projections: two tile shapes only
+        if (p.tok_T < 1 || p.tok_S != p.tok_T + 1) return hipErrorInvalidValue;
+        if (epi == H3_TOKENS) {
+            if (!p.pe || !p.Cs) return hipErrorInvalidValue;
+            return tile == 8 ? launch_h3_one<H128x128w8s2, H3_TOKENS>(p, s) : launch_h3_one<H64x128w8s2, H3_TOKENS>(p, s);
+        }
+        if (!p.C) return hipErrorInvalidValue;
+        return tile == 8 ? launch_h3_one<H128x128w8s2, H3_MOTION>(p, s) : launch_h3_one<H64x128w8s2, H3_MOTION>(p, s);
+    }
     switch (epi) {
         case H3_PLAIN: return launch_h3_tiles<H3_PLAIN>(p, tile, s);
         case H3_GELU_SPLIT: return launch_h3_tiles<H3_GELU_SPLIT>(p, tile, s);

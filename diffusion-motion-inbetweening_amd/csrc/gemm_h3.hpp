@@ -300,8 +300,10 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
         const int n = n0 + wn * ROWLEN + cl;     // first of this lane's 4 consecutive columns
         const bool nok = n < p.N;
         float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.bias && nok) bias4 = *reinterpret_cast<const float4*>(p.bias + n);
+        if (EPI != H3_MOTION && p.bias && nok) bias4 = *reinterpret_cast<const float4*>(p.bias + n);
         const int npos = split_pos(n);
+        int mo_b = 0, mo_s = 0;                  // H3_MOTION: (sequence, token) of this lane's first column
+        if constexpr (EPI == H3_MOTION) { mo_b = n / p.tok_S; mo_s = n - mo_b * p.tok_S; }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -321,6 +323,39 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
                     if (pos < p.t_lo || pos >= p.t_hi) continue;
                 }
                 float v[4] = {t.x + bias4.x, t.y + bias4.y, t.z + bias4.z, t.w + bias4.w};
+                if constexpr (EPI == H3_TOKENS) {
+                    const int b = m / p.tok_T, fr = m - b * p.tok_T;
+                    const float4 pe4 = *reinterpret_cast<const float4*>(p.pe + (size_t)(1 + fr) * p.N + n);
+                    v[0] += pe4.x; v[1] += pe4.y; v[2] += pe4.z; v[3] += pe4.w;
+                    h4 oh, ol;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        _Float16 a, b2;
+                        split_f16(v[e], a, b2);
+                        oh[e] = a; ol[e] = b2;
+                        overflow |= !(fabsf(v[e]) < 65504.0f);
+                    }
+                    _Float16* dst = p.Cs + ((size_t)b * p.tok_S + 1 + fr) * (2 * p.N) + npos;
+                    *reinterpret_cast<h4*>(dst) = oh;
+                    *reinterpret_cast<h4*>(dst + 32) = ol;
+                    if (p.tok_dup) {
+                        dst += (size_t)p.tok_dup * p.tok_S * (2 * p.N);
+                        *reinterpret_cast<h4*>(dst) = oh;
+                        *reinterpret_cast<h4*>(dst + 32) = ol;
+                    }
+                    continue;
+                }
+                if constexpr (EPI == H3_MOTION) {
+                    const float bm = p.bias ? p.bias[m] : 0.f;
+                    int b = mo_b, sq = mo_s;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (n + e < p.N && sq > 0)
+                            p.C[((size_t)b * M + m) * p.tok_T + (sq - 1)] = v[e] + bm;
+                        if (++sq == p.tok_S) { sq = 0; ++b; }
+                    }
+                    continue;
+                }
                 const size_t off = (size_t)m * p.ldc + n;
                 // (non-temporal stores were measured: faster in isolation, slower in the layer chain —
                 // the next kernel then finds its input in HBM instead of the memory-side cache)
@@ -377,7 +412,8 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
             }
         }
     }
-    if constexpr (EPI == H3_GELU_SPLIT || EPI == H3_PLAIN_SPLIT || EPI == H3_GELUGRAD_SPLIT || EPI == H3_RESID) {
+    if constexpr (EPI == H3_GELU_SPLIT || EPI == H3_PLAIN_SPLIT || EPI == H3_GELUGRAD_SPLIT || EPI == H3_RESID ||
+                  EPI == H3_TOKENS) {
         if (overflow && p.range_flag) atomicOr(p.range_flag, 1);
     }
     if ((p.dbg & 16) && p.dbg_buf && tid == 0) {

@@ -50,6 +50,10 @@ enum H3Epi {
     H3_GELUGRAD_SPLIT = 4, // Cs = split(v * gelu'(aux[m][n]))   (backward through linear1's GELU)
     H3_RESID_LN = 5,    // x = (v + bias) + R; aux = x (optional); y = LayerNorm(x) -> C (fp32) and Cs (split,
                         // optional); needs a tile that spans the whole row (N == BN)
+    H3_TOKENS = 6,      // input projection: GEMM row m = (b, t) -> token row b*S + 1 + t of Cs:
+                        // Cs = split((v + bias[n]) + pe[1 + t][n]), also written for sequence b + tok_dup (CFG)
+    H3_MOTION = 7,      // output projection, roles swapped: A = weight rows (m = feature c < M), W = token rows
+                        // (n = b*S + s): out[b][c][s - 1] = v + bias[c] for s >= 1  (T contiguous, fp32)
 };
 
 struct H3Params {
@@ -59,6 +63,8 @@ struct H3Params {
     float* C;           // fp32 output [M][ldc]
     _Float16* Cs;       // split output [M][2N]
     const float* R;     // residual [M][ldc]
+    const float* pe;    // H3_TOKENS: positional table [.][N]
+    int tok_T, tok_S, tok_dup;   // H3_TOKENS / H3_MOTION: frames, tokens (= frames + 1) per sequence; CFG copy offset
     const _Float16* Rs; // H3_RESID: the residual as split rows [M][2N] instead (R = hi + lo * 2^-11)
     float* aux;         // optional pre-activation stash [M][ldc]
     const float* ln_g;  // H3_RESID_LN: LayerNorm weight / bias [N], optional (mean, rstd) [M][2]

@@ -70,7 +70,11 @@ hipError_t launch_layernorm_bwd(const float* x, const float* stats, const float*
 hipError_t launch_token0(float* tok, const float* time_table, const float* text_term,
                          const float* pe, const int64_t* t_dev, int64_t t_scalar, int n_seq,
                          int n_per_pass, int S, int d, int n_time_rows, hipStream_t stream,
-                         const int64_t* tmap_dev = nullptr, const int* cursor = nullptr);
+                         const int64_t* tmap_dev = nullptr, const int* cursor = nullptr,
+                         _Float16* tok_split = nullptr /* write split rows instead of fp32 */, int* range_flag = nullptr);
+// x [nb][C][T] -> split frame rows [nb*T][2*Kp] (Kp = C rounded up to 32, zero padded): A operand of the input projection
+hipError_t launch_pose_rows_split(const float* x, _Float16* xs, int nb, int C, int T, int Kp, int* range_flag,
+                                  hipStream_t stream);
 // text_term[b'] rows: conditional rows get proj[b] (already W·c+b), unconditional rows get bias
 hipError_t launch_fill_rows(float* dst, const float* row, int rows, int d, hipStream_t stream);
 hipError_t launch_add2(float* dst, const float* a, const float* b, int64_t n, hipStream_t stream);
