@@ -30,7 +30,8 @@ static hipError_t launch_h3_one(const H3Params& p, hipStream_t stream) {
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    const int tiles = ((p.M + TC::BM - 1) / TC::BM) * ((p.N + TC::BN - 1) / TC::BN);
+    int tiles = ((p.M + TC::BM - 1) / TC::BM) * ((p.N + TC::BN - 1) / TC::BN);
+    if (EPI == H3_PLAIN && p.ksplit > 1) tiles *= p.ksplit;
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(TC::NT), TC::LDS_BYTES, stream, p);
     return hipGetLastError();
 }
@@ -102,6 +103,7 @@ hipError_t launch_gemm_h3(int epi, const H3Params& p, int tile, hipStream_t s) {
         if (p.N != 512 || !p.R || !p.ln_g || !p.ln_b || !p.C) return hipErrorInvalidValue;
         return launch_h3_one<H64x512ln, H3_RESID_LN>(p, s);
     }
+    if (p.ksplit > 1 && (epi != H3_PLAIN || tile == 20 || p.K / 32 < p.ksplit)) return hipErrorInvalidValue;
     if (tile == 0) tile = gemm_h3_auto_tile(p.M, p.N);
     if (epi == H3_TOKENS || epi == H3_MOTION) {   // the two I/O projections: two tile shapes only
         if (p.tok_T < 1 || p.tok_S != p.tok_T + 1) return hipErrorInvalidValue;

@@ -73,6 +73,10 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
     const int wm = wave / TC::WN, wn = wave % TC::WN;
 
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (M - m_begin + BM - 1) / BM;
+    int kslice = 0, nslice = 1;                       // split-K (H3_PLAIN): slice of the K loop this block owns
+    if constexpr (EPI == H3_PLAIN) {
+        if (p.ksplit > 1) { nslice = p.ksplit; kslice = block_id % nslice; block_id /= nslice; }
+    }
     const int bid = xcd_remap(block_id, tiles_m * tiles_n);
     const int m0 = m_begin + (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
 
@@ -136,16 +140,17 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
     const int a_row = (wm * TM * 32 + l31) * 128;            // + i * 32 * 128
     const int w_row = BM * 128 + (wn * TN * 32 + l31) * 128;  // + j * 32 * 128
 
-    const int nk = p.K / 32;
+    const int nk_all = p.K / 32;
+    const int kt0 = (int)((long)nk_all * kslice / nslice), nk = (int)((long)nk_all * (kslice + 1) / nslice);
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s)
-        if (s < nk) issue(s, s);
-    if (NSTAGE == 3 && nk > 1) wait_vmcnt<PW>(); else wait_vmcnt<0>();
+        if (kt0 + s < nk) issue(kt0 + s, s);
+    if (NSTAGE == 3 && nk - kt0 > 1) wait_vmcnt<PW>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
 
     if (p.dbg & 16) t_loop = __builtin_readcyclecounter();
     int cur = 0, nxt = NSTAGE - 1;   // stage being multiplied / stage being filled
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = kt0; kt < nk; ++kt) {
         const bool more = kt + NSTAGE - 1 < nk;
         if (more && !(p.dbg & 1)) issue(kt + NSTAGE - 1, nxt);
         const char* st = lds + cur * STAGE;
@@ -300,7 +305,7 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
         const int n = n0 + wn * ROWLEN + cl;     // first of this lane's 4 consecutive columns
         const bool nok = n < p.N;
         float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (EPI != H3_MOTION && p.bias && nok) bias4 = *reinterpret_cast<const float4*>(p.bias + n);
+        if (EPI != H3_MOTION && p.bias && nok && kslice == 0) bias4 = *reinterpret_cast<const float4*>(p.bias + n);
         const int npos = split_pos(n);
         int mo_b = 0, mo_s = 0;                  // H3_MOTION: (sequence, token) of this lane's first column
         if constexpr (EPI == H3_MOTION) { mo_b = n / p.tok_S; mo_s = n - mo_b * p.tok_S; }
@@ -360,7 +365,7 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
                 // (non-temporal stores were measured: faster in isolation, slower in the layer chain —
                 // the next kernel then finds its input in HBM instead of the memory-side cache)
                 if constexpr (EPI == H3_PLAIN) {
-                    *reinterpret_cast<float4*>(p.C + off) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(p.C + (size_t)kslice * p.slice_stride + off) = make_float4(v[0], v[1], v[2], v[3]);
                 } else if constexpr (EPI == H3_RESID) {
                     if (p.Rs) {
                         const _Float16* rs = p.Rs + (size_t)m * (2 * p.N) + npos;

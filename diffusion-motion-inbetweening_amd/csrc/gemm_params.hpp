@@ -63,6 +63,8 @@ struct H3Params {
     float* C;           // fp32 output [M][ldc]
     _Float16* Cs;       // split output [M][2N]
     const float* R;     // residual [M][ldc]
+    int ksplit;         // H3_PLAIN only: > 1 = that many blocks per tile, each over a slice of K; slice s writes its
+    long slice_stride;  // partial sums to C + s * slice_stride (the consumer adds the slices); bias joins slice 0
     const float* pe;    // H3_TOKENS: positional table [.][N]
     int tok_T, tok_S, tok_dup;   // H3_TOKENS / H3_MOTION: frames, tokens (= frames + 1) per sequence; CFG copy offset
     const _Float16* Rs; // H3_RESID: the residual as split rows [M][2N] instead (R = hi + lo * 2^-11)

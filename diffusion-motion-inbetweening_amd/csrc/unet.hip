@@ -19,6 +19,7 @@
 #include <string>
 #include <vector>
 
+#include <cstdlib>
 #include "common.hpp"
 #include "gemm_h3.hpp"
 #include "kernels.hpp"
@@ -85,8 +86,18 @@ __global__ void unet_emb_kernel(float* __restrict__ emb, const float* __restrict
 
 // ---- GroupNorm statistics: one block per (sequence, group); two-pass mean / biased variance over the
 // (C/8 channels) x (Tv frames) of the group (nn.GroupNorm(8, C), eps 1e-5) --------------------------------
+// x may arrive as nsl partial sums (split-K slices of the convolution, sl floats apart), added in slice order
+__device__ __forceinline__ float4 load_slices(const float* __restrict__ p, int nsl, size_t sl) {
+    float4 v = *reinterpret_cast<const float4*>(p);
+    for (int s = 1; s < nsl; ++s) {
+        const float4 w = *reinterpret_cast<const float4*>(p + s * sl);
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    return v;
+}
+
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, float* __restrict__ stats,
-                                                       int C, int Tp, int h, int Tv) {
+                                                       int C, int Tp, int h, int Tv, int nsl, size_t sl) {
     __shared__ float red[4];
     const int seq = blockIdx.x, g = blockIdx.y, cg = C / NG;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -96,7 +107,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
     float s = 0.f;
     for (int i = tid; i < total; i += 256) {
         const int r = i / q4, c4 = i - r * q4;
-        const float4 v = *reinterpret_cast<const float4*>(base + (size_t)r * C + c4 * 4);
+        const float4 v = load_slices(base + (size_t)r * C + c4 * 4, nsl, sl);
         s += (v.x + v.y) + (v.z + v.w);
     }
     s = wave_sum(s);
@@ -107,7 +118,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
     float q = 0.f;
     for (int i = tid; i < total; i += 256) {
         const int r = i / q4, c4 = i - r * q4;
-        const float4 v = *reinterpret_cast<const float4*>(base + (size_t)r * C + c4 * 4);
+        const float4 v = load_slices(base + (size_t)r * C + c4 * 4, nsl, sl);
         const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
         q += (a * a + b * b) + (c * c + d * d);
     }
@@ -127,7 +138,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ ss, const float* __restrict__ resid,
                                                        float* __restrict__ yf, _Float16* __restrict__ ys, int ys_ld,
-                                                       int* __restrict__ range_flag, int C, int Tp, int h, int Tv, int ss_ld) {
+                                                       int* __restrict__ range_flag, int C, int Tp, int h, int Tv, int ss_ld,
+                                                       int nsl, size_t sl) {
     const int seq = blockIdx.y;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= Tv) return;
@@ -138,7 +150,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     for (int c = lane * 4; c < C; c += 256) {
         const int g = c / cg;
         const float mean = stats[((size_t)seq * NG + g) * 2], rstd = stats[((size_t)seq * NG + g) * 2 + 1];
-        const float4 v = *reinterpret_cast<const float4*>(x + row * C + c);
+        const float4 v = load_slices(x + row * C + c, nsl, sl);
         const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
         const float4 be = *reinterpret_cast<const float4*>(beta + c);
         float y[4] = {(v.x - mean) * rstd * ga.x + be.x, (v.y - mean) * rstd * ga.y + be.y,
@@ -233,6 +245,7 @@ struct UnetModel {
     bool finalized = false;
     // workspace
     float *emb_h = nullptr, *cvec = nullptr, *cm = nullptr, *ss = nullptr, *stats = nullptr;
+    int ksplit_ok = 1;   // CMDI_UNET_KSPLIT=0: no split-K at the coarse levels
     float *tw_all = nullptr, *tb_all = nullptr;   // the 16 time_mlp.1 Linears stacked: ONE GEMM per evaluation
     int ss_ld = 0;
     float *F1[4] = {}, *F2[4] = {}, *Xa[4] = {}, *Xb[4] = {};
@@ -337,6 +350,7 @@ hipError_t pack(UnetModel* u, Conv& c, hipStream_t s) {
 UnetModel* unet_new(int n_feats, int added, int dim, const int mults[4], int max_seq, bool text) {
     UnetModel* u = new UnetModel();
     u->J = n_feats; u->added = added; u->dim = dim; u->max_seq = max_seq; u->text = text;
+    if (const char* v = std::getenv("CMDI_UNET_KSPLIT")) u->ksplit_ok = std::atoi(v);
     u->C[0] = n_feats + added;
     for (int i = 0; i < 4; ++i) u->C[i + 1] = dim * mults[i];
     u->Cin0p = (u->C[0] + 31) / 32 * 32;
@@ -369,7 +383,8 @@ UnetModel* unet_new(int n_feats, int added, int dim, const int mults[4], int max
     rc |= ualloc_t(u, &u->ss, ns * 16 * 2 * Cw) | ualloc_t(u, &u->stats, ns * NG * 2);
     for (int l = 0; l < 4 && !rc; ++l) {
         const size_t rows = ns * (size_t)(256 >> l);
-        rc |= alloc_rows(u, &u->F1[l], rows, Cw) | alloc_rows(u, &u->F2[l], rows, Cw);
+        const size_t frows = rows > 8192 ? rows : 8192;   // split-K: up to 4 slices of <= 2048 rows, 2 of <= 4096
+        rc |= alloc_rows(u, &u->F1[l], frows, Cw) | alloc_rows(u, &u->F2[l], frows, Cw);
         rc |= alloc_rows(u, &u->Xa[l], rows, Cw) | alloc_rows(u, &u->Xb[l], rows, Cw);
         rc |= alloc_rows(u, &u->H1S[l], rows, 2 * (size_t)Cw) | alloc_rows(u, &u->Sa[l], rows, 2 * (size_t)Cw);
         rc |= alloc_rows(u, &u->Sb[l], rows, 2 * (size_t)Cw) | alloc_rows(u, &u->CAT[l], rows, 4 * (size_t)Cw);
@@ -473,7 +488,7 @@ inline Lvl lvl(int l) { return {256 >> l, 16 >> l, TPAD >> l}; }
 // conv as GEMM over rows; `a` points at row 0 of the input frame buffer (column block already applied)
 int conv_rows(UnetModel* u, const Conv& c, const _Float16* ws, const _Float16* a, int a_ld, int m_rows, int level_out,
               int taps, int pad, int a_mul, int c_mul, int c_add, float* out_f, _Float16* out_s, int cs_ld,
-              const float* resid, hipStream_t s) {
+              const float* resid, hipStream_t s, int* nsl_out = nullptr) {
     const Lvl lo = lvl(level_out);
     H3Params p{};
     p.A = a - (ptrdiff_t)pad * a_ld;
@@ -482,21 +497,34 @@ int conv_rows(UnetModel* u, const Conv& c, const _Float16* ws, const _Float16* a
     p.a_ld = a_ld; p.a_row_mul = a_mul; p.taps = taps; p.cpt = c.cin_p / 32;
     p.c_row_mul = c_mul; p.c_row_add = c_add; p.tp = lo.Tp; p.t_lo = lo.h; p.t_hi = lo.h + lo.Tv;
     p.cs_ld = cs_ld; p.range_flag = u->range_flag;
-    int kind;
+    int kind, tile = 0;
     if (resid) { kind = H3_RESID; p.R = resid; p.C = out_f; p.Cs = out_s; }
     else if (out_s) { kind = H3_PLAIN_SPLIT; p.Cs = out_s; p.aux = out_f; }
-    else { kind = H3_PLAIN; p.C = out_f; }
-    UCHK(launch_gemm_h3(kind, p, 0, s));
+    else {
+        kind = H3_PLAIN; p.C = out_f;
+        // coarse levels: too few 128x128 tiles for the chip's 512 block slots and a long K (taps * cin) ->
+        // 2 or 4 blocks per tile, each over a slice of K; slice s leaves its partial sums in out_f + s * M * N
+        // and the GroupNorm kernels add the slices in order (deterministic; atomics were measured slower)
+        const long tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+        if (nsl_out && u->ksplit_ok && tiles <= 256 && p.K >= 2048) {
+            p.ksplit = tiles <= 128 ? 4 : 2;
+            p.slice_stride = (long)p.M * p.N;
+            tile = 8;
+        }
+    }
+    if (nsl_out) *nsl_out = p.ksplit > 1 ? p.ksplit : 1;
+    UCHK(launch_gemm_h3(kind, p, tile, s));
     return 0;
 }
 
-int group_norm(UnetModel* u, const float* x, const GN& n, const float* ss, const float* resid, float* yf, _Float16* ys,
-               int ys_ld, int nseq, int level, hipStream_t s) {
+int group_norm(UnetModel* u, const float* x, int nsl, const GN& n, const float* ss, const float* resid, float* yf,
+               _Float16* ys, int ys_ld, int nseq, int level, hipStream_t s) {
     const Lvl L = lvl(level);
     const int C = u->C[1];
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(nseq, NG), dim3(256), 0, s, x, u->stats, C, L.Tp, L.h, L.Tv);
+    const size_t sl = (size_t)nseq * L.Tp * C;   // floats between the split-K slices of x
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nseq, NG), dim3(256), 0, s, x, u->stats, C, L.Tp, L.h, L.Tv, nsl, sl);
     hipLaunchKernelGGL(gn_apply_kernel, dim3((L.Tv + 3) / 4, nseq), dim3(256), 0, s, x, u->stats, n.g, n.b, ss, resid, yf,
-                       ys, ys_ld, u->range_flag, C, L.Tp, L.h, L.Tv, u->ss_ld);
+                       ys, ys_ld, u->range_flag, C, L.Tp, L.h, L.Tv, u->ss_ld, nsl, sl);
     UCHK(hipGetLastError());
     return 0;
 }
@@ -507,13 +535,14 @@ int res_block(UnetModel* u, const ResBlock& r, const _Float16* xs, int a_ld, con
     const Lvl L = lvl(level);
     const int rows = nseq * L.Tp, C = r.cout;
     const float* ss = u->ss + r.ss_off;   // (scale | shift) = Linear(Mish(c)), computed for all blocks up front
-    if (conv_rows(u, r.c1, r.c1.ws, xs, a_ld, rows, level, 5, 2, 1, 0, 0, u->F1[level], nullptr, 0, nullptr, s)) return -1;
-    if (group_norm(u, u->F1[level], r.n1, ss, nullptr, nullptr, u->H1S[level], 2 * C, nseq, level, s)) return -1;
-    if (conv_rows(u, r.c2, r.c2.ws, u->H1S[level], 2 * C, rows, level, 5, 2, 1, 0, 0, u->F2[level], nullptr, 0, nullptr, s)) return -1;
+    int n1 = 1, n2 = 1;   // split-K slices the two convolutions left behind
+    if (conv_rows(u, r.c1, r.c1.ws, xs, a_ld, rows, level, 5, 2, 1, 0, 0, u->F1[level], nullptr, 0, nullptr, s, &n1)) return -1;
+    if (group_norm(u, u->F1[level], n1, r.n1, ss, nullptr, nullptr, u->H1S[level], 2 * C, nseq, level, s)) return -1;
+    if (conv_rows(u, r.c2, r.c2.ws, u->H1S[level], 2 * C, rows, level, 5, 2, 1, 0, 0, u->F2[level], nullptr, 0, nullptr, s, &n2)) return -1;
     if (!r.res.ws) {   // identity residual, added behind the Mish
-        return group_norm(u, u->F2[level], r.n2, nullptr, xf, out_f, out_s, out_ld, nseq, level, s);
+        return group_norm(u, u->F2[level], n2, r.n2, nullptr, xf, out_f, out_s, out_ld, nseq, level, s);
     }
-    if (group_norm(u, u->F2[level], r.n2, nullptr, nullptr, u->F1[level], nullptr, 0, nseq, level, s)) return -1;
+    if (group_norm(u, u->F2[level], n2, r.n2, nullptr, nullptr, u->F1[level], nullptr, 0, nseq, level, s)) return -1;
     return conv_rows(u, r.res, r.res.ws, xs, a_ld, rows, level, 1, 0, 1, 0, 0, out_f, out_s, out_ld, u->F1[level], s);
 }
 
@@ -585,8 +614,9 @@ int unet_forward(UnetModel* u, const float* x, const float* obs, const uint8_t* 
     }
     // ---- final_conv: Conv1dBlock(k=5) then Conv1d(dim, J, 1) -------------------------------------------------
     const int rows0 = nseq * 256;
-    if (conv_rows(u, u->fin, u->fin.ws, u->Sa[0], 2 * Cw, rows0, 0, 5, 2, 1, 0, 0, u->F1[0], nullptr, 0, nullptr, s)) return -1;
-    if (group_norm(u, u->F1[0], u->fin_n, nullptr, nullptr, nullptr, u->H1S[0], 2 * Cw, nseq, 0, s)) return -1;
+    int nfin = 1;
+    if (conv_rows(u, u->fin, u->fin.ws, u->Sa[0], 2 * Cw, rows0, 0, 5, 2, 1, 0, 0, u->F1[0], nullptr, 0, nullptr, s, &nfin)) return -1;
+    if (group_norm(u, u->F1[0], nfin, u->fin_n, nullptr, nullptr, nullptr, u->H1S[0], 2 * Cw, nseq, 0, s)) return -1;
     if (conv_rows(u, u->outc, u->outc.ws, u->H1S[0], 2 * Cw, rows0, 0, 1, 0, 1, 0, 0, u->outF, nullptr, 0, nullptr, s)) return -1;
     hipLaunchKernelGGL(unet_output_kernel, dim3((T + 255) / 256, u->J, nseq), dim3(256), 0, s, u->outF, out, u->J, T, u->Np,
                        256, 16);

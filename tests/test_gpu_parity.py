@@ -497,6 +497,7 @@ def test_unet_forward_vs_reference(cases):
     kw = dict(obs_x0=tt(inp["obs_x0"]), obs_mask=tt(inp["obs_mask"]))
     y = {"text_embed": tt(inp["enc_text"])}
     oc = model(x, t, y=y, **kw).cpu().numpy()
+    assert np.array_equal(oc, model(x, t, y=y, **kw).cpu().numpy())   # split-K accumulation is order-independent
     ou = model(x, t, y=dict(y, uncond=True), **kw).cpu().numpy()
     wrapped = sub("model.cfg_sampler").ClassifierFreeSampleModel(model)
     cfg = wrapped(x, t, y=dict(y, text_scale=tt(inp["text_scale"])), **kw).cpu().numpy()
