@@ -246,6 +246,7 @@ struct UnetModel {
     // workspace
     float *emb_h = nullptr, *cvec = nullptr, *cm = nullptr, *ss = nullptr, *stats = nullptr;
     int ksplit_ok = 1;   // CMDI_UNET_KSPLIT=0: no split-K at the coarse levels
+    int big_tile = 0;    // CMDI_UNET_TILE: gemm_h3 tile id for the long-K convolutions that are not split
     float *tw_all = nullptr, *tb_all = nullptr;   // the 16 time_mlp.1 Linears stacked: ONE GEMM per evaluation
     int ss_ld = 0;
     float *F1[4] = {}, *F2[4] = {}, *Xa[4] = {}, *Xb[4] = {};
@@ -351,6 +352,7 @@ UnetModel* unet_new(int n_feats, int added, int dim, const int mults[4], int max
     UnetModel* u = new UnetModel();
     u->J = n_feats; u->added = added; u->dim = dim; u->max_seq = max_seq; u->text = text;
     if (const char* v = std::getenv("CMDI_UNET_KSPLIT")) u->ksplit_ok = std::atoi(v);
+    if (const char* v = std::getenv("CMDI_UNET_TILE")) u->big_tile = std::atoi(v);
     u->C[0] = n_feats + added;
     for (int i = 0; i < 4; ++i) u->C[i + 1] = dim * mults[i];
     u->Cin0p = (u->C[0] + 31) / 32 * 32;
@@ -513,6 +515,7 @@ int conv_rows(UnetModel* u, const Conv& c, const _Float16* ws, const _Float16* a
         }
     }
     if (nsl_out) *nsl_out = p.ksplit > 1 ? p.ksplit : 1;
+    if (!tile && u->big_tile && p.K >= 2048) tile = u->big_tile;
     UCHK(launch_gemm_h3(kind, p, tile, s));
     return 0;
 }
