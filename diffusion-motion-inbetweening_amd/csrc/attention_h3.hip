@@ -522,9 +522,10 @@ __global__ __launch_bounds__(64 * BW, 1) void attn_bwd_q_h3_kernel(const _Float1
 
 // ---- dK / dV: wave = 32 keys, loop over query tiles ------------------------------------------------------
 // Two instantiations (the fused form needs ~650 registers per lane and spills): WHICH = 0 computes dK (needs
-// K, V fragments and the two-accumulator dK), WHICH = 1 computes dV (K fragments only, one accumulator).
+// K, V fragments and the two-accumulator dK: 512 registers, one wave per SIMD), WHICH = 1 computes dV (K fragments
+// only, one accumulator: fits 248 registers, so two blocks share a CU).
 template <int WHICH>
-__global__ __launch_bounds__(64 * BW, 1) void attn_bwd_kv_h3_kernel(const _Float16* __restrict__ qkv,
+__global__ __launch_bounds__(64 * BW, WHICH == 1 ? 2 : 1) void attn_bwd_kv_h3_kernel(const _Float16* __restrict__ qkv,
                                                                     const _Float16* __restrict__ d_o,
                                                                     const float* __restrict__ row_stats,
                                                                     const float* __restrict__ rowdot,
