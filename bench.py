@@ -89,7 +89,7 @@ def build_unet(dev, seed=0):
     sd = weights.to_torch(weights.fill_like(shapes, seed))
     sd.update({k: v for k, v in model.state_dict().items() if k.endswith(".pe")})
     mu.load_model_wo_clip(model, sd)
-    return model.to(dev).eval(), None
+    return model.to(dev).eval(), sd
 
 
 def build_model(cfg_on, dev, seed=0):
@@ -146,6 +146,55 @@ def cpu_baseline(sd, B, n_steps=3):
             "sample": f"{n_steps} full CFG DDPM steps at B={B}x{T_FRAMES}x{N_FEATS} after 1 warm-up "
                       f"(oracle/torch_cpu_port.py: torch {torch.__version__} CPU nn.TransformerEncoder, the "
                       f"reference's own denoiser arithmetic; {best} intra-op threads picked from a calibration "
+                      f"on a host with {host} logical CPUs)"}
+
+
+def cpu_baseline_unet(sd, B, n_steps=2):
+    """The same for --config unet: MDM_UNET on torch's CPU conv1d / group_norm / mish kernels
+    (oracle/torch_cpu_port.py::TorchCpuUNET), two sequential CFG passes + the posterior update."""
+    from oracle import diffusion_oracle as do
+    from oracle.torch_cpu_port import TorchCpuUNET
+    rng = np.random.default_rng(1)
+    m = TorchCpuUNET(sd)
+    sch = do.Schedule(do.named_betas("cosine", 1000), do.space_timesteps(1000, [1000]))
+    shape = (B, N_FEATS, 1, T_FRAMES)
+    x = rng.standard_normal(shape).astype(np.float32)
+    obs = torch.from_numpy(rng.standard_normal(shape).astype(np.float32))
+    mask = torch.zeros(shape, dtype=torch.bool)
+    mask[..., ::5] = True
+    enc = torch.from_numpy(rng.standard_normal((B, 512)).astype(np.float32))
+    scale = torch.full((B,), 2.5)
+    nz = rng.standard_normal((n_steps + 1,) + shape).astype(np.float32)
+    host = os.cpu_count() or 1
+    prev = torch.get_num_threads()
+    best, best_dt = host, None
+    t999 = torch.full((B,), 999, dtype=torch.long)
+    xs = torch.from_numpy(x[:4])
+    for n in sorted({host, min(host, 64), min(host, 32), min(host, 16)}, reverse=True):
+        torch.set_num_threads(n)
+        m.forward(xs, t999[:4], enc[:4], False, obs[:4], mask[:4])   # warm this thread count (4 sequences)
+        t0 = time.perf_counter()
+        m.forward(xs, t999[:4], enc[:4], False, obs[:4], mask[:4])
+        dt = time.perf_counter() - t0
+        if best_dt is None or dt < best_dt:
+            best, best_dt = n, dt
+    torch.set_num_threads(best)
+
+    def one(xc, i, k):
+        t = torch.full((B,), i, dtype=torch.long)
+        hat, _, _ = m.forward_cfg(torch.from_numpy(xc), t, enc, scale, obs, mask)
+        return do.step_update(sch, i, xc, hat.numpy(), nz[k])[0]
+
+    xc = one(x, 999, 0)  # warm-up
+    t0 = time.perf_counter()
+    for k in range(n_steps):
+        xc = one(xc, 998 - k, k + 1)
+    dt = time.perf_counter() - t0
+    torch.set_num_threads(prev)
+    return {"value": n_steps / dt, "unit": "denoising steps/s", "cores": best, "kind": "port",
+            "sample": f"{n_steps} full CFG DDPM steps of MDM_UNET at B={B}x{T_FRAMES}x{N_FEATS} after 1 warm-up "
+                      f"(oracle/torch_cpu_port.py::TorchCpuUNET: torch {torch.__version__} CPU conv1d / group_norm / "
+                      f"mish, the reference's own layer kernels; {best} intra-op threads picked from a calibration "
                       f"on a host with {host} logical CPUs)"}
 
 
@@ -267,8 +316,9 @@ def main():
         "allgather_ms": gather_ms,
     }
 
-    if rank == 0 and not args.no_roofline and not is_unet:
-        # instrumented second pass over the same K steps: HIP events around every in_proj GEMM
+    if rank == 0 and not args.no_roofline:
+        # instrumented second pass over the same K steps: HIP events around every in_proj GEMM (transformer) or
+        # around one level-0 k=5 convolution GEMM per evaluation (U-Net: downs.0.1 blocks.1)
         eng.profile_enable(True)
         eng.sample_loop(x, K - 1, 0, sampler=sampler, seed=seed, first_sample=first)
         torch.cuda.synchronize(dev)
@@ -281,13 +331,16 @@ def main():
         if pmc.exists():
             traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
         ach = flop_launch / avg_s / 1e12
+        if is_unet:
+            traffic = None   # no PMC pass committed for this shape
         if split:
             # algorithmic flops = 2MNK of the fp32 product; the kernel executes 3 f16 MFMA products
             # per algorithmic product, so its ceiling is the dense f16 peak / 3
             peak = F16_MFMA_PEAK_TFLOPS / 3.0
+            what = ("unet.downs.0.1.blocks.1 Conv1d k=5 as a tap-shifted GEMM" if is_unet else "self_attn.in_proj")
             out["roofline"] = {
-                "kernel": f"gemm_h3_kernel (self_attn.in_proj, M={m} N={n} K={k}, 3x v_mfma_f32_32x32x16_f16 "
-                          "per fp32-equivalent product, split-rows output)",
+                "kernel": f"gemm_h3_kernel ({what}, M={m} N={n} K={k}, 3x v_mfma_f32_32x32x16_f16 "
+                          "per fp32-equivalent product" + ("" if is_unet else ", split-rows output") + ")",
                 "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                 "traffic": traffic, "launches": launches, "avg_launch_us": avg_s * 1e6,
                 "flops_per_launch": flop_launch, "executed_f16_tflops": 3.0 * ach,
@@ -303,8 +356,8 @@ def main():
             }
     if world > 1:
         dist.barrier()
-    if rank == 0 and world == 1 and not args.no_cpu and not is_unet:
-        out["cpu_baseline"] = cpu_baseline(sd, B)
+    if rank == 0 and world == 1 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline_unet(sd, B) if is_unet else cpu_baseline(sd, B)
         out["gpu_over_cpu"] = steps_per_s / out["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -380,8 +380,22 @@ int mdm_forward(cmdi_engine* e, const float* x, const int64_t* t_dev, int64_t t_
         if (keep) return fail(CMDI_E_STATE, "UNET engine: no activation stash / VJP");
         HIPCHK(launch_unet_emb(e->uemb, e->time_table, e->have_text ? e->text_term : nullptr, t_dev, t_scalar,
                                n_seq, B, d, e->n_time_rows, s));
-        if (unet_forward(e->unet, x, e->have_obs ? e->obs_x0 : nullptr, e->have_obs ? e->obs_mask : nullptr,
-                         e->uemb, B, n_seq, T, out_buf, s) != 0)
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        int mnk[3] = {0, 0, 0};
+        if (e->profile) {   // bench: HIP events around one level-0 convolution GEMM per evaluation
+            if (e->ev_used + 2 > e->ev_pool.size()) {
+                hipEvent_t a, b;
+                HIPCHK(hipEventCreate(&a));
+                HIPCHK(hipEventCreate(&b));
+                e->ev_pool.push_back(a);
+                e->ev_pool.push_back(b);
+            }
+            ev0 = e->ev_pool[e->ev_used]; ev1 = e->ev_pool[e->ev_used + 1];
+        }
+        const int urc = unet_forward(e->unet, x, e->have_obs ? e->obs_x0 : nullptr, e->have_obs ? e->obs_mask : nullptr,
+                                     e->uemb, B, n_seq, T, out_buf, s, ev0, ev1, mnk);
+        if (e->profile && mnk[0]) { e->ev_used += 2; e->prof_m = mnk[0]; e->prof_n = mnk[1]; e->prof_k = mnk[2]; }
+        if (urc != 0)
             return fail(CMDI_E_HIP, std::string("UNET: ") + unet_error(e->unet));
         e->stash_valid = false;
         return CMDI_OK;

@@ -95,8 +95,10 @@ int64_t unet_bytes(const UnetModel* u);
 void unet_free(UnetModel* u);
 int unet_load_weight(UnetModel* u, const char* name, const float* d_src, int64_t numel, hipStream_t s);
 int unet_finalize(UnetModel* u, hipStream_t s);
+// ev0 / ev1 (bench): recorded around the second k=5 convolution GEMM of downs.0.1; its M, N, K land in probe_mnk
 int unet_forward(UnetModel* u, const float* x, const float* obs, const uint8_t* mask, const float* emb, int B, int nseq,
-                 int T, float* out, hipStream_t s);
+                 int T, float* out, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
+                 int* probe_mnk = nullptr);
 int unet_range_flag(UnetModel* u, int* flag, hipStream_t s);
 hipError_t launch_unet_emb(float* emb, const float* time_table, const float* text_term, const int64_t* t_dev,
                            int64_t t_scalar, int n_seq, int n_per_pass, int d, int n_time_rows, hipStream_t stream);

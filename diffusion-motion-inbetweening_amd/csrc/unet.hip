@@ -246,6 +246,8 @@ struct UnetModel {
     // workspace
     float *emb_h = nullptr, *cvec = nullptr, *cm = nullptr, *ss = nullptr, *stats = nullptr;
     int ksplit_ok = 1;   // CMDI_UNET_KSPLIT=0: no split-K at the coarse levels
+    hipEvent_t probe_ev[2] = {nullptr, nullptr};   // bench: events around ONE convolution GEMM (downs.0.1, blocks.1)
+    int probe_mnk[3] = {0, 0, 0};
     int big_tile = 0;    // CMDI_UNET_TILE: gemm_h3 tile id for the long-K convolutions that are not split
     float *tw_all = nullptr, *tb_all = nullptr;   // the 16 time_mlp.1 Linears stacked: ONE GEMM per evaluation
     int ss_ld = 0;
@@ -541,7 +543,13 @@ int res_block(UnetModel* u, const ResBlock& r, const _Float16* xs, int a_ld, con
     int n1 = 1, n2 = 1;   // split-K slices the two convolutions left behind
     if (conv_rows(u, r.c1, r.c1.ws, xs, a_ld, rows, level, 5, 2, 1, 0, 0, u->F1[level], nullptr, 0, nullptr, s, &n1)) return -1;
     if (group_norm(u, u->F1[level], n1, r.n1, ss, nullptr, nullptr, u->H1S[level], 2 * C, nseq, level, s)) return -1;
+    const bool probe = u->probe_ev[0] && &r == &u->down[0][1];
+    if (probe) {
+        UCHK(hipEventRecord(u->probe_ev[0], s));
+        u->probe_mnk[0] = nseq * L.Tv; u->probe_mnk[1] = C; u->probe_mnk[2] = 5 * r.c2.cin_p;   // algorithmic: valid frames only
+    }
     if (conv_rows(u, r.c2, r.c2.ws, u->H1S[level], 2 * C, rows, level, 5, 2, 1, 0, 0, u->F2[level], nullptr, 0, nullptr, s, &n2)) return -1;
+    if (probe) UCHK(hipEventRecord(u->probe_ev[1], s));
     if (!r.res.ws) {   // identity residual, added behind the Mish
         return group_norm(u, u->F2[level], n2, r.n2, nullptr, xf, out_f, out_s, out_ld, nseq, level, s);
     }
@@ -554,7 +562,9 @@ int res_block(UnetModel* u, const ResBlock& r, const _Float16* xs, int a_ld, con
 // x, obs [B, J, T] fp32, mask u8 (obs / mask may be null when added == 0), emb [nseq, dim] fp32 (time embedding +
 // text term per sequence), out [nseq, J, T].  nseq = B or 2B (CFG: [cond | uncond], same input rows).
 int unet_forward(UnetModel* u, const float* x, const float* obs, const uint8_t* mask, const float* emb, int B, int nseq,
-                 int T, float* out, hipStream_t s) {
+                 int T, float* out, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int* probe_mnk) {
+    u->probe_ev[0] = ev0; u->probe_ev[1] = ev1;
+    struct ProbeOut { UnetModel* u; int* o; ~ProbeOut() { if (o) { o[0] = u->probe_mnk[0]; o[1] = u->probe_mnk[1]; o[2] = u->probe_mnk[2]; } } } probe_out{u, probe_mnk};
     if (!u->finalized) { u->err = "UNET weights not finalized"; return -1; }
     if (nseq > u->max_seq || T > TPAD || T < 1) { u->err = "batch / frames exceed the UNET workspace"; return -1; }
     if (u->added && (!obs || !mask)) { u->err = "a keyframe-conditioned UNET needs obs_x0 and obs_mask"; return -1; }

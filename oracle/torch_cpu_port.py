@@ -58,3 +58,72 @@ class TorchCpuMDM(nn.Module):
         oc = self.forward(x, t, enc_text, uncond=False)
         ou = self.forward(x, t, enc_text, uncond=True)
         return ou + text_scale.view(-1, 1, 1, 1) * (oc - ou), oc, ou
+
+
+class TorchCpuUNET(nn.Module):
+    """MDM_UNET (keyframe-conditioned, AdaGN) on torch's CPU kernels — the reference's TemporalUnet IS a stack of
+    nn.Conv1d / nn.GroupNorm / nn.Mish / nn.ConvTranspose1d (model/mdm_unet.py:15-99,165-358), so the functional
+    calls below run the same oneDNN / native kernels as the reference's CPU path.  Follows MDM_UNET.forward /
+    forward_core (:767-849) and TemporalUnet.forward (:318-358); weights by the reference's state-dict names.
+    Pinned by tests/test_oracle_golden.py::test_torch_cpu_unet_matches_golden."""
+
+    def __init__(self, sd: dict):
+        super().__init__()
+        self.w = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)) if isinstance(v, np.ndarray)
+                  else v.detach().float().cpu() for k, v in sd.items()}
+        self.n_levels = 1 + max(int(k.split(".")[2]) for k in self.w if k.startswith("unet.downs."))
+        self.pe = self.w["sequence_pos_encoder.pe"].reshape(-1, self.w["sequence_pos_encoder.pe"].shape[-1])
+
+    def _block(self, p, x, ss=None):
+        F, w = nn.functional, self.w
+        pre = "block1" if ss is not None else "block"
+        cw = w[f"{p}.{pre}.0.weight"]
+        h = F.conv1d(x, cw, w[f"{p}.{pre}.0.bias"], padding=cw.shape[2] // 2)
+        h = F.group_norm(h, 8, w[f"{p}.{pre}.2.weight"], w[f"{p}.{pre}.2.bias"])
+        if ss is not None:
+            scale, shift = ss.chunk(2, dim=1)
+            h = h * (1 + scale[:, :, None]) + shift[:, :, None]
+        return F.mish(h)
+
+    def _res(self, p, x, c):
+        F, w = nn.functional, self.w
+        ss = F.linear(F.mish(c), w[f"{p}.time_mlp.1.weight"], w[f"{p}.time_mlp.1.bias"])
+        h = self._block(f"{p}.blocks.1", self._block(f"{p}.blocks.0", x, ss))
+        if f"{p}.residual_conv.weight" in w:
+            x = F.conv1d(x, w[f"{p}.residual_conv.weight"], w[f"{p}.residual_conv.bias"])
+        return h + x
+
+    @torch.no_grad()
+    def forward(self, x, t, enc_text=None, uncond=False, obs_x0=None, obs_mask=None):
+        F, w = nn.functional, self.w
+        B, J, Fd, T = x.shape
+        if obs_mask is not None:
+            x = torch.cat([obs_x0 * obs_mask + x * (~obs_mask), obs_mask.float()], dim=1)
+        emb = F.linear(F.silu(F.linear(self.pe[t], w["embed_timestep.time_embed.0.weight"],
+                                       w["embed_timestep.time_embed.0.bias"])),
+                       w["embed_timestep.time_embed.2.weight"], w["embed_timestep.time_embed.2.bias"])
+        if "embed_text.weight" in w:
+            ctext = torch.zeros(B, w["embed_text.weight"].shape[1]) if (uncond or enc_text is None) else enc_text
+            emb = emb + F.linear(ctext, w["embed_text.weight"], w["embed_text.bias"])
+        h = F.pad(x.reshape(B, -1, T), (0, 224 - T))
+        c = F.linear(F.mish(F.linear(emb, w["unet.time_mlp.0.weight"], w["unet.time_mlp.0.bias"])),
+                     w["unet.time_mlp.2.weight"], w["unet.time_mlp.2.bias"])
+        skips, n = [], self.n_levels
+        for l in range(n):
+            h = self._res(f"unet.downs.{l}.1", self._res(f"unet.downs.{l}.0", h, c), c)
+            skips.append(h)
+            if l < n - 1:
+                h = F.conv1d(h, w[f"unet.downs.{l}.3.conv.weight"], w[f"unet.downs.{l}.3.conv.bias"], stride=2, padding=1)
+        h = self._res("unet.mid_block2", self._res("unet.mid_block1", h, c), c)
+        for u in range(n - 1):
+            h = torch.cat((h, skips.pop()), dim=1)
+            h = self._res(f"unet.ups.{u}.1", self._res(f"unet.ups.{u}.0", h, c), c)
+            h = F.conv_transpose1d(h, w[f"unet.ups.{u}.3.conv.weight"], w[f"unet.ups.{u}.3.conv.bias"], stride=2, padding=1)
+        h = F.conv1d(self._block("unet.final_conv.0", h), w["unet.final_conv.1.weight"], w["unet.final_conv.1.bias"])
+        return h[:, :, :T].reshape(B, J, Fd, T)
+
+    @torch.no_grad()
+    def forward_cfg(self, x, t, enc_text, text_scale, obs_x0=None, obs_mask=None):
+        oc = self.forward(x, t, enc_text, False, obs_x0, obs_mask)
+        ou = self.forward(x, t, enc_text, True, obs_x0, obs_mask)
+        return ou + text_scale.view(-1, 1, 1, 1) * (oc - ou), oc, ou

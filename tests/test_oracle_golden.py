@@ -225,3 +225,17 @@ def test_unet_oracle_conv_primitives():
     g, b = rng.standard_normal(16).astype(np.float32), rng.standard_normal(16).astype(np.float32)
     assert max_abs(uo.group_norm(x, g, b), F.group_norm(t(x), 8, t(g), t(b)).numpy()) <= 1e-5
     assert max_abs(uo._mish(x * 10), F.mish(t(x * 10)).numpy()) <= 1e-5
+
+
+def test_torch_cpu_unet_matches_golden(cases):
+    """bench.py --config unet's cpu_baseline model (torch CPU conv1d / group_norm / mish) reproduces the reference."""
+    import torch
+    from oracle.torch_cpu_port import TorchCpuUNET
+    inp = cases.make_unet_inputs()
+    g = load_golden("unet_fwd")
+    m = TorchCpuUNET(unet_state_dict(cases))
+    t = torch.from_numpy
+    cfg, oc, ou = m.forward_cfg(t(inp["x"]), t(inp["t"]).long(), t(inp["enc_text"]), t(inp["text_scale"]),
+                                t(inp["obs_x0"]), t(inp["obs_mask"]))
+    for mine, key in ((oc, "out_cond"), (ou, "out_uncond"), (cfg, "out_cfg")):
+        assert max_abs(mine.numpy(), g[key]) <= 2e-5 and rel_l2(mine.numpy(), g[key]) <= 5e-6, key
