@@ -377,7 +377,6 @@ int mdm_forward(cmdi_engine* e, const float* x, const int64_t* t_dev, int64_t t_
     const int B = e->B, T = e->T, S = T + 1, d = e->d, C = e->C;
     const int n_seq = e->cfg ? 2 * B : B;
     if (e->unet) {   // MDM_UNET.forward (model/mdm_unet.py:766-849)
-        if (keep) return fail(CMDI_E_STATE, "UNET engine: no activation stash / VJP");
         HIPCHK(launch_unet_emb(e->uemb, e->time_table, e->have_text ? e->text_term : nullptr, t_dev, t_scalar,
                                n_seq, B, d, e->n_time_rows, s));
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -393,11 +392,11 @@ int mdm_forward(cmdi_engine* e, const float* x, const int64_t* t_dev, int64_t t_
             ev0 = e->ev_pool[e->ev_used]; ev1 = e->ev_pool[e->ev_used + 1];
         }
         const int urc = unet_forward(e->unet, x, e->have_obs ? e->obs_x0 : nullptr, e->have_obs ? e->obs_mask : nullptr,
-                                     e->uemb, B, n_seq, T, out_buf, s, ev0, ev1, mnk);
+                                     e->uemb, B, n_seq, T, out_buf, s, ev0, ev1, mnk, keep);
         if (e->profile && mnk[0]) { e->ev_used += 2; e->prof_m = mnk[0]; e->prof_n = mnk[1]; e->prof_k = mnk[2]; }
         if (urc != 0)
             return fail(CMDI_E_HIP, std::string("UNET: ") + unet_error(e->unet));
-        e->stash_valid = false;
+        e->stash_valid = keep;
         return CMDI_OK;
     }
 
@@ -524,6 +523,13 @@ int mdm_backward(cmdi_engine* e, const float* gout, float* gx, hipStream_t s) {
     const int n_seq = e->cfg ? 2 * B : B;
     const int M = n_seq * S;
     if (!e->stash_valid) return fail(CMDI_E_STATE, "cmdi_mdm_vjp: no stashed forward pass");
+    if (e->unet) {   // the U-Net's own input-VJP (unet.hip), under the same power-of-two gradient scale
+        HIPCHK(hipMemsetAsync(e->gs_bits, 0, sizeof(unsigned), s));
+        HIPCHK(launch_absmax_bits(gout, (int64_t)n_seq * C * T, e->gs_bits, s));
+        if (unet_backward(e->unet, gout, e->have_obs ? e->obs_mask : nullptr, e->gs_bits, B, n_seq, T, gx, s) != 0)
+            return fail(CMDI_E_HIP, std::string("UNET backward: ") + unet_error(e->unet));
+        return CMDI_OK;
+    }
 
     // output projection: d tok[b*S+1+t][k] = sum_c gout[b][c][t] W_out[c][k]; token 0 rows get 0
     HIPCHK(hipMemsetAsync(e->dA, 0, (size_t)M * d * sizeof(float), s));
@@ -614,7 +620,6 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
         // the temporal U-Net of unet.hip; the sampler / condition machinery is shared
         if (desc->d_model != 512 || desc->max_frames > 224 || desc->pe_rows < 1)
             return fail(CMDI_E_INVALID, "UNET engine: latent_dim must be 512, max_frames <= 224");
-        if (desc->want_grad) return fail(CMDI_E_INVALID, "UNET engine: no VJP (reconstruction guidance) yet");
         if (desc->precision == CMDI_PREC_F32) return fail(CMDI_E_INVALID, "UNET engine: only the f16x3 precision is built");
         cmdi_engine* e = new cmdi_engine();
         e->desc = *desc;
@@ -641,8 +646,9 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
         ALLOC(e->range_flag, 1);
         HIPCHK(hipMemset(e->range_flag, 0, sizeof(int)));
         ALLOC(e->gs_bits, 16);
+        if (desc->want_grad) { ALLOC(e->gout, nseq * e->C * e->Tmax); ALLOC(e->gx, nseq * e->C * e->Tmax); }
         e->unet = unet_new(desc->n_feats, desc->unet_added, desc->d_model, desc->unet_mults, (int)nseq,
-                           desc->text_cond != 0);
+                           desc->text_cond != 0, desc->want_grad != 0);
         if (unet_error(e->unet)[0]) return fail(CMDI_E_INVALID, std::string("UNET: ") + unet_error(e->unet));
         e->bytes += unet_bytes(e->unet);
         e->pipelines = 0;
@@ -885,7 +891,7 @@ int cmdi_finalize_weights(cmdi_handle e, int32_t n_time_rows, cmdi_stream stream
         if (ur != 0) return fail(CMDI_E_HIP, std::string("UNET: ") + unet_error(e->unet));
     } else
     HIPCHK(launch_pad_copy(e->w_in_pad, e->w_in, d, C, e->Cpad, s));
-    if (e->desc.want_grad) {
+    if (e->desc.want_grad && !e->unet) {
         HIPCHK(launch_transpose_pad(e->w_inT, e->w_in, d, C, d, s));          // [C][d]
         HIPCHK(launch_transpose_pad(e->w_outT_pad, e->w_out, C, d, e->Cpad, s));  // [d][Cpad]
         for (LayerW& w : e->layers) {
@@ -973,7 +979,7 @@ int cmdi_set_condition(cmdi_handle e, const cmdi_condition* c, cmdi_stream strea
     if (c->cfg && !c->d_text_scale) return fail(CMDI_E_INVALID, "cfg needs text_scale");
     if ((c->imputate || c->recon_guidance) && (!c->d_inpaint_mask || !c->d_inpaint_motion))
         return fail(CMDI_E_INVALID, "imputation / reconstruction guidance need inpainting_mask and inpainted_motion");
-    if (c->recon_guidance && e->L > 0 && !e->desc.want_grad)
+    if (c->recon_guidance && (e->L > 0 || e->unet) && !e->desc.want_grad)
         return fail(CMDI_E_STATE, "reconstruction guidance needs an engine created with want_grad=1");
     if (c->recon_guidance && !c->recon_w) return fail(CMDI_E_INVALID, "reconstruction guidance needs recon_w");
     const int B = c->batch, T = c->n_frames, d = e->d;
@@ -990,7 +996,6 @@ int cmdi_set_condition(cmdi_handle e, const cmdi_condition* c, cmdi_stream strea
         HIPCHK(hipMemcpyAsync(e->inpaint, c->d_inpaint_motion, n * sizeof(float), hipMemcpyDeviceToDevice, s));
     e->have_obs = false;
     if (e->unet) {
-        if (c->recon_guidance) return fail(CMDI_E_INVALID, "UNET engine: reconstruction guidance (VJP) is not built yet");
         if ((c->d_obs_x0 == nullptr) != (c->d_obs_mask == nullptr))
             return fail(CMDI_E_INVALID, "with spatial-conditioning, both obs_x0 and obs_mask must be provided");
         if (e->desc.unet_added && !c->d_obs_x0)

@@ -373,7 +373,7 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] += (float)rh[e] + (float)rl[e] * kLoInv;
                     } else {
-                        const float4 rr = *reinterpret_cast<const float4*>(p.R + off);
+                        const float4 rr = *reinterpret_cast<const float4*>(p.R + (p.r_ld ? (size_t)m * p.r_ld + n : off));
                         v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
                     }
                     if (p.C) *reinterpret_cast<float4*>(p.C + off) = make_float4(v[0], v[1], v[2], v[3]);

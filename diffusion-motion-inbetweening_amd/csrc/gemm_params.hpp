@@ -62,7 +62,8 @@ struct H3Params {
     const float* bias;  // [N] or null
     float* C;           // fp32 output [M][ldc]
     _Float16* Cs;       // split output [M][2N]
-    const float* R;     // residual [M][ldc]
+    const float* R;     // residual [M][r_ld ? r_ld : ldc]
+    int r_ld;
     int ksplit;         // H3_PLAIN only: > 1 = that many blocks per tile, each over a slice of K; slice s writes its
     long slice_stride;  // partial sums to C + s * slice_stride (the consumer adds the slices); bias joins slice 0
     const float* pe;    // H3_TOKENS: positional table [.][N]

@@ -89,7 +89,7 @@ hipError_t launch_transpose_pad(float* dst, const float* src, int rows, int cols
 
 // ---- unet.hip: MDM_UNET denoiser ------------------------------------------------------------------
 struct UnetModel;
-UnetModel* unet_new(int n_feats, int added, int dim, const int mults[4], int max_seq, bool text);
+UnetModel* unet_new(int n_feats, int added, int dim, const int mults[4], int max_seq, bool text, bool want_grad);
 const char* unet_error(const UnetModel* u);
 int64_t unet_bytes(const UnetModel* u);
 void unet_free(UnetModel* u);
@@ -98,7 +98,10 @@ int unet_finalize(UnetModel* u, hipStream_t s);
 // ev0 / ev1 (bench): recorded around the second k=5 convolution GEMM of downs.0.1; its M, N, K land in probe_mnk
 int unet_forward(UnetModel* u, const float* x, const float* obs, const uint8_t* mask, const float* emb, int B, int nseq,
                  int T, float* out, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr,
-                 int* probe_mnk = nullptr);
+                 int* probe_mnk = nullptr, bool keep = false /* stash activations for unet_backward */);
+// input-VJP of the last stashing forward pass: gx [nseq, J, T] from gout [nseq, J, T]
+int unet_backward(UnetModel* u, const float* gout, const uint8_t* mask, const unsigned* gs_bits, int B, int nseq, int T,
+                  float* gx, hipStream_t s);
 int unet_range_flag(UnetModel* u, int* flag, hipStream_t s);
 hipError_t launch_unet_emb(float* emb, const float* time_table, const float* text_term, const int64_t* t_dev,
                            int64_t t_scalar, int n_seq, int n_per_pass, int d, int n_time_rows, hipStream_t stream);

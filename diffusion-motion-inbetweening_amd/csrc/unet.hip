@@ -185,6 +185,172 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     if (overflow && range_flag) atomicOr(range_flag, 1);
 }
 
+// ---- input-VJP pieces (reconstruction guidance through the U-Net): everything is linear in the output gradient ----
+__device__ __forceinline__ float mish_grad(float z) {
+    // d/dz [z tanh(softplus(z))] = tanh(sp) + z (1 - tanh(sp)^2) sigmoid(z);  softplus' = 1 beyond torch's threshold
+    const float sp = z > 20.f ? z : log1pf(expf(z));
+    const float ts = tanhf(sp);
+    const float sg = z > 20.f ? 1.f : 1.f / (1.f + expf(-z));
+    return ts + z * (1.f - ts * ts) * sg;
+}
+
+// g = dY * Mish'(z) * (1 + scale) * gamma,  z = (xhat * gamma + beta) [* (1 + scale) + shift],  xhat = (F - mean) * rstd
+__device__ __forceinline__ void gn_bwd_terms(const float4 f, const float4 dy, float mean, float rstd, const float4 ga,
+                                             const float4 be, const float4 sc, const float4 sh, bool ada, float xh[4],
+                                             float g[4]) {
+    const float fv[4] = {f.x, f.y, f.z, f.w}, dv[4] = {dy.x, dy.y, dy.z, dy.w};
+    const float gv[4] = {ga.x, ga.y, ga.z, ga.w}, bv[4] = {be.x, be.y, be.z, be.w};
+    const float sv[4] = {sc.x, sc.y, sc.z, sc.w}, hv[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        xh[e] = (fv[e] - mean) * rstd;
+        float z = xh[e] * gv[e] + bv[e];
+        float k = gv[e];
+        if (ada) { z = z * (1.f + sv[e]) + hv[e]; k *= 1.f + sv[e]; }
+        g[e] = dv[e] * mish_grad(z) * k;
+    }
+}
+
+// GroupNorm backward, pass 1: per (sequence, group) means of g and g * xhat over the group's valid frames
+__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restrict__ dy, int ld_dy, const float* __restrict__ f,
+                                                           int nsl, size_t sl, const float* __restrict__ stats,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ ss, int ss_ld, float* __restrict__ sums,
+                                                           int C, int Tp, int h, int Tv) {
+    __shared__ float red[8];
+    const int seq = blockIdx.x, g = blockIdx.y, cg = C / NG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float mean = stats[((size_t)seq * NG + g) * 2], rstd = stats[((size_t)seq * NG + g) * 2 + 1];
+    const int q4 = cg / 4, total = Tv * q4;
+    float s1 = 0.f, s2 = 0.f;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < total; i += 256) {
+        const int r = i / q4, c = g * cg + (i - r * q4) * 4;
+        const size_t row = (size_t)seq * Tp + h + r;
+        const float4 fv = load_slices(f + row * C + c, nsl, sl);
+        const float4 dv = *reinterpret_cast<const float4*>(dy + row * ld_dy + c);
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + c), be = *reinterpret_cast<const float4*>(beta + c);
+        const float4 sc = ss ? *reinterpret_cast<const float4*>(ss + (size_t)seq * ss_ld + c) : zero;
+        const float4 sh = ss ? *reinterpret_cast<const float4*>(ss + (size_t)seq * ss_ld + C + c) : zero;
+        float xh[4], gg[4];
+        gn_bwd_terms(fv, dv, mean, rstd, ga, be, sc, sh, ss != nullptr, xh, gg);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s1 += gg[e]; s2 += gg[e] * xh[e]; }
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0) { red[wave] = s1; red[4 + wave] = s2; }
+    __syncthreads();
+    if (tid == 0) {
+        const float n = (float)(Tv * cg);
+        sums[((size_t)seq * NG + g) * 2] = ((red[0] + red[1]) + (red[2] + red[3])) / n;
+        sums[((size_t)seq * NG + g) * 2 + 1] = ((red[4] + red[5]) + (red[6] + red[7])) / n;
+    }
+}
+
+// pass 2: dF = rstd * (g - mean(g) - xhat * mean(g xhat)) -> split rows (the A operand of the transposed convolution)
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ dy, int ld_dy, const float* __restrict__ f,
+                                                           int nsl, size_t sl, const float* __restrict__ stats,
+                                                           const float* __restrict__ sums, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ ss,
+                                                           int ss_ld, _Float16* __restrict__ out, int C, int Tp, int h, int Tv) {
+    const int seq = blockIdx.y;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= Tv) return;
+    const int lane = threadIdx.x & 63, cg = C / NG;
+    const size_t row = (size_t)seq * Tp + h + t;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = lane * 4; c < C; c += 256) {
+        const int g = c / cg;
+        const float mean = stats[((size_t)seq * NG + g) * 2], rstd = stats[((size_t)seq * NG + g) * 2 + 1];
+        const float m1 = sums[((size_t)seq * NG + g) * 2], m2 = sums[((size_t)seq * NG + g) * 2 + 1];
+        const float4 fv = load_slices(f + row * C + c, nsl, sl);
+        const float4 dv = *reinterpret_cast<const float4*>(dy + row * ld_dy + c);
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + c), be = *reinterpret_cast<const float4*>(beta + c);
+        const float4 sc = ss ? *reinterpret_cast<const float4*>(ss + (size_t)seq * ss_ld + c) : zero;
+        const float4 sh = ss ? *reinterpret_cast<const float4*>(ss + (size_t)seq * ss_ld + C + c) : zero;
+        float xh[4], gg[4];
+        gn_bwd_terms(fv, dv, mean, rstd, ga, be, sc, sh, ss != nullptr, xh, gg);
+        h4 oh, ol;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            _Float16 a, l;
+            split_f16(rstd * (gg[e] - m1 - xh[e] * m2), a, l);
+            oh[e] = a; ol[e] = l;
+        }
+        _Float16* d = out + row * (2 * (size_t)C) + split_pos(c);
+        *reinterpret_cast<h4*>(d) = oh;
+        *reinterpret_cast<h4*>(d + 32) = ol;
+    }
+}
+
+// gout [nseq, J, T] -> split rows [nseq * Tp, 2 * Np] (frames T..223 and channels J.. are zero), times the power-of-two
+// gradient scale (common.hpp grad_scale_from_bits) that parks the chain mid-range of f16
+__global__ __launch_bounds__(256) void unet_output_bwd_kernel(const float* __restrict__ gout, _Float16* __restrict__ rows,
+                                                              const unsigned* __restrict__ gs_bits, int J, int T, int Np,
+                                                              int Tp, int h) {
+    const int seq = blockIdx.y;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= TPAD) return;
+    const int lane = threadIdx.x & 63;
+    const float gs = grad_scale_from_bits(*gs_bits);
+    _Float16* row = rows + ((size_t)seq * Tp + h + t) * (2 * (size_t)Np);
+    for (int c = lane; c < Np; c += 64) {
+        const float v = (t < T && c < J) ? gout[((size_t)seq * J + c) * T + t] * gs : 0.f;
+        _Float16 a, l;
+        split_f16(v, a, l);
+        row[split_pos(c)] = a;
+        row[split_pos(c) + 32] = l;
+    }
+}
+
+// gx[seq][c][t] = d in0[row(seq, t)][c] * (1 - mask[b][c][t]) / scale   (x enters as obs*m + x*~m: mdm_unet.py:781)
+__global__ void unet_input_bwd_kernel(const float* __restrict__ rows, const uint8_t* __restrict__ mask,
+                                      const unsigned* __restrict__ gs_bits, float* __restrict__ gx, int B, int J, int T,
+                                      int ld, int Tp, int h) {
+    const int seq = blockIdx.z, c = blockIdx.y, b = seq % B;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    const float inv = 1.0f / grad_scale_from_bits(*gs_bits);   // exact: a power of two
+    const bool obs = mask && mask[((size_t)b * J + c) * T + t];
+    gx[((size_t)seq * J + c) * T + t] = obs ? 0.f : rows[((size_t)seq * Tp + h + t) * ld + c] * inv;
+}
+
+// dst[r][0..C) += src[r][0..C)   (row strides ld_dst / ld_src floats)
+__global__ void add_rows_kernel(float* __restrict__ dst, int ld_dst, const float* __restrict__ src, int ld_src,
+                                int64_t rows, int C) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int c4 = C / 4;
+    if (i >= rows * c4) return;
+    const int64_t r = i / c4;
+    const int c = (int)(i - r * c4) * 4;
+    float4 a = *reinterpret_cast<float4*>(dst + r * ld_dst + c);
+    const float4 b = *reinterpret_cast<const float4*>(src + r * ld_src + c);
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    *reinterpret_cast<float4*>(dst + r * ld_dst + c) = a;
+}
+
+// GEMM weights of the input-gradient convolutions: out [Cin_p rows][taps_b * Cout_p] (zero padded)
+//   mode 3  Conv1d k, stride 1:   out[n][q*Cout_p + c] = w[c][n][k-1-q]            (dX[t] = sum_j dY[t+pad-j] W_j^T)
+//   mode 4/5 Conv1d(3, stride 2): even input rows  out[n][c] = w[c][n][1];  odd rows  q=0: w[c][n][2], q=1: w[c][n][0]
+//   mode 6  ConvTranspose1d(4, 2, 1) [Cin][Cout][4]:  out[n][q*Cout_p + c] = w[n][c][q]   (rows 2m-1 .. 2m+2 of dY)
+__global__ void pack_conv_wT_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int Cin_p,
+                                    int Cout_p, int k, int mode) {
+    const int taps = mode == 3 ? k : (mode == 4 ? 1 : (mode == 5 ? 2 : 4));
+    const int64_t K = (int64_t)taps * Cout_p;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)Cin_p * K) return;
+    const int n = (int)(i / K);
+    const int r = (int)(i - (int64_t)n * K), q = r / Cout_p, c = r - q * Cout_p;
+    float v = 0.f;
+    if (n < Cin && c < Cout) {
+        if (mode == 3) v = w[((size_t)c * Cin + n) * k + (k - 1 - q)];
+        else if (mode == 4) v = w[((size_t)c * Cin + n) * 3 + 1];
+        else if (mode == 5) v = w[((size_t)c * Cin + n) * 3 + (q == 0 ? 2 : 0)];
+        else v = w[((size_t)n * Cout + c) * 4 + q];
+    }
+    out[i] = v;
+}
+
 // out[seq][c][t] = rows[(seq*Tp + h + t)][c]  for c < J, t < T   (the crop x[:nframes] and the final permute)
 __global__ void unet_output_kernel(const float* __restrict__ rows, float* __restrict__ out, int J, int T, int N,
                                    int Tp, int h) {
@@ -219,9 +385,14 @@ struct Conv {
     int cin = 0, cin_p = 0, cout = 0, k = 0;
     float *w = nullptr, *b = nullptr;       // fp32 originals (w freed after packing)
     _Float16 *ws = nullptr, *ws2 = nullptr;  // split GEMM weights (ws2: odd rows of a transposed conv)
+    _Float16 *wb = nullptr, *wb2 = nullptr;  // want_grad: weights of the input-gradient GEMMs (pack_conv_wT_kernel)
+    int cout_p = 0;
     bool transposed = false;
 };
 struct GN { float *g = nullptr, *b = nullptr; };
+// what a ResidualTemporalBlock keeps for the input-VJP: both convolution outputs (pre-GroupNorm, possibly as split-K
+// slices) and the GroupNorm statistics
+struct RBStash { float *F1 = nullptr, *F2 = nullptr, *st1 = nullptr, *st2 = nullptr; int n1 = 1, n2 = 1; };
 struct ResBlock {
     Conv c1, c2, res;      // res.w == nullptr: identity residual
     GN n1, n2;
@@ -254,6 +425,11 @@ struct UnetModel {
     float *F1[4] = {}, *F2[4] = {}, *Xa[4] = {}, *Xb[4] = {};
     _Float16 *in0S = nullptr, *H1S[4] = {}, *Sa[4] = {}, *Sb[4] = {}, *CAT[4] = {}, *S0skip = nullptr;
     float* outF = nullptr;
+    // input-VJP (want_grad): activation stash of the last forward pass + gradient workspace
+    bool want_grad = false, stash_valid = false;
+    RBStash st_down[4][2], st_mid[2], st_up[3][2], st_fin;   // st_fin: F1 / st1 only
+    float *GA[4] = {}, *GC[4] = {}, *GT[4] = {}, *GB[4] = {}, *gIn0 = nullptr, *bsums = nullptr;
+    _Float16 *GS[4] = {}, *GU[4] = {}, *GBS[4] = {}, *gOutS = nullptr;
     int* range_flag = nullptr;
     std::string err;
 };
@@ -290,6 +466,13 @@ int conv_alloc(UnetModel* u, Conv& c, int cin, int cout, int k, bool transposed 
         u->err = "hipMemset failed"; return -1;
     }
     if (transposed && ualloc_t(u, &c.ws2, np * kk * 2)) return -1;
+    c.cout_p = (int)np;
+    if (u->want_grad) {   // [cin_p rows][taps_b * cout_p] split: conv k -> k taps; stride-2 conv -> 1 + 2; transposed -> 4
+        const size_t rows = (size_t)c.cin_p;
+        const size_t k1 = (size_t)(transposed ? 4 : (k == 3 ? 1 : k)) * np;
+        if (ualloc_t(u, &c.wb, rows * k1 * 2)) return -1;
+        if (!transposed && k == 3 && ualloc_t(u, &c.wb2, rows * 2 * np * 2)) return -1;
+    }
     // the fp32 original is a transient allocation (freed by unet_finalize)
     if (hipMalloc(reinterpret_cast<void**>(&c.w), (size_t)cin * cout * k * sizeof(float)) != hipSuccess) {
         u->err = "hipMalloc failed"; return -1;
@@ -341,6 +524,25 @@ hipError_t pack(UnetModel* u, Conv& c, hipStream_t s) {
         e = launch_split_f16(tmp, pass ? c.ws2 : c.ws, n_rows, kk, kk, u->range_flag, s);
         if (e != hipSuccess) break;
     }
+    if (e == hipSuccess && c.wb) {
+        // one or two input-gradient GEMM weights (see pack_conv_wT_kernel)
+        const int modes[2] = {c.transposed ? 6 : (c.k == 3 ? 4 : 3), c.k == 3 && !c.transposed ? 5 : -1};
+        for (int pass = 0; pass < 2 && e == hipSuccess; ++pass) {
+            const int mode = modes[pass];
+            if (mode < 0) break;
+            const int taps = mode == 3 ? c.k : (mode == 4 ? 1 : (mode == 5 ? 2 : 4));
+            const int64_t K = (int64_t)taps * c.cout_p, n = (int64_t)c.cin_p * K;
+            float* tb = nullptr;
+            e = hipMalloc(reinterpret_cast<void**>(&tb), (size_t)n * sizeof(float));
+            if (e != hipSuccess) break;
+            hipLaunchKernelGGL(pack_conv_wT_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c.w, tb, c.cout, c.cin,
+                               c.cin_p, c.cout_p, c.k, mode);
+            e = launch_split_f16(tb, pass ? c.wb2 : c.wb, c.cin_p, (int)K, K, u->range_flag, s);
+            hipError_t e3 = hipStreamSynchronize(s);
+            (void)hipFree(tb);
+            if (e == hipSuccess) e = e3;
+        }
+    }
     hipError_t e2 = hipStreamSynchronize(s);
     (void)hipFree(tmp);
     (void)hipFree(c.w);
@@ -350,9 +552,9 @@ hipError_t pack(UnetModel* u, Conv& c, hipStream_t s) {
 
 }  // namespace
 
-UnetModel* unet_new(int n_feats, int added, int dim, const int mults[4], int max_seq, bool text) {
+UnetModel* unet_new(int n_feats, int added, int dim, const int mults[4], int max_seq, bool text, bool want_grad) {
     UnetModel* u = new UnetModel();
-    u->J = n_feats; u->added = added; u->dim = dim; u->max_seq = max_seq; u->text = text;
+    u->J = n_feats; u->added = added; u->dim = dim; u->max_seq = max_seq; u->text = text; u->want_grad = want_grad;
     if (const char* v = std::getenv("CMDI_UNET_KSPLIT")) u->ksplit_ok = std::atoi(v);
     if (const char* v = std::getenv("CMDI_UNET_TILE")) u->big_tile = std::atoi(v);
     u->C[0] = n_feats + added;
@@ -396,6 +598,26 @@ UnetModel* unet_new(int n_feats, int added, int dim, const int mults[4], int max
     rc |= alloc_rows(u, &u->in0S, ns * 256, 2 * (size_t)u->Cin0p);
     rc |= alloc_rows(u, &u->S0skip, ns * 256, 2 * (size_t)Cw);
     rc |= alloc_rows(u, &u->outF, ns * 256, (size_t)u->Np);
+    if (want_grad && !rc) {
+        auto stash = [&](RBStash& st, int l, bool second) {
+            const size_t rows = ns * (size_t)(256 >> l), frows = rows > 8192 ? rows : 8192;
+            int r = alloc_rows(u, &st.F1, frows, Cw) | ualloc_t(u, &st.st1, ns * NG * 2);
+            if (second) r |= alloc_rows(u, &st.F2, frows, Cw) | ualloc_t(u, &st.st2, ns * NG * 2);
+            return r;
+        };
+        for (int l = 0; l < 4; ++l) rc |= stash(u->st_down[l][0], l, true) | stash(u->st_down[l][1], l, true);
+        rc |= stash(u->st_mid[0], 3, true) | stash(u->st_mid[1], 3, true);
+        for (int i = 0; i < 3; ++i) rc |= stash(u->st_up[i][0], 3 - i, true) | stash(u->st_up[i][1], 3 - i, true);
+        rc |= stash(u->st_fin, 0, false);
+        for (int l = 0; l < 4 && !rc; ++l) {
+            const size_t rows = ns * (size_t)(256 >> l);
+            rc |= alloc_rows(u, &u->GA[l], rows, Cw) | alloc_rows(u, &u->GC[l], rows, Cw) | alloc_rows(u, &u->GT[l], rows, Cw);
+            rc |= alloc_rows(u, &u->GS[l], rows, 2 * (size_t)Cw) | alloc_rows(u, &u->GU[l], rows, 2 * (size_t)Cw);
+            if (l > 0) rc |= alloc_rows(u, &u->GB[l], rows, 2 * (size_t)Cw) | alloc_rows(u, &u->GBS[l], rows, 4 * (size_t)Cw);
+        }
+        rc |= alloc_rows(u, &u->gIn0, ns * 256, (size_t)u->Cin0p) | alloc_rows(u, &u->gOutS, ns * 256, 2 * (size_t)u->Np);
+        rc |= ualloc_t(u, &u->bsums, ns * NG * 2);
+    }
     if (rc && u->err.empty()) u->err = "allocation failed";
     return u;
 }
@@ -523,38 +745,102 @@ int conv_rows(UnetModel* u, const Conv& c, const _Float16* ws, const _Float16* a
 }
 
 int group_norm(UnetModel* u, const float* x, int nsl, const GN& n, const float* ss, const float* resid, float* yf,
-               _Float16* ys, int ys_ld, int nseq, int level, hipStream_t s) {
+               _Float16* ys, int ys_ld, int nseq, int level, hipStream_t s, float* stats = nullptr) {
     const Lvl L = lvl(level);
     const int C = u->C[1];
     const size_t sl = (size_t)nseq * L.Tp * C;   // floats between the split-K slices of x
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(nseq, NG), dim3(256), 0, s, x, u->stats, C, L.Tp, L.h, L.Tv, nsl, sl);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3((L.Tv + 3) / 4, nseq), dim3(256), 0, s, x, u->stats, n.g, n.b, ss, resid, yf,
+    if (!stats) stats = u->stats;                // (a stashing forward pass keeps them per GroupNorm)
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nseq, NG), dim3(256), 0, s, x, stats, C, L.Tp, L.h, L.Tv, nsl, sl);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((L.Tv + 3) / 4, nseq), dim3(256), 0, s, x, stats, n.g, n.b, ss, resid, yf,
                        ys, ys_ld, u->range_flag, C, L.Tp, L.h, L.Tv, u->ss_ld, nsl, sl);
     UCHK(hipGetLastError());
     return 0;
 }
 
-// ResidualTemporalBlock: xs = input rows (split, a_ld halves per row), xf = the same in fp32 (identity residual only)
+// ResidualTemporalBlock: xs = input rows (split, a_ld halves per row), xf = the same in fp32 (identity residual only);
+// st (a stashing forward pass): the block's own buffers for both convolution outputs and GroupNorm statistics
 int res_block(UnetModel* u, const ResBlock& r, const _Float16* xs, int a_ld, const float* xf, int nseq, int level,
-              float* out_f, _Float16* out_s, int out_ld, hipStream_t s) {
+              float* out_f, _Float16* out_s, int out_ld, hipStream_t s, RBStash* st = nullptr) {
     const Lvl L = lvl(level);
     const int rows = nseq * L.Tp, C = r.cout;
     const float* ss = u->ss + r.ss_off;   // (scale | shift) = Linear(Mish(c)), computed for all blocks up front
+    float* f1 = st ? st->F1 : u->F1[level];
+    float* f2 = st ? st->F2 : u->F2[level];
     int n1 = 1, n2 = 1;   // split-K slices the two convolutions left behind
-    if (conv_rows(u, r.c1, r.c1.ws, xs, a_ld, rows, level, 5, 2, 1, 0, 0, u->F1[level], nullptr, 0, nullptr, s, &n1)) return -1;
-    if (group_norm(u, u->F1[level], n1, r.n1, ss, nullptr, nullptr, u->H1S[level], 2 * C, nseq, level, s)) return -1;
+    if (conv_rows(u, r.c1, r.c1.ws, xs, a_ld, rows, level, 5, 2, 1, 0, 0, f1, nullptr, 0, nullptr, s, &n1)) return -1;
+    if (group_norm(u, f1, n1, r.n1, ss, nullptr, nullptr, u->H1S[level], 2 * C, nseq, level, s, st ? st->st1 : nullptr)) return -1;
     const bool probe = u->probe_ev[0] && &r == &u->down[0][1];
     if (probe) {
         UCHK(hipEventRecord(u->probe_ev[0], s));
         u->probe_mnk[0] = nseq * L.Tv; u->probe_mnk[1] = C; u->probe_mnk[2] = 5 * r.c2.cin_p;   // algorithmic: valid frames only
     }
-    if (conv_rows(u, r.c2, r.c2.ws, u->H1S[level], 2 * C, rows, level, 5, 2, 1, 0, 0, u->F2[level], nullptr, 0, nullptr, s, &n2)) return -1;
+    if (conv_rows(u, r.c2, r.c2.ws, u->H1S[level], 2 * C, rows, level, 5, 2, 1, 0, 0, f2, nullptr, 0, nullptr, s, &n2)) return -1;
     if (probe) UCHK(hipEventRecord(u->probe_ev[1], s));
+    if (st) { st->n1 = n1; st->n2 = n2; }
+    float* stats2 = st ? st->st2 : nullptr;
     if (!r.res.ws) {   // identity residual, added behind the Mish
-        return group_norm(u, u->F2[level], n2, r.n2, nullptr, xf, out_f, out_s, out_ld, nseq, level, s);
+        return group_norm(u, f2, n2, r.n2, nullptr, xf, out_f, out_s, out_ld, nseq, level, s, stats2);
     }
-    if (group_norm(u, u->F2[level], n2, r.n2, nullptr, nullptr, u->F1[level], nullptr, 0, nseq, level, s)) return -1;
+    if (group_norm(u, f2, n2, r.n2, nullptr, nullptr, u->F1[level], nullptr, 0, nseq, level, s, stats2)) return -1;
     return conv_rows(u, r.res, r.res.ws, xs, a_ld, rows, level, 1, 0, 1, 0, 0, out_f, out_s, out_ld, u->F1[level], s);
+}
+
+// ---- input-VJP ---------------------------------------------------------------------------------------------------------
+// one GEMM over gradient rows: C[M', N] (+)= A-rows (tap-shifted, strided) x W^T, frames only (halo rows stay zero)
+int grad_gemm(UnetModel* u, const _Float16* a, int a_ld, const _Float16* w, int M, int N, int K1, int taps, int pad,
+              int a_mul, int c_mul, int c_add, int level_out, float* out_f, int ldc, _Float16* out_s, int cs_ld,
+              const float* resid, int r_ld, hipStream_t s) {
+    const Lvl lo = lvl(level_out);
+    H3Params p{};
+    p.A = a - (ptrdiff_t)pad * a_ld;
+    p.W = w;
+    p.M = M; p.N = N; p.K = taps * K1; p.ldc = ldc;
+    p.a_ld = a_ld; p.a_row_mul = a_mul; p.taps = taps; p.cpt = K1 / 32;
+    p.c_row_mul = c_mul; p.c_row_add = c_add; p.tp = lo.Tp; p.t_lo = lo.h; p.t_hi = lo.h + lo.Tv;
+    p.cs_ld = cs_ld;
+    int kind;
+    if (resid) { kind = H3_RESID; p.R = resid; p.r_ld = r_ld; p.C = out_f; p.Cs = out_s; }
+    else if (out_s) { kind = H3_PLAIN_SPLIT; p.Cs = out_s; p.aux = out_f; }
+    else { kind = H3_PLAIN; p.C = out_f; }
+    UCHK(launch_gemm_h3(kind, p, 0, s));
+    return 0;
+}
+
+// dF (split rows in u->GS[level]) of Mish(GroupNorm(F) [* (1 + scale) + shift]) given d out = dy
+int gn_bwd(UnetModel* u, const float* dy, int ld_dy, const float* f, int nsl, const float* stats, const GN& n,
+           const float* ss, int nseq, int level, hipStream_t s) {
+    const Lvl L = lvl(level);
+    const int C = u->C[1];
+    const size_t sl = (size_t)nseq * L.Tp * C;
+    hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(nseq, NG), dim3(256), 0, s, dy, ld_dy, f, nsl, sl, stats, n.g, n.b, ss,
+                       u->ss_ld, u->bsums, C, L.Tp, L.h, L.Tv);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((L.Tv + 3) / 4, nseq), dim3(256), 0, s, dy, ld_dy, f, nsl, sl, stats, u->bsums,
+                       n.g, n.b, ss, u->ss_ld, u->GS[level], C, L.Tp, L.h, L.Tv);
+    UCHK(hipGetLastError());
+    return 0;
+}
+
+// ResidualTemporalBlock backward: dy = d out (fp32 rows, stride ld_dy; dys = the same as split rows, needed only when the
+// block has a 1x1 residual convolution) -> d x into out_f (fp32, cin_p wide, may be null) and / or out_s (split rows)
+int res_block_bwd(UnetModel* u, const ResBlock& r, const RBStash& st, const float* dy, int ld_dy, const _Float16* dys,
+                  int nseq, int level, float* out_f, _Float16* out_s, hipStream_t s) {
+    const Lvl L = lvl(level);
+    const int rows = nseq * L.Tp, C = r.cout, Ni = r.c1.cin_p;
+    const float* ss = u->ss + r.ss_off;
+    // out = Mish(GN2(conv2(h1))) + R(x)
+    if (gn_bwd(u, dy, ld_dy, st.F2, st.n2, st.st2, r.n2, nullptr, nseq, level, s)) return -1;
+    if (grad_gemm(u, u->GS[level], 2 * C, r.c2.wb, rows, C, C, 5, 2, 1, 0, 0, level, u->GT[level], C, nullptr, 0, nullptr, 0, s))
+        return -1;
+    // h1 = Mish(GN1(conv1(x)) * (1 + scale) + shift)
+    if (gn_bwd(u, u->GT[level], C, st.F1, st.n1, st.st1, r.n1, ss, nseq, level, s)) return -1;
+    if (!r.res.wb) {   // identity residual: d x = conv1^T(dF1) + d out
+        return grad_gemm(u, u->GS[level], 2 * C, r.c1.wb, rows, Ni, C, 5, 2, 1, 0, 0, level, out_f, Ni, out_s, 2 * Ni, dy,
+                         ld_dy, s);
+    }
+    if (!out_f || !dys) { u->err = "res_block_bwd: a block with a residual convolution needs out_f and dys"; return -1; }
+    if (grad_gemm(u, u->GS[level], 2 * C, r.c1.wb, rows, Ni, C, 5, 2, 1, 0, 0, level, out_f, Ni, nullptr, 0, nullptr, 0, s))
+        return -1;
+    return grad_gemm(u, dys, 2 * C, r.res.wb, rows, Ni, C, 1, 0, 1, 0, 0, level, out_f, Ni, out_s, 2 * Ni, out_f, Ni, s);
 }
 
 }  // namespace
@@ -562,8 +848,10 @@ int res_block(UnetModel* u, const ResBlock& r, const _Float16* xs, int a_ld, con
 // x, obs [B, J, T] fp32, mask u8 (obs / mask may be null when added == 0), emb [nseq, dim] fp32 (time embedding +
 // text term per sequence), out [nseq, J, T].  nseq = B or 2B (CFG: [cond | uncond], same input rows).
 int unet_forward(UnetModel* u, const float* x, const float* obs, const uint8_t* mask, const float* emb, int B, int nseq,
-                 int T, float* out, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int* probe_mnk) {
+                 int T, float* out, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1, int* probe_mnk, bool keep) {
     u->probe_ev[0] = ev0; u->probe_ev[1] = ev1;
+    if (keep && !u->want_grad) { u->err = "UNET engine created without want_grad"; return -1; }
+    u->stash_valid = false;
     struct ProbeOut { UnetModel* u; int* o; ~ProbeOut() { if (o) { o[0] = u->probe_mnk[0]; o[1] = u->probe_mnk[1]; o[2] = u->probe_mnk[2]; } } } probe_out{u, probe_mnk};
     if (!u->finalized) { u->err = "UNET weights not finalized"; return -1; }
     if (nseq > u->max_seq || T > TPAD || T < 1) { u->err = "batch / frames exceed the UNET workspace"; return -1; }
@@ -597,11 +885,12 @@ int unet_forward(UnetModel* u, const float* x, const float* obs, const uint8_t* 
     int xs_ld = 2 * u->Cin0p;
     const float* xf = nullptr;
     for (int l = 0; l < 4; ++l) {
-        if (res_block(u, u->down[l][0], xs, xs_ld, xf, nseq, l, u->Xa[l], u->Sa[l], 2 * Cw, s)) return -1;
+        if (res_block(u, u->down[l][0], xs, xs_ld, xf, nseq, l, u->Xa[l], u->Sa[l], 2 * Cw, s, keep ? &u->st_down[l][0] : nullptr)) return -1;
         // skip of level l >= 1 goes straight into the right half of that level's concat buffer
         _Float16* skip = l == 0 ? u->S0skip : u->CAT[l] + 2 * Cw;
         const int skip_ld = l == 0 ? 2 * Cw : 4 * Cw;
-        if (res_block(u, u->down[l][1], u->Sa[l], 2 * Cw, u->Xa[l], nseq, l, l == 3 ? u->Xb[3] : nullptr, skip, skip_ld, s))
+        if (res_block(u, u->down[l][1], u->Sa[l], 2 * Cw, u->Xa[l], nseq, l, l == 3 ? u->Xb[3] : nullptr, skip, skip_ld, s,
+                      keep ? &u->st_down[l][1] : nullptr))
             return -1;
         if (l < 3) {   // Downsample1d: Conv1d(dim, dim, 3, 2, 1)
             const int rows_out = nseq * lvl(l + 1).Tp;
@@ -611,13 +900,13 @@ int unet_forward(UnetModel* u, const float* x, const float* obs, const uint8_t* 
         }
     }
     // ---- middle -------------------------------------------------------------------------------------------
-    if (res_block(u, u->mid[0], u->CAT[3] + 2 * Cw, 4 * Cw, u->Xb[3], nseq, 3, u->Xa[3], u->Sa[3], 2 * Cw, s)) return -1;
-    if (res_block(u, u->mid[1], u->Sa[3], 2 * Cw, u->Xa[3], nseq, 3, nullptr, u->CAT[3], 4 * Cw, s)) return -1;
+    if (res_block(u, u->mid[0], u->CAT[3] + 2 * Cw, 4 * Cw, u->Xb[3], nseq, 3, u->Xa[3], u->Sa[3], 2 * Cw, s, keep ? &u->st_mid[0] : nullptr)) return -1;
+    if (res_block(u, u->mid[1], u->Sa[3], 2 * Cw, u->Xa[3], nseq, 3, nullptr, u->CAT[3], 4 * Cw, s, keep ? &u->st_mid[1] : nullptr)) return -1;
     // ---- up path: cat(x, skip) is the [left | right] halves of CAT[l] --------------------------------------
     for (int i = 0; i < 3; ++i) {
         const int l = 3 - i;
-        if (res_block(u, u->up[i][0], u->CAT[l], 4 * Cw, nullptr, nseq, l, u->Xa[l], u->Sa[l], 2 * Cw, s)) return -1;
-        if (res_block(u, u->up[i][1], u->Sa[l], 2 * Cw, u->Xa[l], nseq, l, nullptr, u->Sb[l], 2 * Cw, s)) return -1;
+        if (res_block(u, u->up[i][0], u->CAT[l], 4 * Cw, nullptr, nseq, l, u->Xa[l], u->Sa[l], 2 * Cw, s, keep ? &u->st_up[i][0] : nullptr)) return -1;
+        if (res_block(u, u->up[i][1], u->Sa[l], 2 * Cw, u->Xa[l], nseq, l, nullptr, u->Sb[l], 2 * Cw, s, keep ? &u->st_up[i][1] : nullptr)) return -1;
         // Upsample1d: ConvTranspose1d(dim, dim, 4, 2, 1): even rows taps (x[j-1] W3, x[j] W1), odd (x[j] W2, x[j+1] W0)
         _Float16* dst = l - 1 >= 1 ? u->CAT[l - 1] : u->Sa[0];
         const int dst_ld = l - 1 >= 1 ? 4 * Cw : 2 * Cw;
@@ -628,11 +917,79 @@ int unet_forward(UnetModel* u, const float* x, const float* obs, const uint8_t* 
     // ---- final_conv: Conv1dBlock(k=5) then Conv1d(dim, J, 1) -------------------------------------------------
     const int rows0 = nseq * 256;
     int nfin = 1;
-    if (conv_rows(u, u->fin, u->fin.ws, u->Sa[0], 2 * Cw, rows0, 0, 5, 2, 1, 0, 0, u->F1[0], nullptr, 0, nullptr, s, &nfin)) return -1;
-    if (group_norm(u, u->F1[0], nfin, u->fin_n, nullptr, nullptr, nullptr, u->H1S[0], 2 * Cw, nseq, 0, s)) return -1;
+    float* ffin = keep ? u->st_fin.F1 : u->F1[0];
+    if (conv_rows(u, u->fin, u->fin.ws, u->Sa[0], 2 * Cw, rows0, 0, 5, 2, 1, 0, 0, ffin, nullptr, 0, nullptr, s, &nfin)) return -1;
+    if (group_norm(u, ffin, nfin, u->fin_n, nullptr, nullptr, nullptr, u->H1S[0], 2 * Cw, nseq, 0, s, keep ? u->st_fin.st1 : nullptr)) return -1;
+    if (keep) u->st_fin.n1 = nfin;
     if (conv_rows(u, u->outc, u->outc.ws, u->H1S[0], 2 * Cw, rows0, 0, 1, 0, 1, 0, 0, u->outF, nullptr, 0, nullptr, s)) return -1;
     hipLaunchKernelGGL(unet_output_kernel, dim3((T + 255) / 256, u->J, nseq), dim3(256), 0, s, u->outF, out, u->J, T, u->Np,
                        256, 16);
+    UCHK(hipGetLastError());
+    u->stash_valid = keep;
+    return 0;
+}
+
+// gx [nseq, J, T] = (d out / d x)^T gout [nseq, J, T] for the LAST stashing forward pass (same B, nseq, T); mask as in
+// the forward (observed entries of x are replaced by obs_x0: no gradient).  gs_bits: device word holding the float bits
+// of max|gout| (launch_absmax_bits) -> power-of-two scale applied on entry and undone on exit.
+int unet_backward(UnetModel* u, const float* gout, const uint8_t* mask, const unsigned* gs_bits, int B, int nseq, int T,
+                  float* gx, hipStream_t s) {
+    if (!u->want_grad || !u->stash_valid) { u->err = "UNET backward: no stashed forward pass"; return -1; }
+    const int Cw = u->C[1];
+    auto rows = [&](int l) { return nseq * lvl(l).Tp; };
+    hipLaunchKernelGGL(unet_output_bwd_kernel, dim3(TPAD / 4, nseq), dim3(256), 0, s, gout, u->gOutS, gs_bits, u->J, T, u->Np,
+                       256, 16);
+    UCHK(hipGetLastError());
+    // final_conv.1 (1x1) and final_conv.0 (Conv5 -> GN -> Mish): d Sa0 as split rows (the upsampled frames of ups.2)
+    if (grad_gemm(u, u->gOutS, 2 * u->Np, u->outc.wb, rows(0), Cw, u->Np, 1, 0, 1, 0, 0, 0, u->GA[0], Cw, nullptr, 0, nullptr, 0, s))
+        return -1;
+    if (gn_bwd(u, u->GA[0], Cw, u->st_fin.F1, u->st_fin.n1, u->st_fin.st1, u->fin_n, nullptr, nseq, 0, s)) return -1;
+    if (grad_gemm(u, u->GS[0], 2 * Cw, u->fin.wb, rows(0), Cw, Cw, 5, 2, 1, 0, 0, 0, nullptr, Cw, u->GU[0], 2 * Cw, nullptr, 0, s))
+        return -1;
+    // ---- up path, last stage first ---------------------------------------------------------------------------------
+    for (int i = 2; i >= 0; --i) {
+        const int l = 3 - i;
+        // ConvTranspose1d(4, 2, 1) backward = stride-2 convolution over the finer level's gradient rows 2m-1 .. 2m+2
+        const _Float16* a = i == 2 ? u->GU[0] : u->GBS[l - 1];
+        const int a_ld = i == 2 ? 2 * Cw : 4 * Cw;
+        if (grad_gemm(u, a, a_ld, u->ups[i].wb, rows(l), Cw, Cw, 4, 1, 2, 0, 0, l, u->GA[l], Cw, nullptr, 0, nullptr, 0, s))
+            return -1;
+        if (res_block_bwd(u, u->up[i][1], u->st_up[i][1], u->GA[l], Cw, nullptr, nseq, l, u->GC[l], u->GU[l], s)) return -1;
+        // d cat(x, skip): left half = d x (upsampled frames of the previous stage / the middle), right half = d skip
+        if (res_block_bwd(u, u->up[i][0], u->st_up[i][0], u->GC[l], Cw, u->GU[l], nseq, l, u->GB[l], u->GBS[l], s)) return -1;
+    }
+    // ---- middle ----------------------------------------------------------------------------------------------------
+    if (res_block_bwd(u, u->mid[1], u->st_mid[1], u->GB[3], 2 * Cw, nullptr, nseq, 3, u->GA[3], nullptr, s)) return -1;
+    if (res_block_bwd(u, u->mid[0], u->st_mid[0], u->GA[3], Cw, nullptr, nseq, 3, u->GC[3], nullptr, s)) return -1;
+    {   // d skip_3 = d (middle input) + the concat's right half
+        const int64_t n = (int64_t)rows(3) * (Cw / 4);
+        hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, u->GC[3], Cw, u->GB[3] + Cw,
+                           2 * Cw, (int64_t)rows(3), Cw);
+        UCHK(hipGetLastError());
+    }
+    // ---- down path -------------------------------------------------------------------------------------------------
+    for (int l = 3; l >= 0; --l) {
+        const float* sg = (l == 3 || l == 0) ? u->GC[l] : u->GB[l] + Cw;   // d skip_l
+        const int sg_ld = (l == 3 || l == 0) ? Cw : 2 * Cw;
+        if (res_block_bwd(u, u->down[l][1], u->st_down[l][1], sg, sg_ld, nullptr, nseq, l, u->GA[l], l == 0 ? u->GU[0] : nullptr, s))
+            return -1;
+        if (l == 0) {
+            if (res_block_bwd(u, u->down[0][0], u->st_down[0][0], u->GA[0], Cw, u->GU[0], nseq, 0, u->gIn0, nullptr, s)) return -1;
+            break;
+        }
+        if (res_block_bwd(u, u->down[l][0], u->st_down[l][0], u->GA[l], Cw, nullptr, nseq, l, nullptr, u->GU[l], s)) return -1;
+        // Conv1d(3, stride 2, pad 1) backward: even finer rows 2m <- dY[m] W1^T; odd rows 2m+1 <- dY[m] W2^T + dY[m+1] W0^T;
+        // accumulated onto the concat's right half (levels 1, 2) or written (level 0: nothing else feeds skip_0)
+        float* dst = l - 1 == 0 ? u->GC[0] : u->GB[l - 1] + Cw;
+        const int dst_ld = l - 1 == 0 ? Cw : 2 * Cw;
+        const float* acc = l - 1 == 0 ? nullptr : dst;
+        if (grad_gemm(u, u->GU[l], 2 * Cw, u->downs[l - 1].wb, rows(l), Cw, Cw, 1, 0, 1, 2, 0, l - 1, dst, dst_ld, nullptr, 0, acc,
+                      dst_ld, s)) return -1;
+        if (grad_gemm(u, u->GU[l], 2 * Cw, u->downs[l - 1].wb2, rows(l), Cw, Cw, 2, 0, 1, 2, 1, l - 1, dst, dst_ld, nullptr, 0, acc,
+                      dst_ld, s)) return -1;
+    }
+    hipLaunchKernelGGL(unet_input_bwd_kernel, dim3((T + 255) / 256, u->J, nseq), dim3(256), 0, s, u->gIn0, u->added ? mask : nullptr,
+                       gs_bits, gx, B, u->J, T, u->Cin0p, 256, 16);
     UCHK(hipGetLastError());
     return 0;
 }

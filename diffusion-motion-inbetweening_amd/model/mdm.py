@@ -65,6 +65,28 @@ class OutputProcess(nn.Module):
         self.poseFinal = nn.Linear(latent_dim, input_feats)
 
 
+class _NativeDenoise(torch.autograd.Function):
+    """Differentiable (w.r.t. x) call of the native denoiser: forward = cmdi_mdm_forward with the activation
+    stash kept, backward = cmdi_mdm_vjp on that stash.  One stash per engine: the backward must run before the
+    engine's next forward (checked through a per-engine call counter)."""
+
+    @staticmethod
+    def forward(ctx, x, xin, t, eng):
+        out = eng.mdm_forward(xin, t)
+        eng._autograd_serial = getattr(eng, "_autograd_serial", 0) + 1
+        ctx.eng, ctx.serial, ctx.x_dtype = eng, eng._autograd_serial, x.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        eng = ctx.eng
+        if getattr(eng, "_autograd_serial", 0) != ctx.serial:
+            raise RuntimeError("the native denoiser keeps ONE activation stash per engine: call backward / "
+                               "torch.autograd.grad before the next model(...) call with requires_grad input")
+        gx = eng.mdm_vjp(gout.detach().to(dtype=torch.float32).contiguous())
+        return gx.to(ctx.x_dtype), None, None, None
+
+
 class MDM(nn.Module):
     def __init__(self, modeltype='', njoints=263, nfeats=1, num_actions=1, translation=True,
                  pose_rep='rot6d', glob=True, glob_rot=True, latent_dim=256, ff_size=1024,
@@ -226,15 +248,21 @@ class MDM(nn.Module):
             raise N.NativeError("MDM runs on a HIP device only (no CPU path): call model.to('cuda')")
         B, J, F, T = x.shape
         assert J * F == self.input_feats
-        eng = self.engine(device, max_batch=B, max_frames=T,
+        need_grad = torch.is_grad_enabled() and x.requires_grad
+        eng = self.engine(device, max_batch=B, max_frames=T, want_grad=need_grad,
                           n_time_rows=self.sequence_pos_encoder.pe.shape[0])
         cond = dict(batch=B, n_frames=T, cfg=cfg)
         if 'text' in self.cond_mode and not y.get('uncond', False):
             cond['enc_text'] = self.text_embedding(y, B, device)
         if cfg:
             cond['text_scale'] = torch.as_tensor(y['text_scale'], dtype=torch.float32).reshape(-1)
-        eng.set_condition(**cond)
         xin = x.detach().to(device=device, dtype=torch.float32).contiguous()
+        eng.set_condition(**cond)
+        if need_grad:
+            # torch.autograd.grad(loss(model(z, t, **kw)), z) — the reference's reconstruction-guidance and
+            # cond_fn pattern (gaussian_diffusion.py:411-416, utils/editing_util.py:276-296) — is served by the
+            # native input-VJP (cmdi_mdm_vjp): gradients flow to x only, the weights are constants.
+            return _NativeDenoise.apply(x, xin, timesteps.to(device), eng)
         return eng.mdm_forward(xin, timesteps.to(device))
 
     def forward(self, x, timesteps, y=None, obs_x0=None, obs_mask=None, cond_val=None,

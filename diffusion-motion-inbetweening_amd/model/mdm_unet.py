@@ -149,9 +149,6 @@ class MDM_UNET(nn.Module):
     def engine(self, device, max_batch, max_frames, want_grad=False, n_time_rows=1000):
         """The native engine holding this module's weights on `device` (built / grown lazily)."""
         from ..engine import Engine
-        if want_grad:
-            raise NotImplementedError("reconstruction guidance through the UNET needs its VJP (not built yet); "
-                                      "keyframes reach this denoiser through obs_x0 / obs_mask and imputation")
         device = torch.device(device)
         if device.type == 'cuda' and device.index is None:
             device = torch.device('cuda', torch.cuda.current_device())
@@ -159,15 +156,16 @@ class MDM_UNET(nn.Module):
         n_time_rows = min(int(n_time_rows), pe_rows)
         eng = self._engine
         need_new = (eng is None or eng.device != device or eng.max_batch < max_batch or eng.max_frames < max_frames
-                    or self._engine_key != self._weights_key(n_time_rows))
+                    or (want_grad and not eng.want_grad) or self._engine_key != self._weights_key(n_time_rows))
         if need_new:
             if eng is not None:
                 max_batch, max_frames = max(max_batch, eng.max_batch), max(max_frames, eng.max_frames)
+                want_grad = want_grad or eng.want_grad
                 eng.close()
             eng = Engine(n_layers=0, d_model=self.latent_dim, d_ff=0, n_heads=0, n_feats=self.input_feats,
                          max_frames=max_frames, max_batch=max_batch, pe_rows=pe_rows,
-                         text_cond='text' in self.cond_mode, arch="unet", unet_added=self.added_channels,
-                         unet_mults=self.dim_mults, device=device)
+                         text_cond='text' in self.cond_mode, want_grad=want_grad, arch="unet",
+                         unet_added=self.added_channels, unet_mults=self.dim_mults, device=device)
             sd = {k: v for k, v in self.state_dict().items() if not k.startswith('clip_model.')}
             eng.load_state_dict(sd, n_time_rows=n_time_rows)
             self._engine = eng
@@ -186,7 +184,9 @@ class MDM_UNET(nn.Module):
             raise N.NativeError("MDM_UNET runs on a HIP device only (no CPU path): call model.to('cuda')")
         B, J, F, T = x.shape
         assert J * F == self.input_feats
-        eng = self.engine(device, max_batch=B, max_frames=T, n_time_rows=self.sequence_pos_encoder.pe.shape[0])
+        need_grad = torch.is_grad_enabled() and x.requires_grad
+        eng = self.engine(device, max_batch=B, max_frames=T, want_grad=need_grad,
+                          n_time_rows=self.sequence_pos_encoder.pe.shape[0])
         cond = dict(batch=B, n_frames=T, cfg=cfg)
         if 'text' in self.cond_mode and not y.get('uncond', False):
             cond['enc_text'] = self.text_embedding(y, B, device)
@@ -196,6 +196,9 @@ class MDM_UNET(nn.Module):
             cond['obs_x0'], cond['obs_mask'] = obs_x0, obs_mask
         eng.set_condition(**cond)
         xin = x.detach().to(device=device, dtype=torch.float32).contiguous()
+        if need_grad:   # torch.autograd.grad(loss(model(z, ...)), z) through the native input-VJP (see model/mdm.py)
+            from .mdm import _NativeDenoise
+            return _NativeDenoise.apply(x, xin, timesteps.to(device), eng)
         return eng.mdm_forward(xin, timesteps.to(device))
 
     def forward(self, x, timesteps, y=None, obs_x0=None, obs_mask=None, **kwargs):

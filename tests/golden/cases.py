@@ -151,3 +151,15 @@ KEYFRAME_MODES = [  # (edit_mode, trans_length, feature_mode, n_keyframes)
     ("gmd_keyframes", 10, "pos_rot_vel", 5), ("gmd_keyframes", 10, "pos", 3),
 ]
 KEYFRAME_RANDOM_FRAMES = dict(B=3, T=196, lengths=[196, 150, 41], seed=402)   # random_frames draws 20 frames
+
+
+# ---- MDM_UNET input-VJP and reconstruction guidance through it ------------------------------------------------
+UNET_VJP_CASE = dict(UNET_CASE, seed=303, t=[333, 333], text_scale=[2.5, 1.0])
+UNET_RECON_CHAIN = dict(UNET_CHAIN, seed=304, recon_weight=20.0, stop_recguidance_at=0)
+
+
+def make_unet_vjp_inputs(case: dict = UNET_VJP_CASE) -> dict:
+    inp = make_unet_inputs(case)
+    rng = np.random.default_rng(case["seed"] + 1000)
+    inp["gout"] = np.ascontiguousarray(rng.standard_normal(inp["x"].shape), dtype=np.float32)
+    return inp

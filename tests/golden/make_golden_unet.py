@@ -67,3 +67,35 @@ with ref_shims.injected_noise(stream):
     final = diffusion.p_sample_loop(wrapped, ci["x_T"].shape, **kw)
 np.savez_compressed(HERE / "unet_chain.npz", final=final.detach().numpy(), fingerprint=cases.fingerprint(ci))
 print("chain", final.shape, float(final.abs().mean()))
+
+
+# ---- input-VJP through ClassifierFreeSampleModel(MDM_UNET): what torch.autograd.grad(loss, z) computes at
+# diffusion/gaussian_diffusion.py:411-416 -----------------------------------------------------------------------
+vc = cases.UNET_VJP_CASE
+vi = cases.make_unet_vjp_inputs()
+ref_shims.set_text_embedding(t(vi["enc_text"]))
+z = t(vi["x"]).clone().requires_grad_(True)
+yv = {"text": ["a"] * vc["B"], "mask": torch.ones(vc["B"], 1, 1, vc["T"], dtype=torch.bool), "text_scale": t(vi["text_scale"])}
+with torch.enable_grad():
+    outv = wrapped(z, t(vi["t"]), y=yv, obs_x0=t(vi["obs_x0"]), obs_mask=t(vi["obs_mask"]))
+    gxv, = torch.autograd.grad((outv * t(vi["gout"])).sum(), z)
+np.savez_compressed(HERE / "unet_vjp.npz", out=outv.detach().numpy(), gx=gxv.numpy(), fingerprint=cases.fingerprint(vi))
+print("vjp", float(gxv.abs().mean()), float(gxv[t(vi["obs_mask"])].abs().max()))
+
+# ---- the same chain with reconstruction guidance through the UNET (imputation + guidance, ragged lengths) -----
+rc = cases.UNET_RECON_CHAIN
+ri = cases.make_unet_chain_inputs(rc)
+ref_shims.set_text_embedding(t(ri["enc_text"]))
+obs_mask_r = t(ri["obs_mask"])
+yr = {"mask": t(ri["len_mask"]), "lengths": t(ri["lengths"]), "text": ["a"] * rc["B"], "text_scale": t(ri["text_scale"]),
+      "inpainting_mask": obs_mask_r, "inpainted_motion": t(ri["x0"]), "imputate": True,
+      "stop_imputation_at": rc["stop_imputation_at"], "replacement_distribution": "conditional",
+      "reconstruction_guidance": True, "reconstruction_weight": rc["recon_weight"], "gradient_schedule": None,
+      "stop_recguidance_at": rc["stop_recguidance_at"], "diffusion_steps": 1000}
+kwr = dict(noise=t(ri["x_T"]), clip_denoised=False, device=torch.device("cpu"),
+           model_kwargs={"y": yr, "obs_x0": t(ri["x0"]), "obs_mask": obs_mask_r})
+stream = [t(ri["noise"][k]) for k in range(diffusion.num_timesteps)]
+with ref_shims.injected_noise(stream):
+    final_r = diffusion.p_sample_loop(wrapped, ri["x_T"].shape, **kwr)
+np.savez_compressed(HERE / "unet_recon_chain.npz", final=final_r.detach().numpy(), fingerprint=cases.fingerprint(ri))
+print("recon chain", float(final_r.abs().mean()))

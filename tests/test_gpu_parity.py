@@ -251,6 +251,32 @@ def test_vjp_vs_reference_autograd(cases, precision):
         assert rel_l2(gk, g["gx"]) <= 5e-5, (k, rel_l2(gk, g["gx"]))
 
 
+def test_torch_autograd_through_the_native_denoiser(cases):
+    """torch.autograd.grad(loss(model(z, t, **kw)), z) — the reference's reconstruction-guidance / cond_fn pattern
+    (gaussian_diffusion.py:411-416) — runs the native forward + input-VJP behind an autograd.Function."""
+    case = cases.CASES["vjp_text_cfg"]
+    inp = cases.make_inputs(case)
+    model, _ = make_model(case)
+    g = load_golden("vjp_text_cfg")
+    z = tt(inp["x"]).requires_grad_(True)
+    y = {"text_embed": tt(inp["enc_text"]), "text_scale": tt(inp["text_scale"])}
+    with torch.enable_grad():
+        out = model(z, tt(inp["t"]), y=y)
+        assert out.requires_grad and rel_l2(out.detach().cpu().numpy(), g["out"]) <= 2e-5
+        loss = (out * tt(inp["gout"])).sum()           # d loss / d out = gout
+        gx, = torch.autograd.grad(loss, z)
+    assert rel_l2(gx.cpu().numpy(), g["gx"]) <= 5e-5, rel_l2(gx.cpu().numpy(), g["gx"])
+    # a second forward invalidates the first graph's stash: the stale backward must fail loudly
+    with torch.enable_grad():
+        o1 = model(z, tt(inp["t"]), y=y)
+        o2 = model(z, tt(inp["t"]), y=y)
+        with pytest.raises(RuntimeError):
+            torch.autograd.grad(o1.sum(), z)
+        torch.autograd.grad(o2.sum(), z)
+    with torch.no_grad():                                # no graph requested: plain forward
+        assert not model(z, tt(inp["t"]), y=y).requires_grad
+
+
 # ---- sampler arithmetic ----------------------------------------------------------------------------
 @pytest.mark.parametrize("sampler,eta", [("ddpm", 0.0), ("ddim", 0.0), ("ddim", 0.7)])
 @pytest.mark.parametrize("mode", ["plain", "impute", "recon", "recon_impute"])
@@ -546,6 +572,53 @@ def test_unet_chain_vs_reference(cases):
     final = diffusion.p_sample_loop(wrapped, ci["x_T"].shape, noise=tt(ci["x_T"]), clip_denoised=False,
                                     model_kwargs={"y": y, "obs_x0": tt(ci["x0"]), "obs_mask": obs_mask}).cpu().numpy()
     assert rel_l2(final, g["final"]) <= 1e-4, rel_l2(final, g["final"])
+
+
+def test_unet_vjp_vs_reference_autograd(cases):
+    """Input-VJP of ClassifierFreeSampleModel(MDM_UNET) (unet.hip::unet_backward) vs torch autograd through the real
+    reference on CPU; also reached through torch.autograd.grad on the native module, and linear in gout over 21 decades."""
+    vi = cases.make_unet_vjp_inputs()
+    g = load_golden("unet_vjp")
+    assert np.array_equal(g["fingerprint"], cases.fingerprint(vi))
+    model, _ = make_unet(cases)
+    wrapped = sub("model.cfg_sampler").ClassifierFreeSampleModel(model)
+    y = {"text_embed": tt(vi["enc_text"]), "text_scale": tt(vi["text_scale"])}
+    kw = dict(obs_x0=tt(vi["obs_x0"]), obs_mask=tt(vi["obs_mask"]))
+    z = tt(vi["x"]).requires_grad_(True)
+    with torch.enable_grad():
+        out = wrapped(z, tt(vi["t"]), y=y, **kw)
+        assert rel_l2(out.detach().cpu().numpy(), g["out"]) <= 2e-5
+        gx, = torch.autograd.grad((out * tt(vi["gout"])).sum(), z)
+    gx = gx.cpu().numpy()
+    assert float(np.abs(gx[vi["obs_mask"]]).max()) == 0.0          # observed entries are replaced by obs_x0
+    assert rel_l2(gx, g["gx"]) <= 5e-5, rel_l2(gx, g["gx"])
+    eng = model._engine            # the engine (and activation stash) of the forward pass above
+    assert eng is not None and eng.want_grad
+    for k in (1e-12, 1e9):
+        gk = eng.mdm_vjp(tt(vi["gout"] * np.float32(k))).cpu().numpy().astype(np.float64) / k
+        assert rel_l2(gk, g["gx"]) <= 5e-5, (k, rel_l2(gk, g["gx"]))
+
+
+def test_unet_recon_guidance_chain_vs_reference(cases):
+    """p_sample_loop with imputation AND reconstruction guidance through the native MDM_UNET vs the real reference."""
+    cc = cases.UNET_RECON_CHAIN
+    ci = cases.make_unet_chain_inputs(cc)
+    g = load_golden("unet_recon_chain")
+    assert np.array_equal(g["fingerprint"], cases.fingerprint(ci))
+    model, _ = make_unet(cases)
+    wrapped = sub("model.cfg_sampler").ClassifierFreeSampleModel(model)
+    diffusion = make_diffusion(cc["respacing"])
+    obs_mask = tt(ci["obs_mask"])
+    y = {"mask": tt(ci["len_mask"]), "lengths": tt(ci["lengths"]), "text_embed": tt(ci["enc_text"]),
+         "text_scale": tt(ci["text_scale"]), "inpainting_mask": obs_mask, "inpainted_motion": tt(ci["x0"]),
+         "imputate": True, "stop_imputation_at": cc["stop_imputation_at"], "replacement_distribution": "conditional",
+         "reconstruction_guidance": True, "reconstruction_weight": cc["recon_weight"], "gradient_schedule": None,
+         "stop_recguidance_at": cc["stop_recguidance_at"], "diffusion_steps": 1000}
+    diffusion.injected_noise = tt(ci["noise"])
+    final = diffusion.p_sample_loop(wrapped, ci["x_T"].shape, noise=tt(ci["x_T"]), clip_denoised=False,
+                                    model_kwargs={"y": y, "obs_x0": tt(ci["x0"]), "obs_mask": obs_mask}).cpu().numpy()
+    assert np.isfinite(final).all()
+    assert rel_l2(final, g["final"]) <= 2e-4, rel_l2(final, g["final"])
 
 
 def test_keyframes_mask_built_on_device(cases):
