@@ -29,6 +29,7 @@ namespace cmdi {
 namespace {
 constexpr int NG = 8;          // GroupNorm groups
 constexpr int TPAD = 224;      // the reference pads every sequence to 224 frames (mdm_unet.py:810)
+constexpr int GNB_CHUNKS = 8; // frame ranges per (sequence, group) in the GroupNorm-backward reduction
 constexpr int GUARD = 16;      // rows in front of / behind every row buffer (taps of the first / last frame)
 
 __device__ __forceinline__ float mish(float x) {
@@ -221,11 +222,15 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restri
     const int seq = blockIdx.x, g = blockIdx.y, cg = C / NG;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float mean = stats[((size_t)seq * NG + g) * 2], rstd = stats[((size_t)seq * NG + g) * 2 + 1];
-    const int q4 = cg / 4, total = Tv * q4;
+    // blockIdx.z = one of GNB_CHUNKS frame ranges of the group: 8x the blocks of a (sequence, group) grid, and the
+    // partial sums are added in chunk order by the apply kernel (deterministic)
+    const int per = (Tv + GNB_CHUNKS - 1) / GNB_CHUNKS, r0 = blockIdx.z * per;
+    const int nr = r0 < Tv ? (Tv - r0 < per ? Tv - r0 : per) : 0;
+    const int q4 = cg / 4, total = nr * q4;
     float s1 = 0.f, s2 = 0.f;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < total; i += 256) {
-        const int r = i / q4, c = g * cg + (i - r * q4) * 4;
+        const int r = r0 + i / q4, c = g * cg + (i % q4) * 4;
         const size_t row = (size_t)seq * Tp + h + r;
         const float4 fv = load_slices(f + row * C + c, nsl, sl);
         const float4 dv = *reinterpret_cast<const float4*>(dy + row * ld_dy + c);
@@ -242,8 +247,9 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restri
     __syncthreads();
     if (tid == 0) {
         const float n = (float)(Tv * cg);
-        sums[((size_t)seq * NG + g) * 2] = ((red[0] + red[1]) + (red[2] + red[3])) / n;
-        sums[((size_t)seq * NG + g) * 2 + 1] = ((red[4] + red[5]) + (red[6] + red[7])) / n;
+        float* o = sums + (((size_t)seq * NG + g) * GNB_CHUNKS + blockIdx.z) * 2;
+        o[0] = ((red[0] + red[1]) + (red[2] + red[3])) / n;
+        o[1] = ((red[4] + red[5]) + (red[6] + red[7])) / n;
     }
 }
 
@@ -262,7 +268,10 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
     for (int c = lane * 4; c < C; c += 256) {
         const int g = c / cg;
         const float mean = stats[((size_t)seq * NG + g) * 2], rstd = stats[((size_t)seq * NG + g) * 2 + 1];
-        const float m1 = sums[((size_t)seq * NG + g) * 2], m2 = sums[((size_t)seq * NG + g) * 2 + 1];
+        float m1 = 0.f, m2 = 0.f;
+        const float* sp = sums + ((size_t)seq * NG + g) * GNB_CHUNKS * 2;
+#pragma unroll
+        for (int k = 0; k < GNB_CHUNKS; ++k) { m1 += sp[2 * k]; m2 += sp[2 * k + 1]; }
         const float4 fv = load_slices(f + row * C + c, nsl, sl);
         const float4 dv = *reinterpret_cast<const float4*>(dy + row * ld_dy + c);
         const float4 ga = *reinterpret_cast<const float4*>(gamma + c), be = *reinterpret_cast<const float4*>(beta + c);
@@ -616,7 +625,7 @@ UnetModel* unet_new(int n_feats, int added, int dim, const int mults[4], int max
             if (l > 0) rc |= alloc_rows(u, &u->GB[l], rows, 2 * (size_t)Cw) | alloc_rows(u, &u->GBS[l], rows, 4 * (size_t)Cw);
         }
         rc |= alloc_rows(u, &u->gIn0, ns * 256, (size_t)u->Cin0p) | alloc_rows(u, &u->gOutS, ns * 256, 2 * (size_t)u->Np);
-        rc |= ualloc_t(u, &u->bsums, ns * NG * 2);
+        rc |= ualloc_t(u, &u->bsums, ns * NG * 2 * GNB_CHUNKS);
     }
     if (rc && u->err.empty()) u->err = "allocation failed";
     return u;
@@ -812,7 +821,7 @@ int gn_bwd(UnetModel* u, const float* dy, int ld_dy, const float* f, int nsl, co
     const Lvl L = lvl(level);
     const int C = u->C[1];
     const size_t sl = (size_t)nseq * L.Tp * C;
-    hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(nseq, NG), dim3(256), 0, s, dy, ld_dy, f, nsl, sl, stats, n.g, n.b, ss,
+    hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(nseq, NG, GNB_CHUNKS), dim3(256), 0, s, dy, ld_dy, f, nsl, sl, stats, n.g, n.b, ss,
                        u->ss_ld, u->bsums, C, L.Tp, L.h, L.Tv);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((L.Tv + 3) / 4, nseq), dim3(256), 0, s, dy, ld_dy, f, nsl, sl, stats, u->bsums,
                        n.g, n.b, ss, u->ss_ld, u->GS[level], C, L.Tp, L.h, L.Tv);
