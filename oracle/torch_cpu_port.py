@@ -95,6 +95,10 @@ class TorchCpuUNET(nn.Module):
 
     @torch.no_grad()
     def forward(self, x, t, enc_text=None, uncond=False, obs_x0=None, obs_mask=None):
+        return self.forward_impl(x, t, enc_text, uncond, obs_x0, obs_mask)
+
+    def forward_impl(self, x, t, enc_text=None, uncond=False, obs_x0=None, obs_mask=None):
+        """The same without the no_grad guard: torch autograd through it is the test reference of the native input-VJP."""
         F, w = nn.functional, self.w
         B, J, Fd, T = x.shape
         if obs_mask is not None:

@@ -599,6 +599,50 @@ def test_unet_vjp_vs_reference_autograd(cases):
         assert rel_l2(gk, g["gx"]) <= 5e-5, (k, rel_l2(gk, g["gx"]))
 
 
+@pytest.mark.parametrize("B,T,keyframe,cfg", [(3, 100, True, False), (1, 224, False, True), (2, 33, True, True)])
+def test_unet_vjp_other_configs_vs_torch_port(cases, B, T, keyframe, cfg):
+    """Other geometries of the U-Net input-VJP (frame counts, no keyframe channels -> 263-channel input, with / without
+    CFG) vs torch autograd through the CPU port (oracle/torch_cpu_port.py, itself pinned to the reference's outputs)."""
+    from oracle.torch_cpu_port import TorchCpuUNET
+    mu = sub("utils.model_util")
+    args = SimpleNamespace(dataset="humanml", arch="unet", keyframe_conditioned=keyframe, dim_mults=(1, 1, 1, 1),
+                           cond_mask_prob=0.1)
+    model, _ = mu.create_model_and_diffusion(args, None)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    mu.load_model_wo_clip(model, weights.to_torch(weights.fill_like(shapes, 77)) |
+                          {k: v for k, v in model.state_dict().items() if k.endswith(".pe")})
+    model = model.to(DEV).eval()
+    port = TorchCpuUNET({k: v.detach().cpu() for k, v in model.state_dict().items()})
+    rng = np.random.default_rng(5000 + 13 * B + T)
+    shape = (B, 263, 1, T)
+    x, gout = (rng.standard_normal(shape).astype(np.float32) for _ in range(2))
+    obs = rng.standard_normal(shape).astype(np.float32)
+    m = rng.random(shape) < 0.2
+    t = rng.integers(0, 1000, B)
+    enc = rng.standard_normal((B, 512)).astype(np.float32)
+    scale = np.linspace(0.5, 2.5, B).astype(np.float32)
+    tc = torch.from_numpy
+    okw = dict(obs_x0=tc(obs), obs_mask=tc(m)) if keyframe else {}
+    zc = tc(x).clone().requires_grad_(True)
+    with torch.enable_grad():
+        oc = port.forward_impl(zc, tc(t), tc(enc), False, **okw)
+        if cfg:
+            ou = port.forward_impl(zc, tc(t), tc(enc), True, **okw)
+            oc = ou + tc(scale).view(-1, 1, 1, 1) * (oc - ou)
+        want, = torch.autograd.grad((oc * tc(gout)).sum(), zc)
+    net = sub("model.cfg_sampler").ClassifierFreeSampleModel(model) if cfg else model
+    y = {"text_embed": tt(enc)}
+    if cfg:
+        y["text_scale"] = tt(scale)
+    gkw = dict(obs_x0=tt(obs), obs_mask=tt(m)) if keyframe else {}
+    z = tt(x).requires_grad_(True)
+    with torch.enable_grad():
+        out = net(z, tt(t), y=y, **gkw)
+        got, = torch.autograd.grad((out * tt(gout)).sum(), z)
+    assert rel_l2(out.detach().cpu().numpy(), oc.detach().numpy()) <= 2e-5
+    assert rel_l2(got.cpu().numpy(), want.numpy()) <= 5e-5, rel_l2(got.cpu().numpy(), want.numpy())
+
+
 def test_unet_recon_guidance_chain_vs_reference(cases):
     """p_sample_loop with imputation AND reconstruction guidance through the native MDM_UNET vs the real reference."""
     cc = cases.UNET_RECON_CHAIN
