@@ -599,6 +599,47 @@ def test_unet_vjp_vs_reference_autograd(cases):
         assert rel_l2(gk, g["gx"]) <= 5e-5, (k, rel_l2(gk, g["gx"]))
 
 
+def test_unet_xl_geometry_vs_torch_port(cases):
+    """The released geometry (configs/model.py motion_unet_adagn_xl: dim 512 x mults (2,2,2,2) = 1024 channels, 128 per
+    GroupNorm group) — forward and input-VJP vs the torch CPU port; the golden fixtures use 512 channels."""
+    from oracle.torch_cpu_port import TorchCpuUNET
+    mu = sub("utils.model_util")
+    args = SimpleNamespace(dataset="humanml", arch="unet", keyframe_conditioned=True, dim_mults=(2, 2, 2, 2),
+                           cond_mask_prob=0.1)
+    model, _ = mu.create_model_and_diffusion(args, None)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    mu.load_model_wo_clip(model, weights.to_torch(weights.fill_like(shapes, 78)) |
+                          {k: v for k, v in model.state_dict().items() if k.endswith(".pe")})
+    model = model.to(DEV).eval()
+    port = TorchCpuUNET({k: v.detach().cpu() for k, v in model.state_dict().items()})
+    B, T = 2, 196
+    rng = np.random.default_rng(6001)
+    shape = (B, 263, 1, T)
+    x, gout, obs = (rng.standard_normal(shape).astype(np.float32) for _ in range(3))
+    m = rng.random(shape) < 0.2
+    t = rng.integers(0, 1000, B)
+    enc = rng.standard_normal((B, 512)).astype(np.float32)
+    scale = np.asarray([2.5, 0.7], np.float32)
+    tc = torch.from_numpy
+    zc = tc(x).clone().requires_grad_(True)
+    with torch.enable_grad():
+        oc = port.forward_impl(zc, tc(t), tc(enc), False, tc(obs), tc(m))
+        ou = port.forward_impl(zc, tc(t), tc(enc), True, tc(obs), tc(m))
+        want_out = ou + tc(scale).view(-1, 1, 1, 1) * (oc - ou)
+        want_gx, = torch.autograd.grad((want_out * tc(gout)).sum(), zc)
+    net = sub("model.cfg_sampler").ClassifierFreeSampleModel(model)
+    y = {"text_embed": tt(enc), "text_scale": tt(scale)}
+    with torch.no_grad():   # plain forward (split-K at the coarse levels, no stash)
+        plain = net(tt(x), tt(t), y=y, obs_x0=tt(obs), obs_mask=tt(m)).cpu().numpy()
+    assert max_abs(plain, want_out.detach().numpy()) <= 2e-4 and rel_l2(plain, want_out.detach().numpy()) <= 2e-5
+    z = tt(x).requires_grad_(True)
+    with torch.enable_grad():
+        out = net(z, tt(t), y=y, obs_x0=tt(obs), obs_mask=tt(m))
+        got, = torch.autograd.grad((out * tt(gout)).sum(), z)
+    assert rel_l2(out.detach().cpu().numpy(), want_out.detach().numpy()) <= 2e-5
+    assert rel_l2(got.cpu().numpy(), want_gx.numpy()) <= 5e-5, rel_l2(got.cpu().numpy(), want_gx.numpy())
+
+
 @pytest.mark.parametrize("B,T,keyframe,cfg", [(3, 100, True, False), (1, 224, False, True), (2, 33, True, True)])
 def test_unet_vjp_other_configs_vs_torch_port(cases, B, T, keyframe, cfg):
     """Other geometries of the U-Net input-VJP (frame counts, no keyframe channels -> 263-channel input, with / without
