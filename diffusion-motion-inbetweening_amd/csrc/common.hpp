@@ -39,6 +39,12 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
 
 // Power-of-two "loss scale" of the reconstruction-guidance backward pass on the f16 matrix pipe:
+// x * tanh(softplus(x)), softplus with torch's threshold 20 (nn.Mish -> F.mish)
+__device__ __forceinline__ float mish_f(float x) {
+    const float sp = x > 20.f ? x : log1pf(expf(x));
+    return x * tanhf(sp);
+}
+
 // bits = float bits of max|g| over the output gradient; the scale moves that maximum to [2^6, 2^7)
 // so the whole gradient chain sits well inside the f16 range of the split operands (gemm_h3.hpp).
 // Exact (a power of two) and undone at the end of the chain, which is linear in g.

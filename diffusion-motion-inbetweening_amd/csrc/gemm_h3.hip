@@ -105,6 +105,14 @@ hipError_t launch_gemm_h3(int epi, const H3Params& p, int tile, hipStream_t s) {
     }
     if (p.ksplit > 1 && (epi != H3_PLAIN || tile == 20 || p.K / 32 < p.ksplit)) return hipErrorInvalidValue;
     if (tile == 0) tile = gemm_h3_auto_tile(p.M, p.N);
+    if (epi == H3_CONV_GN) {   // tile rows = one framed sequence: 256 (level 0) or 128 (level 1)
+        if (!p.ln_g || !p.ln_b || (!p.C && !p.Cs) || p.N % 128 != 0 || (p.gn_cg != 128 && p.gn_cg != 64) || p.M % p.tp != 0 ||
+            p.c_row_mul || p.ksplit > 1)
+            return hipErrorInvalidValue;
+        if (p.tp == 256) return launch_h3_one<H256x128s2, H3_CONV_GN>(p, s);
+        if (p.tp == 128) return launch_h3_one<H128x128w8s2, H3_CONV_GN>(p, s);
+        return hipErrorInvalidValue;
+    }
     if (epi == H3_TOKENS || epi == H3_MOTION) {   // the two I/O projections: two tile shapes only
         if (p.tok_T < 1 || p.tok_S != p.tok_T + 1) return hipErrorInvalidValue;
         if (epi == H3_TOKENS) {

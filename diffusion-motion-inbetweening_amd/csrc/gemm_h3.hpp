@@ -305,10 +305,82 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
         const int n = n0 + wn * ROWLEN + cl;     // first of this lane's 4 consecutive columns
         const bool nok = n < p.N;
         float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (EPI != H3_MOTION && p.bias && nok && kslice == 0) bias4 = *reinterpret_cast<const float4*>(p.bias + n);
+        if (EPI != H3_MOTION && EPI != H3_CONV_GN && p.bias && nok && kslice == 0) bias4 = *reinterpret_cast<const float4*>(p.bias + n);
         const int npos = split_pos(n);
         int mo_b = 0, mo_s = 0;                  // H3_MOTION: (sequence, token) of this lane's first column
         if constexpr (EPI == H3_MOTION) { mo_b = n / p.tok_S; mo_s = n - mo_b * p.tok_S; }
+        if constexpr (EPI == H3_CONV_GN) {
+            // GroupNorm over (gn_cg channels) x (the sequence's valid frames), statistics straight from the fp32
+            // accumulators: the tile is ONE framed sequence (BM == tp) and a wave's 32*TN columns lie in one group
+            __shared__ float red[2][16];
+            const int grp = (wn * ROWLEN) / p.gn_cg;               // this wave's group inside the tile
+            const float inv_n = 1.0f / (float)((p.t_hi - p.t_lo) * p.gn_cg);
+            float cb[TN], cg_[TN], cbeta[TN], csc[TN], csh[TN];
+            const int seq = m0 / p.tp;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * ROWLEN + j * 32 + l31;
+                const bool ok = col < p.N;
+                cb[j] = ok && p.bias ? p.bias[col] : 0.f;
+                cg_[j] = ok ? p.ln_g[col] : 0.f;
+                cbeta[j] = ok ? p.ln_b[col] : 0.f;
+                csc[j] = ok && p.gn_ss ? p.gn_ss[(size_t)seq * p.gn_ss_ld + col] : 0.f;
+                csh[j] = ok && p.gn_ss ? p.gn_ss[(size_t)seq * p.gn_ss_ld + p.N + col] : 0.f;
+            }
+            float s1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (wm * TM + i) * 32 + mfma32_row(r, lane);
+                    const bool valid = row >= p.t_lo && row < p.t_hi;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const float v = acc0[i][j][r] + acc1[i][j][r] * kLoInv + cb[j];
+                        acc0[i][j][r] = v;
+                        if (valid) s1 += v;
+                    }
+                }
+            s1 = wave_sum(s1);
+            if (lane == 0) red[0][wave] = s1;
+            __syncthreads();
+            float mean = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+                if (((w % TC::WN) * ROWLEN) / p.gn_cg == grp) mean += red[0][w];
+            mean *= inv_n;
+            float s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (wm * TM + i) * 32 + mfma32_row(r, lane);
+                    if (row >= p.t_lo && row < p.t_hi) {
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) { const float d = acc0[i][j][r] - mean; s2 += d * d; }
+                    }
+                }
+            s2 = wave_sum(s2);
+            if (lane == 0) red[1][wave] = s2;
+            __syncthreads();
+            float var = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+                if (((w % TC::WN) * ROWLEN) / p.gn_cg == grp) var += red[1][w];
+            const float rstd = 1.0f / sqrtf(var * inv_n + 1e-5f);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float y = (acc0[i][j][r] - mean) * rstd * cg_[j] + cbeta[j];
+                        if (p.gn_ss) y = y * (1.f + csc[j]) + csh[j];
+                        acc0[i][j][r] = mish_f(y);
+                        acc1[i][j][r] = 0.f;
+                    }
+            bias4 = make_float4(0.f, 0.f, 0.f, 0.f);   // already inside the normalised values
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -366,6 +438,25 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
                 // the next kernel then finds its input in HBM instead of the memory-side cache)
                 if constexpr (EPI == H3_PLAIN) {
                     *reinterpret_cast<float4*>(p.C + (size_t)kslice * p.slice_stride + off) = make_float4(v[0], v[1], v[2], v[3]);
+                } else if constexpr (EPI == H3_CONV_GN) {
+                    if (p.R) {
+                        const float4 rr = *reinterpret_cast<const float4*>(p.R + (p.r_ld ? (size_t)m * p.r_ld + n : off));
+                        v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+                    }
+                    if (p.C) *reinterpret_cast<float4*>(p.C + off) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (p.Cs) {
+                        h4 oh, ol;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            _Float16 a, b;
+                            split_f16(v[e], a, b);
+                            oh[e] = a; ol[e] = b;
+                            overflow |= !(fabsf(v[e]) < 65504.0f);
+                        }
+                        _Float16* dst = p.Cs + (size_t)m * (p.cs_ld ? p.cs_ld : 2 * p.N) + npos;
+                        *reinterpret_cast<h4*>(dst) = oh;
+                        *reinterpret_cast<h4*>(dst + 32) = ol;
+                    }
                 } else if constexpr (EPI == H3_RESID) {
                     if (p.Rs) {
                         const _Float16* rs = p.Rs + (size_t)m * (2 * p.N) + npos;
@@ -418,7 +509,7 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
         }
     }
     if constexpr (EPI == H3_GELU_SPLIT || EPI == H3_PLAIN_SPLIT || EPI == H3_GELUGRAD_SPLIT || EPI == H3_RESID ||
-                  EPI == H3_TOKENS) {
+                  EPI == H3_TOKENS || EPI == H3_CONV_GN) {
         if (overflow && p.range_flag) atomicOr(p.range_flag, 1);
     }
     if ((p.dbg & 16) && p.dbg_buf && tid == 0) {

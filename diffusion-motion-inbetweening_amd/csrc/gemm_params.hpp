@@ -52,6 +52,9 @@ enum H3Epi {
                         // optional); needs a tile that spans the whole row (N == BN)
     H3_TOKENS = 6,      // input projection: GEMM row m = (b, t) -> token row b*S + 1 + t of Cs:
                         // Cs = split((v + bias[n]) + pe[1 + t][n]), also written for sequence b + tok_dup (CFG)
+    H3_CONV_GN = 8,     // convolution + GroupNorm [+ AdaGN] + Mish [+ R] in one kernel: the tile owns whole (sequence, group)
+                        // blocks (BM == tp rows = one framed sequence, BN = 128 columns = 1 or 2 groups of gn_cg channels);
+                        // mean / variance from the accumulators (two block reductions), then as H3_RESID: C, Cs optional
     H3_MOTION = 7,      // output projection, roles swapped: A = weight rows (m = feature c < M), W = token rows
                         // (n = b*S + s): out[b][c][s - 1] = v + bias[c] for s >= 1  (T contiguous, fp32)
 };
@@ -66,6 +69,8 @@ struct H3Params {
     int r_ld;
     int ksplit;         // H3_PLAIN only: > 1 = that many blocks per tile, each over a slice of K; slice s writes its
     long slice_stride;  // partial sums to C + s * slice_stride (the consumer adds the slices); bias joins slice 0
+    const float* gn_ss; // H3_CONV_GN: (scale | shift) rows [seq][gn_ss_ld] of the AdaGN block, or null; ln_g / ln_b = gamma / beta
+    int gn_ss_ld, gn_cg;
     const float* pe;    // H3_TOKENS: positional table [.][N]
     int tok_T, tok_S, tok_dup;   // H3_TOKENS / H3_MOTION: frames, tokens (= frames + 1) per sequence; CFG copy offset
     const _Float16* Rs; // H3_RESID: the residual as split rows [M][2N] instead (R = hi + lo * 2^-11)

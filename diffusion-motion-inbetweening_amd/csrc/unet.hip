@@ -428,6 +428,10 @@ struct UnetModel {
     int ksplit_ok = 1;   // CMDI_UNET_KSPLIT=0: no split-K at the coarse levels
     hipEvent_t probe_ev[2] = {nullptr, nullptr};   // bench: events around ONE convolution GEMM (downs.0.1, blocks.1)
     int probe_mnk[3] = {0, 0, 0};
+    // CMDI_UNET_FUSE_GN: bit l = fuse convolution + GroupNorm at level l (0, 1); 0 = separate kernels.  Measured at B=32:
+    // level 1 (128x128 tiles, two blocks per CU) 8.83 -> 8.70 ms/step; level 0 needs 256-row tiles (one block per CU,
+    // nothing to overlap the longer epilogue with) and gains nothing, so only level 1 is on
+    int fuse_gn = 2;
     int big_tile = 0;    // CMDI_UNET_TILE: gemm_h3 tile id for the long-K convolutions that are not split
     float *tw_all = nullptr, *tb_all = nullptr;   // the 16 time_mlp.1 Linears stacked: ONE GEMM per evaluation
     int ss_ld = 0;
@@ -566,6 +570,7 @@ UnetModel* unet_new(int n_feats, int added, int dim, const int mults[4], int max
     u->J = n_feats; u->added = added; u->dim = dim; u->max_seq = max_seq; u->text = text; u->want_grad = want_grad;
     if (const char* v = std::getenv("CMDI_UNET_KSPLIT")) u->ksplit_ok = std::atoi(v);
     if (const char* v = std::getenv("CMDI_UNET_TILE")) u->big_tile = std::atoi(v);
+    if (const char* v = std::getenv("CMDI_UNET_FUSE_GN")) u->fuse_gn = std::atoi(v);
     u->C[0] = n_feats + added;
     for (int i = 0; i < 4; ++i) u->C[i + 1] = dim * mults[i];
     u->Cin0p = (u->C[0] + 31) / 32 * 32;
@@ -766,6 +771,28 @@ int group_norm(UnetModel* u, const float* x, int nsl, const GN& n, const float* 
     return 0;
 }
 
+// Conv1d(k=5) + GroupNorm [+ AdaGN] + Mish [+ resid] as ONE GEMM (H3_CONV_GN): levels 0 and 1, where a tile of
+// 256 / 128 rows is exactly one framed sequence and 128 columns are one (or two) whole groups.  Not used by a stashing
+// forward pass (the backward needs the pre-GroupNorm values) nor where split-K applies (levels 2, 3).
+bool fused_gn_ok(const UnetModel* u, int level, bool keep) {
+    const int cg = u->C[1] / NG;
+    return ((u->fuse_gn >> level) & 1) && !keep && level <= 1 && (cg == 128 || cg == 64);
+}
+int conv_gn_rows(UnetModel* u, const Conv& c, const GN& n, const _Float16* a, int a_ld, int m_rows, int level,
+                 const float* ss, const float* resid, float* out_f, _Float16* out_s, int cs_ld, hipStream_t s) {
+    const Lvl lo = lvl(level);
+    H3Params p{};
+    p.A = a - (ptrdiff_t)2 * a_ld;
+    p.W = c.ws; p.bias = c.b;
+    p.M = m_rows; p.N = c.cout; p.K = 5 * c.cin_p; p.ldc = p.N;
+    p.a_ld = a_ld; p.taps = 5; p.cpt = c.cin_p / 32;
+    p.tp = lo.Tp; p.t_lo = lo.h; p.t_hi = lo.h + lo.Tv;
+    p.ln_g = n.g; p.ln_b = n.b; p.gn_ss = ss; p.gn_ss_ld = u->ss_ld; p.gn_cg = c.cout / NG;
+    p.R = resid; p.C = out_f; p.Cs = out_s; p.cs_ld = cs_ld; p.range_flag = u->range_flag;
+    UCHK(launch_gemm_h3(H3_CONV_GN, p, 0, s));
+    return 0;
+}
+
 // ResidualTemporalBlock: xs = input rows (split, a_ld halves per row), xf = the same in fp32 (identity residual only);
 // st (a stashing forward pass): the block's own buffers for both convolution outputs and GroupNorm statistics
 int res_block(UnetModel* u, const ResBlock& r, const _Float16* xs, int a_ld, const float* xf, int nseq, int level,
@@ -773,6 +800,21 @@ int res_block(UnetModel* u, const ResBlock& r, const _Float16* xs, int a_ld, con
     const Lvl L = lvl(level);
     const int rows = nseq * L.Tp, C = r.cout;
     const float* ss = u->ss + r.ss_off;   // (scale | shift) = Linear(Mish(c)), computed for all blocks up front
+    if (fused_gn_ok(u, level, st != nullptr)) {
+        if (conv_gn_rows(u, r.c1, r.n1, xs, a_ld, rows, level, ss, nullptr, nullptr, u->H1S[level], 2 * C, s)) return -1;
+        if (!r.res.ws) {   // identity residual, added behind the Mish
+            const bool probe = u->probe_ev[0] && &r == &u->down[0][1];
+            if (probe) {
+                UCHK(hipEventRecord(u->probe_ev[0], s));
+                u->probe_mnk[0] = nseq * L.Tv; u->probe_mnk[1] = C; u->probe_mnk[2] = 5 * r.c2.cin_p;
+            }
+            if (conv_gn_rows(u, r.c2, r.n2, u->H1S[level], 2 * C, rows, level, nullptr, xf, out_f, out_s, out_ld, s)) return -1;
+            if (probe) UCHK(hipEventRecord(u->probe_ev[1], s));
+            return 0;
+        }
+        if (conv_gn_rows(u, r.c2, r.n2, u->H1S[level], 2 * C, rows, level, nullptr, nullptr, u->F1[level], nullptr, 0, s)) return -1;
+        return conv_rows(u, r.res, r.res.ws, xs, a_ld, rows, level, 1, 0, 1, 0, 0, out_f, out_s, out_ld, u->F1[level], s);
+    }
     float* f1 = st ? st->F1 : u->F1[level];
     float* f2 = st ? st->F2 : u->F2[level];
     int n1 = 1, n2 = 1;   // split-K slices the two convolutions left behind
@@ -925,11 +967,15 @@ int unet_forward(UnetModel* u, const float* x, const float* obs, const uint8_t* 
     }
     // ---- final_conv: Conv1dBlock(k=5) then Conv1d(dim, J, 1) -------------------------------------------------
     const int rows0 = nseq * 256;
+    if (fused_gn_ok(u, 0, keep)) {
+        if (conv_gn_rows(u, u->fin, u->fin_n, u->Sa[0], 2 * Cw, rows0, 0, nullptr, nullptr, nullptr, u->H1S[0], 2 * Cw, s)) return -1;
+    } else {
     int nfin = 1;
     float* ffin = keep ? u->st_fin.F1 : u->F1[0];
     if (conv_rows(u, u->fin, u->fin.ws, u->Sa[0], 2 * Cw, rows0, 0, 5, 2, 1, 0, 0, ffin, nullptr, 0, nullptr, s, &nfin)) return -1;
     if (group_norm(u, ffin, nfin, u->fin_n, nullptr, nullptr, nullptr, u->H1S[0], 2 * Cw, nseq, 0, s, keep ? u->st_fin.st1 : nullptr)) return -1;
     if (keep) u->st_fin.n1 = nfin;
+    }
     if (conv_rows(u, u->outc, u->outc.ws, u->H1S[0], 2 * Cw, rows0, 0, 1, 0, 1, 0, 0, u->outF, nullptr, 0, nullptr, s)) return -1;
     hipLaunchKernelGGL(unet_output_kernel, dim3((T + 255) / 256, u->J, nseq), dim3(256), 0, s, u->outF, out, u->J, T, u->Np,
                        256, 16);
