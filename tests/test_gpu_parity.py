@@ -599,6 +599,19 @@ def test_unet_vjp_vs_reference_autograd(cases):
         assert rel_l2(gk, g["gx"]) <= 5e-5, (k, rel_l2(gk, g["gx"]))
 
 
+@pytest.mark.parametrize("fuse", ["0", "3"])
+def test_unet_forward_groupnorm_fusion_modes(cases, monkeypatch, fuse):
+    """CMDI_UNET_FUSE_GN = 0 (separate GroupNorm kernels everywhere) and 3 (fused epilogue at levels 0 AND 1; the default
+    fuses level 1 only) give the reference's output to the same tolerance."""
+    monkeypatch.setenv("CMDI_UNET_FUSE_GN", fuse)
+    inp = cases.make_unet_inputs()
+    model, g = make_unet(cases)
+    wrapped = sub("model.cfg_sampler").ClassifierFreeSampleModel(model)
+    cfg = wrapped(tt(inp["x"]), tt(inp["t"]), y={"text_embed": tt(inp["enc_text"]), "text_scale": tt(inp["text_scale"])},
+                  obs_x0=tt(inp["obs_x0"]), obs_mask=tt(inp["obs_mask"])).cpu().numpy()
+    assert max_abs(cfg, g["out_cfg"]) <= 2e-4 and rel_l2(cfg, g["out_cfg"]) <= 2e-5, rel_l2(cfg, g["out_cfg"])
+
+
 def test_unet_xl_geometry_vs_torch_port(cases):
     """The released geometry (configs/model.py motion_unet_adagn_xl: dim 512 x mults (2,2,2,2) = 1024 channels, 128 per
     GroupNorm group) — forward and input-VJP vs the torch CPU port; the golden fixtures use 512 channels."""
