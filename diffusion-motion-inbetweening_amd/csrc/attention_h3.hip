@@ -333,20 +333,36 @@ __device__ __forceinline__ void load_row_frags(h8 fh[8], h8 fl[8], const _Float1
 
 // raw = tile · fragᵀ over the 128 head dims (A = tile rows from LDS, B = row fragments in registers), split
 // products; returns hi·hi + (hi·lo + lo·hi)·2^-11
+template <bool BATCH = true>
 __device__ __forceinline__ f32x16 tile_dot_h3(const char* tile, const h8 fh[8], const h8 fl[8], int l31, int hi) {
     f32x16 a0, a1, a2;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; a2[r] = 0.f; }
     const int fk = kswz(l31);
     const char* rowp = tile + l31 * ROWB;
+    // two half-passes of 4 k-steps: the 8 fragment reads of a half are issued back to back, then its 12 MFMAs —
+    // one LDS round trip per half instead of one per read (at one wave per SIMD nothing else hides that latency)
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-        const int t = (ks >> 1) * 8 + (ks & 1) * 2 + hi;
-        const h8 th = *reinterpret_cast<const h8*>(rowp + ((t ^ fk) << 4));
-        const h8 tl = *reinterpret_cast<const h8*>(rowp + (((t + 4) ^ fk) << 4));
-        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(th, fh[ks], a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(th, fl[ks], a1, 0, 0, 0);
-        a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl, fh[ks], a2, 0, 0, 0);
+    for (int half = 0; half < 2; ++half) {
+        h8 th[4], tl[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ks = half * 4 + q;
+            const int t = (ks >> 1) * 8 + (ks & 1) * 2 + hi;
+            th[q] = *reinterpret_cast<const h8*>(rowp + ((t ^ fk) << 4));
+            tl[q] = *reinterpret_cast<const h8*>(rowp + (((t + 4) ^ fk) << 4));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ks = half * 4 + q;
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[q], fh[ks], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[q], fl[ks], a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl[q], fh[ks], a2, 0, 0, 0);
+        }
+        if constexpr (BATCH) {   // (the dV kernel runs two waves per SIMD in 248 registers: pinning costs it spills)
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);    // 8 DS reads
+            __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);   // 12 MFMAs
+        }
     }
     f32x16 o;
 #pragma unroll
@@ -400,6 +416,8 @@ __device__ __forceinline__ void acc_unbounded(f32x16 o0[4], f32x16 o1[4], const 
         for (int db = 0; db < 4; ++db) o1[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[db], xl, o1[db], 0, 0, 0);
 #pragma unroll
         for (int db = 0; db < 4; ++db) o1[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl[db], xh, o1[db], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);   // the 16 transpose reads of this k-step back to back,
+        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);   // then its 12 MFMAs: one LDS round trip per k-step
     }
 }
 
@@ -447,6 +465,15 @@ __device__ __forceinline__ void store_split_head(_Float16* dst, const f32x16 v[4
 }
 }  // namespace
 
+// Backward grid: 2 blocks (row halves) per (sequence, head), both streaming the same tiles of the other operand.  Linear
+// block ids are dealt round-robin over the 8 XCDs, so ids i and i + 8 share an XCD and start together: pairing the two
+// halves that way lets the second reader find the tiles in that XCD's L2 instead of fetching them from HBM again.
+__device__ __forceinline__ void bwd_block(int id, int nbh, int& bh, int& half) {
+    const int full = nbh & ~7;
+    if (id < 2 * full) { bh = ((id >> 4) << 3) | (id & 7); half = (id >> 3) & 1; }
+    else { const int r = id - 2 * full; bh = full + (r >> 1); half = r & 1; }
+}
+
 // ---- dQ: wave = 32 queries, loop over key tiles --------------------------------------------------------
 __global__ __launch_bounds__(64 * BW, 1) void attn_bwd_q_h3_kernel(const _Float16* __restrict__ qkv,
                                                                    const _Float16* __restrict__ d_o,
@@ -457,12 +484,15 @@ __global__ __launch_bounds__(64 * BW, 1) void attn_bwd_q_h3_kernel(const _Float1
     extern __shared__ __attribute__((aligned(16))) char lds[];  // [2][K tile | V tile]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    int bh, half;
+    bwd_block(blockIdx.x, gridDim.x >> 1, bh, half);
+    if (half * BW * 32 >= S) return;   // short sequences: the second half block has no rows (whole block, before any barrier)
+    const int b = bh / H, h = bh % H;
     const int d_model = H * DH;
     const size_t ld = 6 * (size_t)d_model, ldo = 2 * (size_t)d_model;
     const int qoff = 2 * h * DH, koff = 2 * (d_model + h * DH), voff = 2 * (2 * d_model + h * DH);
     const _Float16* base = qkv + (size_t)b * S * ld;
-    const int q0 = (blockIdx.y * BW + wave) * 32;
+    const int q0 = (half * BW + wave) * 32;
     const bool active = q0 < S;
     const int q = q0 + l31;
     const bool qok = active && q < S;
@@ -535,13 +565,16 @@ __global__ __launch_bounds__(64 * BW, WHICH == 1 ? 2 : 1) void attn_bwd_kv_h3_ke
     constexpr int BSTAGE = STAGE + 512;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    int bh, half;
+    bwd_block(blockIdx.x, gridDim.x >> 1, bh, half);
+    if (half * BW * 32 >= S) return;   // short sequences: the second half block has no rows (whole block, before any barrier)
+    const int b = bh / H, h = bh % H;
     const int d_model = H * DH;
     const size_t ld = 6 * (size_t)d_model, ldo = 2 * (size_t)d_model;
     const int qoff = 2 * h * DH, koff = 2 * (d_model + h * DH), voff = 2 * (2 * d_model + h * DH);
     const _Float16* base = qkv + (size_t)b * S * ld;
     const _Float16* dobase = d_o + (size_t)b * S * ldo;
-    const int k0 = (blockIdx.y * BW + wave) * 32;
+    const int k0 = (half * BW + wave) * 32;
     const bool active = k0 < S;
     const int key = k0 + l31;
     const bool kok = active && key < S;
@@ -586,7 +619,7 @@ __global__ __launch_bounds__(64 * BW, WHICH == 1 ? 2 : 1) void attn_bwd_kv_h3_ke
             const char* qt = lds + cur * BSTAGE;
             const char* dot = qt + TILE;
             const float* sp = reinterpret_cast<const float*>(qt + STAGE);
-            const f32x16 s = tile_dot_h3(qt, kh, kl, l31, hi);     // S (unscaled): lane = key, regs = queries
+            const f32x16 s = tile_dot_h3<WHICH == 0>(qt, kh, kl, l31, hi);     // S (unscaled): lane = key, regs = queries
             float p[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -667,7 +700,8 @@ hipError_t launch_attention_bwd_h3(const _Float16* qkv_split, const float* o_fwd
     const int rows = n_seq * S;
     hipLaunchKernelGGL(rowdot_heads_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, d_out, o_fwd, d_rowdot,
                        rows, S, H);
-    const dim3 grid(n_seq * H, (S + 32 * BW - 1) / (32 * BW)), block(64 * BW);
+    static_assert(32 * BW * 2 >= 224, "two row halves cover S <= 224");
+    const dim3 grid(2 * n_seq * H), block(64 * BW);
     hipLaunchKernelGGL(attn_bwd_q_h3_kernel, grid, block, lds_q, stream, qkv_split, d_out_split, row_stats,
                        d_rowdot, d_qkv_split, S, H, scale);
     hipLaunchKernelGGL(attn_bwd_kv_h3_kernel<0>, grid, block, lds_kv, stream, qkv_split, d_out_split, row_stats,
