@@ -32,11 +32,7 @@ constexpr int TPAD = 224;      // the reference pads every sequence to 224 frame
 constexpr int GNB_CHUNKS = 8; // frame ranges per (sequence, group) in the GroupNorm-backward reduction
 constexpr int GUARD = 16;      // rows in front of / behind every row buffer (taps of the first / last frame)
 
-__device__ __forceinline__ float mish(float x) {
-    // x * tanh(softplus(x)), softplus with torch's threshold 20 (nn.Mish -> F.mish)
-    const float sp = x > 20.f ? x : log1pf(expf(x));
-    return x * tanhf(sp);
-}
+__device__ __forceinline__ float mish(float x) { return mish_f(x); }   // common.hpp: one exponential + one division
 
 // ---- input frames: x' = obs*m + x*(1-m), cat(x', m), zero channel padding; CFG: both passes get the same rows ----
 // x, obs [B, J, T] (T contiguous), mask u8 [B, J, T]; out split rows [nseq * Tp, 2*Cp]; one block per (seq, frame tile)
@@ -187,13 +183,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
 }
 
 // ---- input-VJP pieces (reconstruction guidance through the U-Net): everything is linear in the output gradient ----
-__device__ __forceinline__ float mish_grad(float z) {
-    // d/dz [z tanh(softplus(z))] = tanh(sp) + z (1 - tanh(sp)^2) sigmoid(z);  softplus' = 1 beyond torch's threshold
-    const float sp = z > 20.f ? z : log1pf(expf(z));
-    const float ts = tanhf(sp);
-    const float sg = z > 20.f ? 1.f : 1.f / (1.f + expf(-z));
-    return ts + z * (1.f - ts * ts) * sg;
-}
+__device__ __forceinline__ float mish_grad(float z) { return mish_grad_f(z); }
 
 // g = dY * Mish'(z) * (1 + scale) * gamma,  z = (xhat * gamma + beta) [* (1 + scale) + shift],  xhat = (F - mean) * rstd
 __device__ __forceinline__ void gn_bwd_terms(const float4 f, const float4 dy, float mean, float rstd, const float4 ga,
