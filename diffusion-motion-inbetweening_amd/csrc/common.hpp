@@ -38,7 +38,6 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
 
-// Power-of-two "loss scale" of the reconstruction-guidance backward pass on the f16 matrix pipe:
 // Mish(x) = x tanh(softplus(x)) (nn.Mish, softplus threshold 20).  With w = e^x: tanh(ln(1 + w)) = n / (n + 2), n = w (w + 2)
 // — ONE exponential and one division instead of expf + log1pf + tanhf (the libm trio made the GroupNorm kernels
 // VALU-bound); same fp32 accuracy (max rel. error 3.4e-7 vs 2.6e-7 for the three-call form, against float64).
@@ -55,6 +54,7 @@ __device__ __forceinline__ float mish_grad_f(float x) {
     return t + x * (2.f * u * (1.f + t)) * (w / (1.f + w));
 }
 
+// Power-of-two "loss scale" of the reconstruction-guidance backward pass on the f16 matrix pipe:
 // bits = float bits of max|g| over the output gradient; the scale moves that maximum to [2^6, 2^7)
 // so the whole gradient chain sits well inside the f16 range of the split operands (gemm_h3.hpp).
 // Exact (a power of two) and undone at the end of the chain, which is linear in g.
