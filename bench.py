@@ -335,8 +335,9 @@ def main():
         if pmc.exists():
             traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
         ach = flop_launch / avg_s / 1e12
-        if is_unet:
-            traffic = None   # no PMC pass committed for this shape
+        if is_unet:   # PMC passes of the level-0 convolution GEMM (tools/conv_pmc.py)
+            pmc_u = REPO / "profiles" / "pmc_unet_conv_gemm.json"
+            traffic = json.loads(pmc_u.read_text()).get("hbm_bytes_per_launch") if pmc_u.exists() else None
         if split:
             # algorithmic flops = 2MNK of the fp32 product; the kernel executes 3 f16 MFMA products
             # per algorithmic product, so its ceiling is the dense f16 peak / 3

@@ -78,7 +78,7 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
         if (p.ksplit > 1) { nslice = p.ksplit; kslice = block_id % nslice; block_id /= nslice; }
     }
     const int bid = xcd_remap(block_id, tiles_m * tiles_n);
-    const int m0 = m_begin + (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+    const int m0 = m_begin + (p.m_fast ? bid % tiles_m : bid / tiles_n) * BM, n0 = (p.m_fast ? bid / tiles_m : bid % tiles_n) * BN;
 
     long long t_start = 0, t_loop = 0, t_loop_end = 0, r_start = 0;
     if (p.dbg & 16) { t_start = __builtin_readcyclecounter(); r_start = __builtin_amdgcn_s_memrealtime(); }

@@ -67,6 +67,7 @@ struct H3Params {
     _Float16* Cs;       // split output [M][2N]
     const float* R;     // residual [M][r_ld ? r_ld : ldc]
     int r_ld;
+    int m_fast;         // 1: consecutive block ids walk down a column of tiles (same W panel) instead of along a row
     int ksplit;         // H3_PLAIN only: > 1 = that many blocks per tile, each over a slice of K; slice s writes its
     long slice_stride;  // partial sums to C + s * slice_stride (the consumer adds the slices); bias joins slice 0
     const float* gn_ss; // H3_CONV_GN: (scale | shift) rows [seq][gn_ss_ld] of the AdaGN block, or null; ln_g / ln_b = gamma / beta

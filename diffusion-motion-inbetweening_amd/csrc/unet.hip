@@ -422,6 +422,7 @@ struct UnetModel {
     // level 1 (128x128 tiles, two blocks per CU) 8.83 -> 8.70 ms/step; level 0 needs 256-row tiles (one block per CU,
     // nothing to overlap the longer epilogue with) and gains nothing, so only level 1 is on
     int fuse_gn = 2;
+    int m_fast = 0;      // CMDI_UNET_MFAST: tile order of the convolution GEMMs (gemm_params.hpp)
     int big_tile = 0;    // CMDI_UNET_TILE: gemm_h3 tile id for the long-K convolutions that are not split
     float *tw_all = nullptr, *tb_all = nullptr;   // the 16 time_mlp.1 Linears stacked: ONE GEMM per evaluation
     int ss_ld = 0;
@@ -560,6 +561,7 @@ UnetModel* unet_new(int n_feats, int added, int dim, const int mults[4], int max
     u->J = n_feats; u->added = added; u->dim = dim; u->max_seq = max_seq; u->text = text; u->want_grad = want_grad;
     if (const char* v = std::getenv("CMDI_UNET_KSPLIT")) u->ksplit_ok = std::atoi(v);
     if (const char* v = std::getenv("CMDI_UNET_TILE")) u->big_tile = std::atoi(v);
+    if (const char* v = std::getenv("CMDI_UNET_MFAST")) u->m_fast = std::atoi(v);
     if (const char* v = std::getenv("CMDI_UNET_FUSE_GN")) u->fuse_gn = std::atoi(v);
     u->C[0] = n_feats + added;
     for (int i = 0; i < 4; ++i) u->C[i + 1] = dim * mults[i];
@@ -728,6 +730,7 @@ int conv_rows(UnetModel* u, const Conv& c, const _Float16* ws, const _Float16* a
     p.c_row_mul = c_mul; p.c_row_add = c_add; p.tp = lo.Tp; p.t_lo = lo.h; p.t_hi = lo.h + lo.Tv;
     p.cs_ld = cs_ld; p.range_flag = u->range_flag;
     int kind, tile = 0;
+    p.m_fast = u->m_fast;
     if (resid) { kind = H3_RESID; p.R = resid; p.C = out_f; p.Cs = out_s; }
     else if (out_s) { kind = H3_PLAIN_SPLIT; p.Cs = out_s; p.aux = out_f; }
     else {
@@ -777,6 +780,7 @@ int conv_gn_rows(UnetModel* u, const Conv& c, const GN& n, const _Float16* a, in
     p.M = m_rows; p.N = c.cout; p.K = 5 * c.cin_p; p.ldc = p.N;
     p.a_ld = a_ld; p.taps = 5; p.cpt = c.cin_p / 32;
     p.tp = lo.Tp; p.t_lo = lo.h; p.t_hi = lo.h + lo.Tv;
+    p.m_fast = u->m_fast;
     p.ln_g = n.g; p.ln_b = n.b; p.gn_ss = ss; p.gn_ss_ld = u->ss_ld; p.gn_cg = c.cout / NG;
     p.R = resid; p.C = out_f; p.Cs = out_s; p.cs_ld = cs_ld; p.range_flag = u->range_flag;
     UCHK(launch_gemm_h3(H3_CONV_GN, p, 0, s));
