@@ -35,29 +35,44 @@ constexpr int GUARD = 16;      // rows in front of / behind every row buffer (ta
 __device__ __forceinline__ float mish(float x) { return mish_f(x); }   // common.hpp: one exponential + one division
 
 // ---- input frames: x' = obs*m + x*(1-m), cat(x', m), zero channel padding; CFG: both passes get the same rows ----
-// x, obs [B, J, T] (T contiguous), mask u8 [B, J, T]; out split rows [nseq * Tp, 2*Cp]; one block per (seq, frame tile)
+// x, obs [B, J, T] (T contiguous), mask u8 [B, J, T]; out split rows [nseq * Tp, 2*Cp].  A block transposes 16 frames of
+// one sequence through LDS: the reads run along T, the writes along the channels (both coalesced).
+constexpr int IN_FR = 16;
 __global__ __launch_bounds__(256) void unet_input_kernel(const float* __restrict__ x, const float* __restrict__ obs,
                                                          const uint8_t* __restrict__ mask, _Float16* __restrict__ out,
                                                          int B, int J, int T, int Cp, int Tp, int h, int keyframe) {
+    extern __shared__ float tile[];                    // [Cp][IN_FR + 1]
     const int seq = blockIdx.y, b = seq % B;           // sequences: [cond B | uncond B]
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6); // 4 frames per block
-    if (t >= TPAD) return;
-    const int lane = threadIdx.x & 63;
-    _Float16* row = out + ((size_t)seq * Tp + h + t) * (2 * Cp);
-    for (int c = lane; c < Cp; c += 64) {
+    const int t0 = blockIdx.x * IN_FR;
+    const int tx = threadIdx.x & (IN_FR - 1), ty = threadIdx.x / IN_FR;   // 16 frames x 16 channel lanes
+    const int t = t0 + tx;
+    for (int c = ty; c < Cp; c += 256 / IN_FR) {
         float v = 0.f;
         if (t < T) {
             if (c < J) {
-                v = x[((size_t)b * J + c) * T + t];
-                if (keyframe && mask[((size_t)b * J + c) * T + t]) v = obs[((size_t)b * J + c) * T + t];
+                const size_t i = ((size_t)b * J + c) * T + t;
+                v = (keyframe && mask[i]) ? obs[i] : x[i];
             } else if (keyframe && c < 2 * J) {
                 v = mask[((size_t)b * J + (c - J)) * T + t] ? 1.f : 0.f;
             }
         }
-        _Float16 a, l;
-        split_f16(v, a, l);
-        row[split_pos(c)] = a;
-        row[split_pos(c) + 32] = l;
+        tile[c * (IN_FR + 1) + tx] = v;
+    }
+    __syncthreads();
+    const int chunks = Cp >> 3;                        // 8 consecutive channels per item
+    for (int it = threadIdx.x; it < IN_FR * chunks; it += 256) {
+        const int fr = it / chunks, c = (it - fr * chunks) * 8;
+        if (t0 + fr >= TPAD) continue;
+        h8 oh, ol;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            _Float16 a, l;
+            split_f16(tile[(c + e) * (IN_FR + 1) + fr], a, l);
+            oh[e] = a; ol[e] = l;
+        }
+        _Float16* d = out + ((size_t)seq * Tp + h + t0 + fr) * (2 * (size_t)Cp) + split_pos(c);
+        *reinterpret_cast<h8*>(d) = oh;
+        *reinterpret_cast<h8*>(d + 32) = ol;
     }
 }
 
@@ -921,8 +936,8 @@ int unet_forward(UnetModel* u, const float* x, const float* obs, const uint8_t* 
         r.M = nseq; r.N = u->ss_ld; r.K = dim; r.lda = dim; r.ldw = dim; r.ldc = u->ss_ld; r.out_scale = 1.f;
         UCHK(launch_gemm(GK_PLAIN, r, 4, s));
     }
-    hipLaunchKernelGGL(unet_input_kernel, dim3(TPAD / 4, nseq), dim3(256), 0, s, x, obs, mask, u->in0S, B, u->J, T,
-                       u->Cin0p, 256, 16, u->added ? 1 : 0);
+    hipLaunchKernelGGL(unet_input_kernel, dim3(TPAD / IN_FR, nseq), dim3(256), (size_t)u->Cin0p * (IN_FR + 1) * sizeof(float), s,
+                       x, obs, mask, u->in0S, B, u->J, T, u->Cin0p, 256, 16, u->added ? 1 : 0);
     UCHK(hipGetLastError());
 
     // ---- down path: the second block of each level is the skip (h.append(x)) and feeds the downsample ----
