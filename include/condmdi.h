@@ -61,7 +61,7 @@ typedef struct {
     int32_t max_batch;   /* largest B (samples, before the CFG doubling)       */
     int32_t pe_rows;     /* rows of sequence_pos_encoder.pe (5000)             */
     int32_t text_cond;   /* 1 if cond_mode contains 'text' (embed_text exists) */
-    int32_t want_grad;   /* 1: allocate the activation stash for cmdi_mdm_vjp  */
+    int32_t want_grad;   /* 1: allocate the activation stash for cmdi_mdm_vjp (both architectures) */
     int32_t precision;   /* CMDI_PREC_*                                        */
     int32_t arch;        /* CMDI_ARCH_TRANS_ENC (MDM, model/mdm.py) or CMDI_ARCH_UNET (MDM_UNET, model/mdm_unet.py:561-849;
                             n_layers / d_ff / n_heads unused, d_model = latent_dim = 512)                        */
@@ -151,7 +151,8 @@ int cmdi_mdm_forward(cmdi_handle h, const float* d_x, const int64_t* d_t, float*
 /* Vector-Jacobian product of the (CFG-combined) denoiser output w.r.t. d_x, evaluated at the
  * inputs of the LAST cmdi_mdm_forward on this handle (needs want_grad=1).  Replaces
  * torch.autograd.grad(loss, z) in the reconstruction-guidance block
- * (diffusion/gaussian_diffusion.py:411-416).  d_gout, d_gx: [B,J,1,T]. */
+ * (diffusion/gaussian_diffusion.py:411-416).  d_gout, d_gx: [B,J,1,T].  CMDI_ARCH_UNET: the same through the
+ * U-Net (entries of x replaced by obs_x0 get gradient 0, as x = obs*m + x*~m at model/mdm_unet.py:781). */
 int cmdi_mdm_vjp(cmdi_handle h, const float* d_gout, float* d_gx, cmdi_stream stream);
 
 /* ---- sampler --------------------------------------------------------------------------------
