@@ -219,3 +219,19 @@ def test_get_keyframes_mask_bit_exact_vs_reference(cases):
             eu.get_keyframes_mask(data, lengths, edit_mode=bad)
     with pytest.raises(ValueError):
         eu.get_keyframes_mask(torch.zeros(1, 100, 1, 8), torch.tensor([8]))
+
+
+def test_bench_work_counts_match_the_scope_table():
+    """bench.py's algorithmic FLOP counts: SURVEY.md §8d gives 7,353,212,928 per sample-evaluation of MDM (T=196)
+    and 2.141 GF for config 1 (T=60, no text); the U-Net count is dominated by its k=5 convolutions."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", str(REPO / "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.flops_per_sample_eval() == 7_353_212_928
+    c1 = b.flops_per_sample_eval(T=60) - 2 * 512 * 512          # config 1 has no text branch
+    assert abs(c1 - 2_141_151_232) <= 1
+    u = b.unet_flops_per_sample_eval()
+    conv5 = 2.0 * 224 * 5 * 1024 * 1024                          # one level-0 k=5 convolution: 2.35 GF
+    assert 34.3e9 < u < 34.5e9 and 14 < u / conv5 < 15            # 34.37 GF = 14.6 level-0 convolutions' worth
+    assert set(b.CONFIGS) >= {"c2", "c3", "c4", "unet", "unet_recon"} and b.CONFIGS["c2"]["B"] == 32
