@@ -218,7 +218,8 @@ __device__ __forceinline__ void gn_bwd_terms(const float4 f, const float4 dy, fl
 }
 
 // GroupNorm backward, pass 1: per (sequence, group) means of g and g * xhat over the group's valid frames
-__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restrict__ dy, int ld_dy, const float* __restrict__ f,
+__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restrict__ dy, int ld_dy, int nsl_dy, size_t sl_dy,
+                                                           const float* __restrict__ f,
                                                            int nsl, size_t sl, const float* __restrict__ stats,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ ss, int ss_ld, float* __restrict__ sums,
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restri
         const int r = r0 + i / q4, c = g * cg + (i % q4) * 4;
         const size_t row = (size_t)seq * Tp + h + r;
         const float4 fv = load_slices(f + row * C + c, nsl, sl);
-        const float4 dv = *reinterpret_cast<const float4*>(dy + row * ld_dy + c);
+        const float4 dv = load_slices(dy + row * ld_dy + c, nsl_dy, sl_dy);   // (split-K slices of the producing GEMM)
         const float4 ga = *reinterpret_cast<const float4*>(gamma + c), be = *reinterpret_cast<const float4*>(beta + c);
         const float4 sc = ss ? *reinterpret_cast<const float4*>(ss + (size_t)seq * ss_ld + c) : zero;
         const float4 sh = ss ? *reinterpret_cast<const float4*>(ss + (size_t)seq * ss_ld + C + c) : zero;
@@ -259,7 +260,8 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restri
 }
 
 // pass 2: dF = rstd * (g - mean(g) - xhat * mean(g xhat)) -> split rows (the A operand of the transposed convolution)
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ dy, int ld_dy, const float* __restrict__ f,
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ dy, int ld_dy, int nsl_dy, size_t sl_dy,
+                                                           const float* __restrict__ f,
                                                            int nsl, size_t sl, const float* __restrict__ stats,
                                                            const float* __restrict__ sums, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ ss,
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
 #pragma unroll
         for (int k = 0; k < GNB_CHUNKS; ++k) { m1 += sp[2 * k]; m2 += sp[2 * k + 1]; }
         const float4 fv = load_slices(f + row * C + c, nsl, sl);
-        const float4 dv = *reinterpret_cast<const float4*>(dy + row * ld_dy + c);
+        const float4 dv = load_slices(dy + row * ld_dy + c, nsl_dy, sl_dy);   // (split-K slices of the producing GEMM)
         const float4 ga = *reinterpret_cast<const float4*>(gamma + c), be = *reinterpret_cast<const float4*>(beta + c);
         const float4 sc = ss ? *reinterpret_cast<const float4*>(ss + (size_t)seq * ss_ld + c) : zero;
         const float4 sh = ss ? *reinterpret_cast<const float4*>(ss + (size_t)seq * ss_ld + C + c) : zero;
@@ -632,7 +634,8 @@ UnetModel* unet_new(int n_feats, int added, int dim, const int mults[4], int max
         rc |= stash(u->st_fin, 0, false);
         for (int l = 0; l < 4 && !rc; ++l) {
             const size_t rows = ns * (size_t)(256 >> l);
-            rc |= alloc_rows(u, &u->GA[l], rows, Cw) | alloc_rows(u, &u->GC[l], rows, Cw) | alloc_rows(u, &u->GT[l], rows, Cw);
+            const size_t trows = rows > 8192 ? rows : 8192;   // d h1 may arrive as up to 4 split-K slices
+            rc |= alloc_rows(u, &u->GA[l], rows, Cw) | alloc_rows(u, &u->GC[l], rows, Cw) | alloc_rows(u, &u->GT[l], trows, Cw);
             rc |= alloc_rows(u, &u->GS[l], rows, 2 * (size_t)Cw) | alloc_rows(u, &u->GU[l], rows, 2 * (size_t)Cw);
             if (l > 0) rc |= alloc_rows(u, &u->GB[l], rows, 2 * (size_t)Cw) | alloc_rows(u, &u->GBS[l], rows, 4 * (size_t)Cw);
         }
@@ -849,12 +852,23 @@ int res_block(UnetModel* u, const ResBlock& r, const _Float16* xs, int a_ld, con
 // one GEMM over gradient rows: C[M', N] (+)= A-rows (tap-shifted, strided) x W^T, frames only (halo rows stay zero)
 int grad_gemm(UnetModel* u, const _Float16* a, int a_ld, const _Float16* w, int M, int N, int K1, int taps, int pad,
               int a_mul, int c_mul, int c_add, int level_out, float* out_f, int ldc, _Float16* out_s, int cs_ld,
-              const float* resid, int r_ld, hipStream_t s) {
+              const float* resid, int r_ld, hipStream_t s, int* nsl_out = nullptr) {
     const Lvl lo = lvl(level_out);
     H3Params p{};
     p.A = a - (ptrdiff_t)pad * a_ld;
     p.W = w;
     p.M = M; p.N = N; p.K = taps * K1; p.ldc = ldc;
+    int tile = 0;
+    if (nsl_out) {   // plain fp32 output read back by a GroupNorm-backward kernel: split-K at the coarse levels, as in the forward
+        const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+        *nsl_out = 1;
+        if (!resid && !out_s && u->ksplit_ok && tiles <= 256 && p.K >= 2048 && ldc == N) {
+            p.ksplit = tiles <= 128 ? 4 : 2;
+            p.slice_stride = (long)M * N;
+            tile = 8;
+            *nsl_out = p.ksplit;
+        }
+    }
     p.a_ld = a_ld; p.a_row_mul = a_mul; p.taps = taps; p.cpt = K1 / 32;
     p.c_row_mul = c_mul; p.c_row_add = c_add; p.tp = lo.Tp; p.t_lo = lo.h; p.t_hi = lo.h + lo.Tv;
     p.cs_ld = cs_ld;
@@ -862,19 +876,19 @@ int grad_gemm(UnetModel* u, const _Float16* a, int a_ld, const _Float16* w, int 
     if (resid) { kind = H3_RESID; p.R = resid; p.r_ld = r_ld; p.C = out_f; p.Cs = out_s; }
     else if (out_s) { kind = H3_PLAIN_SPLIT; p.Cs = out_s; p.aux = out_f; }
     else { kind = H3_PLAIN; p.C = out_f; }
-    UCHK(launch_gemm_h3(kind, p, 0, s));
+    UCHK(launch_gemm_h3(kind, p, tile, s));
     return 0;
 }
 
 // dF (split rows in u->GS[level]) of Mish(GroupNorm(F) [* (1 + scale) + shift]) given d out = dy
 int gn_bwd(UnetModel* u, const float* dy, int ld_dy, const float* f, int nsl, const float* stats, const GN& n,
-           const float* ss, int nseq, int level, hipStream_t s) {
+           const float* ss, int nseq, int level, hipStream_t s, int nsl_dy = 1) {
     const Lvl L = lvl(level);
     const int C = u->C[1];
     const size_t sl = (size_t)nseq * L.Tp * C;
-    hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(nseq, NG, GNB_CHUNKS), dim3(256), 0, s, dy, ld_dy, f, nsl, sl, stats, n.g, n.b, ss,
-                       u->ss_ld, u->bsums, C, L.Tp, L.h, L.Tv);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((L.Tv + 3) / 4, nseq), dim3(256), 0, s, dy, ld_dy, f, nsl, sl, stats, u->bsums,
+    hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(nseq, NG, GNB_CHUNKS), dim3(256), 0, s, dy, ld_dy, nsl_dy, sl, f, nsl, sl, stats,
+                       n.g, n.b, ss, u->ss_ld, u->bsums, C, L.Tp, L.h, L.Tv);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((L.Tv + 3) / 4, nseq), dim3(256), 0, s, dy, ld_dy, nsl_dy, sl, f, nsl, sl, stats, u->bsums,
                        n.g, n.b, ss, u->ss_ld, u->GS[level], C, L.Tp, L.h, L.Tv);
     UCHK(hipGetLastError());
     return 0;
@@ -889,10 +903,11 @@ int res_block_bwd(UnetModel* u, const ResBlock& r, const RBStash& st, const floa
     const float* ss = u->ss + r.ss_off;
     // out = Mish(GN2(conv2(h1))) + R(x)
     if (gn_bwd(u, dy, ld_dy, st.F2, st.n2, st.st2, r.n2, nullptr, nseq, level, s)) return -1;
-    if (grad_gemm(u, u->GS[level], 2 * C, r.c2.wb, rows, C, C, 5, 2, 1, 0, 0, level, u->GT[level], C, nullptr, 0, nullptr, 0, s))
+    int nt = 1;   // split-K slices of d h1
+    if (grad_gemm(u, u->GS[level], 2 * C, r.c2.wb, rows, C, C, 5, 2, 1, 0, 0, level, u->GT[level], C, nullptr, 0, nullptr, 0, s, &nt))
         return -1;
     // h1 = Mish(GN1(conv1(x)) * (1 + scale) + shift)
-    if (gn_bwd(u, u->GT[level], C, st.F1, st.n1, st.st1, r.n1, ss, nseq, level, s)) return -1;
+    if (gn_bwd(u, u->GT[level], C, st.F1, st.n1, st.st1, r.n1, ss, nseq, level, s, nt)) return -1;
     if (!r.res.wb) {   // identity residual: d x = conv1^T(dF1) + d out
         return grad_gemm(u, u->GS[level], 2 * C, r.c1.wb, rows, Ni, C, 5, 2, 1, 0, 0, level, out_f, Ni, out_s, 2 * Ni, dy,
                          ld_dy, s);
