@@ -38,7 +38,7 @@ class Schedule(C.Structure):
     _fields_ = [("n_steps", C.c_int32), ("mean_type", C.c_int32)] + [
         (n, C.POINTER(C.c_float)) for n in (
             "post_coef1", "post_coef2", "sigma", "sqrt_ab", "sqrt_1mab", "sqrt_recip_ab",
-            "sqrt_recipm1_ab", "ab", "ab_prev")] + [("timestep_map", C.POINTER(C.c_int64))]
+            "sqrt_recipm1_ab", "ab", "ab_prev")] + [("timestep_map", C.POINTER(C.c_int64)), ("clip_x0", C.c_float)]
 
 
 class Condition(C.Structure):
@@ -84,6 +84,7 @@ SIGNATURES = {
     "cmdi_gemm_h3": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _VP]),
     "cmdi_philox4x32_10": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "cmdi_workspace_bytes": (_I64, [_VP]),
+    "cmdi_pipeline_parts": (C.c_int, [_VP]),
     "cmdi_profile_enable": (C.c_int, [_VP, _I32]),
     "cmdi_profile_read": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(_I64), C.POINTER(_I32),
                                     C.POINTER(_I32), C.POINTER(_I32)]),

@@ -41,6 +41,42 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _fallbacks: dict = {}
 
 
+class _CallerPath:
+    """``__path__`` of a synthetic parent package (``utils``, ``model``, ``diffusion``): every ``<sys.path entry>/<name>``
+    directory outside this package, recomputed on each use like a namespace package's path — so the caller's tree may be put
+    on sys.path before OR after install_reference_aliases(), and its non-aliased submodules (``utils.parser_util``,
+    ``utils.misc``, ``model.mdm_unet`` ...) stay importable."""
+
+    def __init__(self, name):
+        self._name = name
+
+    def _dirs(self):
+        out = []
+        for base in sys.path:
+            cand = os.path.abspath(os.path.join(base or ".", self._name))
+            if os.path.isdir(cand) and not (cand + os.sep).startswith(_PKG_DIR + os.sep) and cand not in out:
+                out.append(cand)
+        return out
+
+    def __iter__(self):
+        return iter(self._dirs())
+
+    def __len__(self):
+        return len(self._dirs())
+
+    def __getitem__(self, i):
+        return self._dirs()[i]
+
+    def __contains__(self, item):
+        return item in self._dirs()
+
+    def __repr__(self):
+        return f"_CallerPath({self._name!r}, {self._dirs()!r})"
+
+    def append(self, item):   # importlib appends to a namespace path it extends; nothing to keep here
+        pass
+
+
 def _callers_module(ref_name: str):
     """The caller tree's own ``<ref_name>.py`` (first hit on sys.path outside this package), loaded once under a
     private name; None when there is none (this repo used standalone)."""
@@ -80,9 +116,16 @@ def install_reference_aliases(overwrite: bool = False):
         parent_name = ref_name.split(".")[0]
         parent = sys.modules.get(parent_name)
         if parent is None:
-            parent = types.ModuleType(parent_name)
-            parent.__path__ = []  # namespace-like: lets `import utils.x` fall through for non-aliased x
-            sys.modules[parent_name] = parent
+            # the caller's own package of that name (the reference's are namespace packages: no __init__.py) if its tree
+            # is already on sys.path; else a synthetic parent whose __path__ tracks sys.path
+            try:
+                parent = importlib.import_module(parent_name)
+                if (getattr(parent, "__file__", None) or "").startswith(_PKG_DIR + os.sep):
+                    raise ImportError
+            except ImportError:
+                parent = types.ModuleType(parent_name)
+                parent.__path__ = _CallerPath(parent_name)
+                sys.modules[parent_name] = parent
         if "__getattr__" not in vars(mod):
             mod.__getattr__ = _fall_through(ref_name, mod)
         sys.modules[ref_name] = mod

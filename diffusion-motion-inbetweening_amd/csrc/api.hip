@@ -66,6 +66,7 @@ struct cmdi_engine {
     // schedule (host)
     bool have_schedule = false;
     int n_steps = 0, mean_type = 0;
+    float clip_x0 = 0.f;
     std::vector<float> c1, c2, sigma, sqrt_ab, sqrt_1mab, sra, srm1a, ab, ab_prev;
     std::vector<int64_t> tmap;
 
@@ -566,11 +567,19 @@ int check_ready(cmdi_engine* e, bool need_schedule, bool need_model = true) {
     return CMDI_OK;
 }
 
+// Gates of utils/editing_util.py:325-346 as host integers.  imputate == 2 ('marginal'): only inside the
+// reconstruction-guidance branch (gaussian_diffusion.py:424 vs :437-439).
+inline bool recon_at(const cmdi_engine* e, int step) { return e->recon && step >= e->stop_rec; }
+inline bool impute_at(const cmdi_engine* e, int step, bool recon) {
+    return e->imputate && step >= e->stop_imp && (e->imputate != 2 || recon);
+}
+
 int build_coef(cmdi_engine* e, int sampler, int step, float eta, bool impute, bool recon,
                StepCoef* k) {
     if (step < 0 || step >= e->n_steps) return fail(CMDI_E_INVALID, "step out of range");
     std::memset(k, 0, sizeof(*k));
     k->mean_eps = e->mean_type == CMDI_MEAN_EPSILON;
+    k->clip = k->mean_eps ? e->clip_x0 : 0.f;
     k->impute = impute;
     k->recon = recon;
     k->sra = e->sra[step];
@@ -953,6 +962,7 @@ int cmdi_set_schedule(cmdi_handle e, const cmdi_schedule* sc) {
     const int n = sc->n_steps;
     e->n_steps = n;
     e->mean_type = sc->mean_type;
+    e->clip_x0 = sc->clip_x0 > 0.f ? sc->clip_x0 : 0.f;
     e->c1.assign(sc->post_coef1, sc->post_coef1 + n);
     e->c2.assign(sc->post_coef2, sc->post_coef2 + n);
     e->sigma.assign(sc->sigma, sc->sigma + n);
@@ -1080,8 +1090,8 @@ int cmdi_sampler_update(cmdi_handle e, int32_t sampler, int32_t step, float eta,
     if (rc != CMDI_OK) return rc;
     if (!d_model_out || !d_x) return fail(CMDI_E_INVALID, "null tensor");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool impute = e->imputate && step >= e->stop_imp;
-    const bool recon = e->recon && step >= e->stop_rec && d_recon_grad != nullptr;
+    const bool recon = recon_at(e, step) && d_recon_grad != nullptr;
+    const bool impute = impute_at(e, step, recon);
     if (e->mean_type == CMDI_MEAN_EPSILON && (impute || recon))
         return fail(CMDI_E_INVALID, "This feature supports only X_start pred for now!");
     StepCoef k;
@@ -1192,8 +1202,8 @@ static int part_backward(cmdi_engine* e, const Part& pt) {
 static int part_step(cmdi_engine* e, const Part& pt, int32_t sampler, int32_t step, float eta, float* d_x,
                      const float* d_noise, uint64_t seed, int64_t first_sample) {
     const int64_t per = (int64_t)e->C * e->T;
-    const bool impute = e->imputate && step >= e->stop_imp;
-    const bool recon = e->recon && step >= e->stop_rec;
+    const bool recon = recon_at(e, step);
+    const bool impute = impute_at(e, step, recon);
     float* x = d_x + (size_t)pt.b0 * per;
     int rc = part_forward(e, pt, x, e->tmap[step], recon);
     if (rc != CMDI_OK) return rc;
@@ -1286,8 +1296,8 @@ static int step_impl(cmdi_engine* e, int32_t sampler, int32_t step, float eta, f
                      hipStream_t s, bool tables) {
     const int64_t per = (int64_t)e->C * e->T;
     const size_t n = (size_t)e->B * per;
-    const bool impute = e->imputate && step >= e->stop_imp;
-    const bool recon = e->recon && step >= e->stop_rec;
+    const bool recon = recon_at(e, step);
+    const bool impute = impute_at(e, step, recon);
     int rc = mdm_forward(e, d_x, nullptr, e->tmap[step], e->out_raw, recon, s, tables);
     if (rc != CMDI_OK) return rc;
     const float* out_c = e->out_raw;
@@ -1316,8 +1326,8 @@ static int step_impl(cmdi_engine* e, int32_t sampler, int32_t step, float eta, f
 
 static int check_step(cmdi_engine* e, int32_t step) {
     if (step < 0 || step >= e->n_steps) return fail(CMDI_E_INVALID, "step out of range");
-    const bool impute = e->imputate && step >= e->stop_imp;
-    const bool recon = e->recon && step >= e->stop_rec;
+    const bool recon = recon_at(e, step);
+    const bool impute = impute_at(e, step, recon);
     if (e->mean_type == CMDI_MEAN_EPSILON && (impute || recon))
         return fail(CMDI_E_INVALID, "This feature supports only X_start pred for now!");
     if (e->tmap[step] >= e->n_time_rows)
@@ -1385,8 +1395,8 @@ static int sample_loop_graph_on(cmdi_engine* e, int32_t sampler, int32_t first_s
     for (int step = last_step; step <= first_step; ++step) {
         int rc = check_step(e, step);
         if (rc != CMDI_OK) return rc;
-        const bool impute = e->imputate && step >= e->stop_imp;
-        const bool recon = e->recon && step >= e->stop_rec;
+        const bool recon = recon_at(e, step);
+        const bool impute = impute_at(e, step, recon);
         rc = build_coef(e, sampler, step, eta, impute, recon, &tab[(size_t)step]);
         if (rc != CMDI_OK) return rc;
     }
@@ -1447,6 +1457,11 @@ int cmdi_sample_loop(cmdi_handle e, int32_t sampler, int32_t first_step, int32_t
         if (rc != CMDI_OK) return rc;
     }
     return CMDI_OK;
+}
+
+int cmdi_pipeline_parts(cmdi_handle e) {
+    if (!e || !e->have_cond) return 0;
+    return (e->pipelines && !e->unet && !e->use_graph && e->L > 0) ? n_parts(e) : 1;
 }
 
 int cmdi_q_sample(cmdi_handle e, int32_t step, const float* d_x0, const float* d_noise, float* d_out,

@@ -165,8 +165,12 @@ __global__ void token0_kernel(float* __restrict__ tok, const float* __restrict__
                               int* __restrict__ range_flag) {
     const int b = blockIdx.x;  // sequence index in [0, n_seq); timesteps repeat per CFG pass
     int64_t t = cursor ? tmap_dev[*cursor] : (t_dev ? t_dev[b % n_per_pass] : t_scalar);
-    if (t < 0) t = 0;
-    if (t >= n_time_rows) t = n_time_rows - 1;
+    if (t < 0 || t >= n_time_rows) {
+        // the reference indexes pe[timesteps] and raises; here the row is clamped (no fault) and bit 1 of the status
+        // flag reports it (cmdi_range_status)
+        if (range_flag && threadIdx.x == 0) atomicOr(range_flag, 2);
+        t = t < 0 ? 0 : n_time_rows - 1;
+    }
     for (int n = threadIdx.x; n < d; n += blockDim.x) {
         float e = time_table[(size_t)t * d + n];
         if (text_term) e += text_term[(size_t)b * d + n];

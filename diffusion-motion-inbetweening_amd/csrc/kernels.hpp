@@ -118,6 +118,7 @@ struct StepCoef {
     float sra, srm1a;      // sqrt_recip_alphas_cumprod[i], sqrt_recipm1_alphas_cumprod[i]
     float sqrt_abp, dir;   // DDIM: sqrt(ab_prev), sqrt(1 - ab_prev - sigma^2)
     float gcoef;           // reconstruction guidance: (w_r * sqrt_ab) / 2
+    float clip;            // > 0: clamp the x0 derived from an eps-prediction to [-clip, clip]
     int ddim, mean_eps, impute, recon;
 };
 struct SamplerIO {

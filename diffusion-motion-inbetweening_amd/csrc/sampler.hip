@@ -123,6 +123,10 @@ __global__ __launch_bounds__(256) void sampler_step_kernel(const SamplerIO io, c
     if (k.mean_eps) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) x0[i] = (k.sra * x[i]) - (k.srm1a * hat[i]);
+        if (k.clip > 0.f) {   // process_xstart: x.clamp(-clip_range, clip_range) (:499)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x0[i] = fminf(fmaxf(x0[i], -k.clip), k.clip);
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) x0[i] = hat[i];

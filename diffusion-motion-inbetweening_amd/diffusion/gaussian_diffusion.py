@@ -170,6 +170,11 @@ class GaussianDiffusion:
         # per-step draws are taken from it in loop order instead of the engine's Philox generator
         # (the shared-noise parity mode of SURVEY.md §8c).
         self.injected_noise: Optional[torch.Tensor] = None
+        # Multi-GPU batch sharding (utils/dist_util.py): GLOBAL index of this rank's first sample.  The engine's
+        # Philox noise is keyed by (seed, first_sample + b, step, element), so with the same torch seed on every
+        # rank (utils.fixseed) a sharded run draws exactly the single-device batch's x_T and per-step noise.
+        # model_kwargs['y']['first_sample'] (set by dist_util.shard_call) overrides it per call.
+        self.first_sample = 0
         self._sampler_engines = {}
 
     # ---- schedule hand-off to the engine --------------------------------------------------------
@@ -187,7 +192,18 @@ class GaussianDiffusion:
         raise NotImplementedError("learned variances are not supported by the sampling engine "
                                   f"({self.model_var_type})")
 
-    def engine_tables(self) -> dict:
+    def _clip_x0(self, clip_denoised) -> float:
+        """process_xstart (reference :489-505): START_X never clips; an EPSILON model clamps the derived x0 to
+        +-clip_range for abs_3d trajectory models and is NotImplemented otherwise."""
+        if not clip_denoised or self.model_mean_type == ModelMeanType.START_X:
+            return 0.0
+        if getattr(self.conf, 'abs_3d', False) and getattr(self.conf, 'traj_only', False):
+            if not self.clip_range or self.clip_range <= 0:
+                raise ValueError("clip_denoised needs conf.clip_range > 0")
+            return float(self.clip_range)
+        raise NotImplementedError()
+
+    def engine_tables(self, clip_x0: float = 0.0) -> dict:
         """fp32 per-step tables for cmdi_set_schedule: float64 numpy -> .float(), like
         _extract_into_tensor (reference :2225); sigma = exp(0.5 * log_variance) in fp32 (:710)."""
         if self.model_mean_type == ModelMeanType.START_X:
@@ -211,10 +227,23 @@ class GaussianDiffusion:
             "ab": f32(self.alphas_cumprod),
             "ab_prev": f32(self.alphas_cumprod_prev),
             "timestep_map": np.asarray(self._timestep_map(), dtype=np.int64),
+            "clip_x0": float(clip_x0),
         }
 
+    @staticmethod
+    def _tables_key(tables: dict):
+        """Content key of a schedule hand-off: the engine lives on the (long-lived) model while diffusion objects
+        come and go, so identity (id()) is not a safe cache key."""
+        import hashlib
+        h = hashlib.blake2b(digest_size=16)
+        for name in sorted(tables):
+            v = tables[name]
+            h.update(name.encode())
+            h.update(np.ascontiguousarray(v).tobytes() if isinstance(v, np.ndarray) else repr(v).encode())
+        return h.hexdigest()
+
     # ---- small tensor helpers kept for API compatibility ----------------------------------------
-    def _engine_for(self, model, device, batch, n_feats, n_frames, want_grad):
+    def _engine_for(self, model, device, batch, n_feats, n_frames, want_grad, clip_denoised=False):
         mdm, _ = _unwrap_model(model)
         if mdm is not None:
             eng = mdm.engine(device, max_batch=batch, max_frames=n_frames, want_grad=want_grad,
@@ -227,7 +256,8 @@ class GaussianDiffusion:
                 eng = Engine(n_layers=0, d_model=0, d_ff=0, n_heads=0, n_feats=n_feats,
                              max_frames=max(n_frames, 1), max_batch=max(batch, 1), device=device)
                 self._sampler_engines[key] = eng
-        eng.set_schedule(self.engine_tables(), key=(id(self), self.num_timesteps))
+        tables = self.engine_tables(self._clip_x0(clip_denoised))
+        eng.set_schedule(tables, key=self._tables_key(tables))
         return eng
 
     def q_sample(self, x_start, t, noise=None):
@@ -270,11 +300,13 @@ class GaussianDiffusion:
         mdm, cfg = _unwrap_model(model)
 
         use_recon = bool(y.get('reconstruction_guidance', False))
-        eng = self._engine_for(model, device, B, J * F, T, want_grad=use_recon and mdm is not None)
+        eng = self._engine_for(model, device, B, J * F, T, want_grad=use_recon and mdm is not None,
+                               clip_denoised=clip_denoised)
         cond = self._condition_from_kwargs(y, mdm, cfg, B, J * F, T, device)
         _add_observations(cond, mdm, model_kwargs, B, J * F, T)
         eng.set_condition(**cond)
 
+        first = int(y.get('first_sample', self.first_sample))
         seed = _fresh_seed()
         draws = _NoiseSource(self.injected_noise, shape, device)
         if noise is not None:
@@ -282,7 +314,7 @@ class GaussianDiffusion:
         elif draws.active:
             img = draws.next().clone()
         else:
-            img = eng.randn(shape, seed=seed, step=-1)
+            img = eng.randn(shape, seed=seed, step=-1, first_sample=first)
 
         if skip_timesteps and init_image is None:
             init_image = torch.zeros_like(img)
@@ -296,7 +328,7 @@ class GaussianDiffusion:
             # whole loop in one native call, nothing materialised per step
             stream = draws.take(len(indices)) if draws.active else None
             eng.sample_loop(img, indices[0], indices[-1], sampler=sampler_id, eta=eta,
-                            noise_stream=stream, seed=seed)
+                            noise_stream=stream, seed=seed, first_sample=first)
             eng.check_range()
             yield {"sample": img, "pred_xstart": None}
             return
@@ -308,14 +340,15 @@ class GaussianDiffusion:
             nz = draws.next() if draws.active else None
             pred = torch.empty_like(img)
             if mdm is not None:
-                eng.step(img, i, sampler=sampler_id, eta=eta, noise=nz, pred_xstart=pred, seed=seed)
+                eng.step(img, i, sampler=sampler_id, eta=eta, noise=nz, pred_xstart=pred, seed=seed,
+                         first_sample=first)
             else:
-                self._generic_step(eng, model, img, i, sampler_id, eta, nz, pred, seed, model_kwargs)
+                self._generic_step(eng, model, img, i, sampler_id, eta, nz, pred, seed, model_kwargs, first)
             yield {"sample": img.clone(), "pred_xstart": pred}
         if mdm is not None:
             eng.check_range()
 
-    def _generic_step(self, eng, model, img, i, sampler_id, eta, nz, pred, seed, model_kwargs):
+    def _generic_step(self, eng, model, img, i, sampler_id, eta, nz, pred, seed, model_kwargs, first=0):
         """Any callable denoiser: the model runs in torch, the sampler arithmetic in the engine."""
         y = model_kwargs['y']
         B = img.shape[0]
@@ -339,7 +372,7 @@ class GaussianDiffusion:
         if isinstance(out, tuple):
             out = out[0]
         eng.sampler_update(img, out.float().contiguous(), i, sampler=sampler_id, eta=eta,
-                           recon_grad=grad, noise=nz, pred_xstart=pred, seed=seed)
+                           recon_grad=grad, noise=nz, pred_xstart=pred, seed=seed, first_sample=first)
 
     def _condition_from_kwargs(self, y, mdm, cfg, B, n_feats, T, device):
         """model_kwargs['y'] -> cmdi_condition (gates of utils/editing_util.py)."""
@@ -351,9 +384,14 @@ class GaussianDiffusion:
             cond['text_scale'] = torch.as_tensor(y['text_scale'], dtype=torch.float32).reshape(-1)
         imputate = editing_util.uses_imputation(y)
         recon = editing_util.uses_reconstruction_guidance(y)
+        impute_mode = 1 if imputate else 0
         if imputate and y.get('replacement_distribution', 'conditional') == 'marginal':
-            imputate = False  # the reference's 'marginal' branch is a no-op (:437-439)
-        elif imputate and y.get('replacement_distribution', 'conditional') != 'conditional':
+            # the reference's 'marginal' branch is a no-op (:437-439) — but it is only reached when reconstruction
+            # guidance is NOT active at that step: inside the guidance branch (:424) imputation happens whatever the
+            # replacement distribution.  Mode 2 = impute only at steps where reconstruction guidance runs.
+            impute_mode = 2 if recon else 0
+            imputate = impute_mode != 0
+        elif imputate and y.get('replacement_distribution', 'conditional') != 'conditional' and not recon:
             raise NotImplementedError
         if imputate or recon:
             if self.model_mean_type != ModelMeanType.START_X:
@@ -364,7 +402,7 @@ class GaussianDiffusion:
             cond['inpaint_mask'] = (mask.bool() & seq_mask.bool()).expand(B, n_feats, 1, T) \
                 .reshape(B, n_feats, 1, T)
             cond['inpaint_motion'] = y['inpainted_motion'].to(device).float().reshape(B, n_feats, 1, T)
-        cond['imputate'] = imputate
+        cond['imputate'] = impute_mode
         cond['stop_imputation_at'] = int(y.get('stop_imputation_at', 0)) if imputate else 0
         cond['recon_guidance'] = recon
         cond['stop_recguidance_at'] = int(y.get('stop_recguidance_at', 0)) if recon else 0
@@ -439,14 +477,14 @@ class GaussianDiffusion:
     def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None,
                  model_kwargs=None, const_noise=False, previous_xstart=None):
         """One ancestral step (reference :656-713) on a fresh copy of x."""
-        return self._single_step("ddpm", model, x, t, cond_fn, model_kwargs, const_noise, 0.0)
+        return self._single_step("ddpm", model, x, t, cond_fn, model_kwargs, const_noise, 0.0, clip_denoised)
 
     def ddim_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None,
                     model_kwargs=None, eta=0.0, previous_xstart=None):
         """One DDIM step (reference :1300-1356)."""
-        return self._single_step("ddim", model, x, t, cond_fn, model_kwargs, False, eta)
+        return self._single_step("ddim", model, x, t, cond_fn, model_kwargs, False, eta, clip_denoised)
 
-    def _single_step(self, sampler, model, x, t, cond_fn, model_kwargs, const_noise, eta):
+    def _single_step(self, sampler, model, x, t, cond_fn, model_kwargs, const_noise, eta, clip_denoised=False):
         assert cond_fn is None, "only support the case where cond_fn is None"
         if const_noise:
             raise NotImplementedError()
@@ -456,19 +494,21 @@ class GaussianDiffusion:
         y = model_kwargs['y']
         mdm, cfg = _unwrap_model(model)
         use_recon = bool(y.get('reconstruction_guidance', False))
-        eng = self._engine_for(model, x.device, B, J * F, T, want_grad=use_recon and mdm is not None)
+        eng = self._engine_for(model, x.device, B, J * F, T, want_grad=use_recon and mdm is not None,
+                               clip_denoised=clip_denoised)
         cond = self._condition_from_kwargs(y, mdm, cfg, B, J * F, T, x.device)
         _add_observations(cond, mdm, model_kwargs, B, J * F, T)
         eng.set_condition(**cond)
+        first = int(y.get('first_sample', self.first_sample))
         out = x.detach().float().contiguous().clone()
         pred = torch.empty_like(out)
         sid = N.CMDI_SAMPLER_DDIM if sampler == "ddim" else N.CMDI_SAMPLER_DDPM
         draws = _NoiseSource(self.injected_noise, x.shape, x.device)
         nz = draws.next() if draws.active else None
         if mdm is not None:
-            eng.step(out, i, sampler=sid, eta=eta, noise=nz, pred_xstart=pred, seed=_fresh_seed())
+            eng.step(out, i, sampler=sid, eta=eta, noise=nz, pred_xstart=pred, seed=_fresh_seed(), first_sample=first)
         else:
-            self._generic_step(eng, model, out, i, sid, eta, nz, pred, _fresh_seed(), model_kwargs)
+            self._generic_step(eng, model, out, i, sid, eta, nz, pred, _fresh_seed(), model_kwargs, first)
         return {"sample": out, "pred_xstart": pred}
 
 

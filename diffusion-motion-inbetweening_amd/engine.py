@@ -86,15 +86,21 @@ class Engine:
     def workspace_bytes(self) -> int:
         return int(self.lib.cmdi_workspace_bytes(self._h))
 
+    def pipeline_parts(self) -> int:
+        """How many independent batch pipelines sample_loop runs for the current condition."""
+        return int(self.lib.cmdi_pipeline_parts(self._h))
+
     def check_range(self):
-        """f16x3 only: raise if an activation left the f16 range since the last check (one 4-byte
-        read-back, synchronises the stream — call once per sampling chain)."""
-        if self.precision != "f16x3":
-            return
+        """Raise if the device status flag was set since the last check: an activation left the f16 range
+        (f16x3), or a timestep fell outside the time-embedding table (one 4-byte read-back, synchronises the
+        stream — call once per sampling chain)."""
         flag = C.c_int32(0)
         with torch.cuda.device(self.device):
             N.check(self.lib.cmdi_range_status(self._h, C.byref(flag), self.stream))
-        if flag.value:
+        if flag.value & 2:
+            raise IndexError("a timestep outside the time-embedding table reached the denoiser "
+                             "(the reference raises at pe[timesteps], model/mdm.py:352)")
+        if flag.value & 1 and self.precision == "f16x3":
             raise N.NativeError(
                 "an activation left the f16 range (|x| >= 65504 or non-finite) in the split-f16 GEMM "
                 "path: results are invalid; re-run with precision='f32' (CMDI_PRECISION=f32)")
@@ -142,7 +148,8 @@ class Engine:
         assert tmap.shape == (n,)
         sc = N.Schedule(n, int(tables["mean_type"]), *[_as_f32_ptr(arrs[k]) for k in (
             "post_coef1", "post_coef2", "sigma", "sqrt_ab", "sqrt_1mab", "sqrt_recip_ab",
-            "sqrt_recipm1_ab", "ab", "ab_prev")], tmap.ctypes.data_as(C.POINTER(C.c_int64)))
+            "sqrt_recipm1_ab", "ab", "ab_prev")], tmap.ctypes.data_as(C.POINTER(C.c_int64)),
+                        float(tables.get("clip_x0", 0.0)))
         N.check(self.lib.cmdi_set_schedule(self._h, C.byref(sc)))
         self.n_steps = n
         self._schedule_key = key

@@ -199,14 +199,16 @@ class MDM(nn.Module):
         return emb.contiguous()
 
     # ---- native engine ------------------------------------------------------------------------
-    def engine(self, device, max_batch, max_frames, want_grad=False, n_time_rows=1000):
-        """The native engine holding this module's weights on `device` (built / grown lazily)."""
+    def engine(self, device, max_batch, max_frames, want_grad=False, n_time_rows=None):
+        """The native engine holding this module's weights on `device` (built / grown lazily).  The time-embedding
+        table is always finalised for every row of `pe` (5000 x d floats, one small GEMM at load time), so forward calls
+        and sampling loops with any respacing share ONE engine (`n_time_rows` is accepted for compatibility)."""
         from ..engine import Engine
         device = torch.device(device)
         if device.type == 'cuda' and device.index is None:
             device = torch.device('cuda', torch.cuda.current_device())
         pe_rows = self.sequence_pos_encoder.pe.shape[0]
-        n_time_rows = min(int(n_time_rows), pe_rows)
+        n_time_rows = pe_rows
         eng = self._engine
         precision = getattr(self, "native_precision", None)  # None = library default (f16x3)
         need_new = (eng is None or eng.device != device or eng.max_batch < max_batch
@@ -249,8 +251,11 @@ class MDM(nn.Module):
         B, J, F, T = x.shape
         assert J * F == self.input_feats
         need_grad = torch.is_grad_enabled() and x.requires_grad
-        eng = self.engine(device, max_batch=B, max_frames=T, want_grad=need_grad,
-                          n_time_rows=self.sequence_pos_encoder.pe.shape[0])
+        if timesteps.device.type == 'cpu':   # host tensor: check like the reference's pe[timesteps] would (no sync)
+            lo, hi = int(timesteps.min()), int(timesteps.max())
+            if lo < 0 or hi >= self.sequence_pos_encoder.pe.shape[0]:
+                raise IndexError(f"timesteps out of range for the positional table: [{lo}, {hi}]")
+        eng = self.engine(device, max_batch=B, max_frames=T, want_grad=need_grad)
         cond = dict(batch=B, n_frames=T, cfg=cfg)
         if 'text' in self.cond_mode and not y.get('uncond', False):
             cond['enc_text'] = self.text_embedding(y, B, device)

@@ -153,7 +153,7 @@ class MDM_UNET(nn.Module):
         if device.type == 'cuda' and device.index is None:
             device = torch.device('cuda', torch.cuda.current_device())
         pe_rows = self.sequence_pos_encoder.pe.shape[0]
-        n_time_rows = min(int(n_time_rows), pe_rows)
+        n_time_rows = pe_rows   # one table for forward calls and every respacing (see MDM.engine)
         eng = self._engine
         need_new = (eng is None or eng.device != device or eng.max_batch < max_batch or eng.max_frames < max_frames
                     or (want_grad and not eng.want_grad) or self._engine_key != self._weights_key(n_time_rows))

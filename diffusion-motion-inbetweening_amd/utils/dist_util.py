@@ -60,6 +60,23 @@ def shard_batch(obj, rank: int, world_size: int, n: int):
     return obj
 
 
+def shard_call(shape, model_kwargs, noise=None, init_image=None):
+    """This rank's share of ``diffusion.p_sample_loop(model, shape, model_kwargs=..., noise=..., init_image=...)``:
+    returns (local_shape, local_model_kwargs, local_noise, local_init_image).  Every batch-leading tensor / list in
+    model_kwargs (``y`` entries, ``obs_x0`` / ``obs_mask``) is sliced to the rank's contiguous range and
+    ``y['first_sample']`` is set to the GLOBAL index of its first sample, which the sampler forwards to the engine's
+    counter-based generator: with the same torch seed on every rank (utils.fixseed) the gathered result equals the
+    single-device batch bit for bit.  Reassemble with all_gather_batch(local_sample, shape[0])."""
+    rank, world_size = world()
+    n = int(shape[0])
+    lo, hi = shard_bounds(n, rank, world_size)
+    local = shard_batch(model_kwargs, rank, world_size, n)
+    local = dict(local)
+    local['y'] = dict(local.get('y', {}), first_sample=lo)
+    cut = lambda t: None if t is None else t[lo:hi]
+    return (hi - lo,) + tuple(shape[1:]), local, cut(noise), cut(init_image)
+
+
 def all_gather_batch(local: torch.Tensor, n: int) -> torch.Tensor:
     """Reassemble the full batch on every rank: ONE all-gather (RCCL over xGMI on GPUs).  Ranks may
     own slices that differ by one sample, so slices are padded to the largest and trimmed after."""

@@ -111,6 +111,9 @@ typedef struct {
     const float* ab;                 /* alphas_cumprod                                       */
     const float* ab_prev;            /* alphas_cumprod_prev                                  */
     const int64_t* timestep_map;     /* respaced i → original t                              */
+    float clip_x0;                   /* > 0 (CMDI_MEAN_EPSILON only): clamp the derived x0 to [-clip_x0, clip_x0] —
+                                        process_xstart with clip_denoised for abs_3d trajectory models
+                                        (diffusion/gaussian_diffusion.py:489-505); 0 = no clamp          */
 } cmdi_schedule;
 int cmdi_set_schedule(cmdi_handle h, const cmdi_schedule* s);
 
@@ -129,7 +132,10 @@ typedef struct {
     const float* d_text_scale;       /* [B] or NULL (required when cfg=1)                      */
     const uint8_t* d_inpaint_mask;   /* [B,J,1,T] already AND-ed with y['mask'], or NULL       */
     const float* d_inpaint_motion;   /* [B,J,1,T] or NULL                                      */
-    int32_t imputate;                /* y['imputate']                                          */
+    int32_t imputate;                /* y['imputate']: 0 off; 1 = replacement_distribution 'conditional' (impute at every
+                                        step >= stop_imputation_at); 2 = 'marginal': a no-op in the reference's plain
+                                        branch (:437-439), so impute only at steps where reconstruction guidance runs
+                                        (its branch imputes whatever the distribution, :424)              */
     int32_t stop_imputation_at;      /* y['stop_imputation_at'] (respaced index)               */
     int32_t recon_guidance;          /* y['reconstruction_guidance']                           */
     int32_t stop_recguidance_at;     /* y['stop_recguidance_at']                               */
@@ -218,10 +224,12 @@ int cmdi_gemm_nt(const float* d_a, const float* d_w, const float* d_bias, const 
                  cmdi_stream stream);
 /* The precision the handle runs at (CMDI_PREC_F32 or CMDI_PREC_F16X3). */
 int cmdi_precision(cmdi_handle h);
-/* F16X3 only: *out_flag = 1 if, since the last call, an activation left the f16 range (|x| >= 65504
- * or non-finite) while being split; the results of that run are then invalid and the caller should
- * re-run on an engine created with CMDI_PREC_F32.  SYNCHRONISES `stream` (one 4-byte read-back);
- * call it once per sampling chain, not per step.  Clears the flag. */
+/* Status bits raised on the device since the last call (cleared by it):
+ *   bit 0 (F16X3 only): an activation left the f16 range (|x| >= 65504 or non-finite) while being split; the results
+ *         of that run are invalid and the caller should re-run on an engine created with CMDI_PREC_F32;
+ *   bit 1: a timestep outside [0, n_time_rows) reached the time-embedding lookup (the reference raises IndexError
+ *         at pe[timesteps], model/mdm.py:352); the row was clamped.
+ * SYNCHRONISES `stream` (one 4-byte read-back); call it once per sampling chain, not per step. */
 int cmdi_range_status(cmdi_handle h, int32_t* out_flag, cmdi_stream stream);
 /* Split-f16 GEMM family alone (test / bench hooks).  cmdi_split_f16: fp32 [rows, cols] -> split rows
  * [rows, 2*cols] f16; per 32-column chunk: 32 hi values f16(x), then 32 lo values
@@ -263,6 +271,9 @@ void cmdi_philox4x32_10(const uint32_t counter[4], const uint32_t key[2], uint32
 int cmdi_profile_enable(cmdi_handle h, int32_t on);
 int cmdi_profile_read(cmdi_handle h, double* total_ms, int64_t* launches, int32_t* m, int32_t* n,
                       int32_t* k);
+/* Number of independent batch pipelines cmdi_sample_loop cuts the CURRENT condition's batch into (1 = none; 2 from
+ * 8192 token rows up, CMDI_GROUPS overrides): each part runs its whole chain on its own stream. */
+int cmdi_pipeline_parts(cmdi_handle h);
 /* Bytes of device memory held by the handle. */
 int64_t cmdi_workspace_bytes(cmdi_handle h);
 

@@ -112,14 +112,17 @@ def gradient_schedule(name, n, scale=.05) -> np.ndarray:
 
 # ---- one denoising step given the (CFG-combined) model output ----------------------------------
 def step_update(sch: Schedule, i: int, x, hat, noise, *, sampler="ddpm", eta=0.0, mean_eps=False,
-                mask=None, inpaint=None, impute=False, recon=False, grad=None, recon_w=None):
+                mask=None, inpaint=None, impute=False, recon=False, grad=None, recon_w=None, clip=0.0):
     """Returns (x_{i-1}, pred_xstart).  `hat` is the model output; `mask` is already AND-ed with
     y['mask']; `grad` is autograd.grad(loss, z)[0] (unmasked); recon_w = grad_ws[i]*weight (fp32)."""
     x = np.asarray(x, dtype=F32)
     hat = np.asarray(hat, dtype=F32)
     noise = np.asarray(noise, dtype=F32)
     if mean_eps:
+        # _predict_xstart_from_eps (:536-541), then process_xstart's clamp (:497-499) when clip_denoised applies
         x0 = (sch.f32(sch.sqrt_recip_ab, i) * x) - (sch.f32(sch.sqrt_recipm1_ab, i) * hat)
+        if clip > 0:
+            x0 = np.clip(x0, F32(-clip), F32(clip))
     else:
         x0 = hat
     if recon:
@@ -157,7 +160,7 @@ def sample_loop(sch: Schedule, model, x_T, noise_stream, *, sampler="ddpm", eta=
                 enc_text=None, text_scale=None, cfg=False, mask=None, inpaint=None,
                 imputate=False, stop_imputation_at=0, recon_guidance=False, stop_recguidance_at=0,
                 recon_weight=0.0, grad_schedule=None, diffusion_steps=1000, first_step=None,
-                last_step=0, collect=False):
+                last_step=0, collect=False, mean_eps=False, clip=0.0, collect_samples=False, marginal=False):
     """p_sample_loop / ddim_sample_loop with injected noise.  `model` is an MDMOracle;
     noise_stream[k] is the k-th th.randn_like draw (loop order)."""
     x = np.asarray(x_T, dtype=F32)
@@ -171,8 +174,10 @@ def sample_loop(sch: Schedule, model, x_T, noise_stream, *, sampler="ddpm", eta=
             hat, _, _ = model.forward_cfg(x, t, enc_text, text_scale)
         else:
             hat = model.forward(x, t, enc_text)
-        do_imp = imputate and i >= stop_imputation_at
         do_rec = recon_guidance and i >= stop_recguidance_at
+        # replacement_distribution 'marginal': the plain imputation branch is a no-op (:437-439), the guidance branch
+        # imputes whatever the distribution (:424)
+        do_imp = imputate and i >= stop_imputation_at and (do_rec or not marginal)
         grad, w = None, None
         if do_rec:
             seed = recon_loss_grad_seed(hat, mask, inpaint)
@@ -180,9 +185,10 @@ def sample_loop(sch: Schedule, model, x_T, noise_stream, *, sampler="ddpm", eta=
                 model.vjp(x, t, seed, enc_text)
             w = F32(grad_ws[i]) * F32(recon_weight)
         x, x0 = step_update(sch, i, x, hat, noise_stream[k], sampler=sampler, eta=eta, mask=mask,
-                            inpaint=inpaint, impute=do_imp, recon=do_rec, grad=grad, recon_w=w)
+                            inpaint=inpaint, impute=do_imp, recon=do_rec, grad=grad, recon_w=w,
+                            mean_eps=mean_eps, clip=clip)
         if collect:
-            preds.append(x0)
+            preds.append(x if collect_samples else x0)
     return (x, preds) if collect else x
 
 

@@ -35,6 +35,14 @@ CASES = {
                               edit=True, trans_length=5, imputate=True, stop_imputation_at=3,
                               recon=False, recon_weight=0.0, grad_schedule=None,
                               stop_recguidance_at=0, lengths=[52, 60]),
+    # replacement_distribution='marginal' (selectable in sample/edit.py): a no-op in the plain imputation branch
+    # (gaussian_diffusion.py:437-439) but the reconstruction-guidance branch imputes regardless (:424) — so with
+    # guidance stopping at step 5 the keyframes are imputed at steps 9..5 only
+    "chain_marginal_recon": dict(kind="chain", text=True, cfg=True, weight_seed=15, B=2, T=60,
+                                 respacing=[10], sampler="ddpm", seed=110, text_scale=[2.5, 2.5],
+                                 edit=True, trans_length=5, imputate=True, stop_imputation_at=1,
+                                 recon=True, recon_weight=20.0, grad_schedule=None, replacement="marginal",
+                                 stop_recguidance_at=5, lengths=[60, 45]),
     "chain_ddim_eta0": dict(kind="chain", text=True, cfg=True, weight_seed=17, B=2, T=60,
                             respacing="ddim10", sampler="ddim", eta=0.0, seed=107,
                             text_scale=[2.5, 2.5]),
@@ -163,3 +171,75 @@ def make_unet_vjp_inputs(case: dict = UNET_VJP_CASE) -> dict:
     rng = np.random.default_rng(case["seed"] + 1000)
     inp["gout"] = np.ascontiguousarray(rng.standard_normal(inp["x"].shape), dtype=np.float32)
     return inp
+
+
+# ---- BASELINE-shape chains (VERDICT r1 task 1): B=32 x 196 frames so that the engine's two-pipeline schedule
+# (n_parts() == 2, part_backward) is compared with REFERENCE values; 1000-step and DDIM-100 chains for drift; an
+# EPSILON-mean-type chain; a B=256 forward (C4's M = 100,864 rows).  Noise is NOT one array here (1000 steps x 412 KB
+# per sample): draw k of a chain is default_rng([seed, k]) — k = 0 is x_T, k = 1 + i the i-th step's randn_like.
+BIG_KEEP = (0, 7, 15, 16, 24, 31)      # samples whose full tensors are stored for the B=32 cases (both pipeline halves)
+BIG_CASES = {
+    "big_c2": dict(kind="chain", text=True, cfg=True, weight_seed=41, B=32, T=196, respacing=[20], sampler="ddpm",
+                   seed=501, ragged=True, keep=BIG_KEEP),
+    "big_c3": dict(kind="chain", text=True, cfg=True, weight_seed=42, B=32, T=196, respacing=[20], sampler="ddpm",
+                   seed=502, ragged=True, keep=BIG_KEEP, edit=True, trans_length=5, imputate=True, stop_imputation_at=1,
+                   recon=True, recon_weight=20.0, grad_schedule=None, stop_recguidance_at=0),
+    "long_ddpm": dict(kind="chain", text=True, cfg=True, weight_seed=43, B=2, T=196, respacing=None, sampler="ddpm",
+                      seed=503, every=100, f64=True),
+    "long_ddim100": dict(kind="chain", text=True, cfg=True, weight_seed=43, B=2, T=196, respacing="ddim100",
+                         sampler="ddim", eta=0.0, seed=504, every=10, f64=True),
+    "eps_ddpm": dict(kind="chain", text=False, cfg=False, weight_seed=44, B=2, T=60, respacing=[10], sampler="ddpm",
+                     seed=505, mean_type="eps", every=3, skip=3, init_image=True),
+    "eps_ddim": dict(kind="chain", text=False, cfg=False, weight_seed=44, B=2, T=60, respacing="ddim10", sampler="ddim",
+                     eta=0.3, seed=506, mean_type="eps", every=3, skip=3, init_image=True),
+    # (EPSILON chains start at respaced index 6 = t 666 from a noised init_image: from t = 999 an UNTRAINED eps-model gives
+    # x0 = 2e4 (x - eps), which says nothing about parity)
+    "fwd_b256": dict(kind="fwd", text=True, weight_seed=45, B=256, T=196, seed=507, keep=(0, 100, 127, 128, 200, 255)),
+}
+
+
+def big_n_steps(case) -> int:
+    r = case.get("respacing")
+    if r is None:
+        return 1000
+    if isinstance(r, str):
+        return int(r[len("ddim"):])
+    return int(r[0])
+
+
+def big_draw(case, k: int) -> np.ndarray:
+    """Draw k of the chain's noise stream (0 = x_T, 1 + i = step i in loop order), fp32 [B, 263, 1, T]."""
+    shape = (case["B"], N_FEATS, 1, case["T"])
+    return np.random.default_rng([case["seed"], k]).standard_normal(shape).astype(np.float32)
+
+
+def make_big_inputs(case: dict) -> dict:
+    rng = np.random.default_rng(case["seed"])
+    B, T = case["B"], case["T"]
+    shape = (B, N_FEATS, 1, T)
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    out = {}
+    if case["kind"] == "fwd":
+        out["x"] = f32(rng.standard_normal(shape))
+        out["t"] = rng.integers(0, 1000, B).astype(np.int64)
+    else:
+        lengths = rng.integers(40, T + 1, B).astype(np.int64) if case.get("ragged") else np.full(B, T, np.int64)
+        out["lengths"] = lengths
+        out["len_mask"] = (np.arange(T)[None, :] < lengths[:, None]).reshape(B, 1, 1, T)
+        if case.get("edit"):
+            out["x0"] = f32(rng.standard_normal(shape))
+            out["inpaint_mask"] = sparse_keyframe_mask(lengths, T, case["trans_length"])
+        if case.get("init_image"):
+            out["init_image"] = f32(rng.standard_normal(shape))
+        out["draw0"] = big_draw(case, 0)
+        out["draw_last"] = big_draw(case, big_n_steps(case) - case.get("skip", 0))
+    if case["text"]:
+        out["enc_text"] = f32(rng.standard_normal((B, 512)))
+        out["text_scale"] = f32(np.full(B, 2.5))
+    return out
+
+
+def sample_stats(a: np.ndarray) -> np.ndarray:
+    """Per-sample (sum, sum of squares) in float64 — a cheap check over samples whose tensors are not stored."""
+    a = np.asarray(a, dtype=np.float64).reshape(a.shape[0], -1)
+    return np.stack([a.sum(1), (a * a).sum(1)], axis=1)

@@ -106,7 +106,7 @@ def vjp_case(ref):
 
 def chain_cases(ref):
     for name in ("chain_uncond_ddpm", "chain_edit_recon", "chain_impute_only", "chain_ddim_eta0",
-                 "chain_ddim_eta05", "chain_skip_init"):
+                 "chain_ddim_eta05", "chain_skip_init", "chain_marginal_recon"):
         case = cases.CASES[name]
         inp = cases.make_inputs(case)
         model, diffusion = build(ref, case)
@@ -123,7 +123,7 @@ def chain_cases(ref):
             assert np.array_equal(ref_mask.numpy(), inp["inpaint_mask"]), "keyframe mask restatement drifted"
             y.update(inpainting_mask=t(inp["inpaint_mask"]), inpainted_motion=t(inp["x0"]),
                      imputate=case["imputate"], stop_imputation_at=case["stop_imputation_at"],
-                     replacement_distribution='conditional',
+                     replacement_distribution=case.get("replacement", "conditional"),
                      reconstruction_guidance=case["recon"],
                      reconstruction_weight=case["recon_weight"],
                      gradient_schedule=case["grad_schedule"], diffusion_steps=1000,

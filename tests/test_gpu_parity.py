@@ -325,7 +325,7 @@ def run_chain(cases, name, precision):
     if case.get("edit"):
         y.update(inpainting_mask=tt(inp["inpaint_mask"]), inpainted_motion=tt(inp["x0"]),
                  imputate=case["imputate"], stop_imputation_at=case["stop_imputation_at"],
-                 replacement_distribution='conditional', reconstruction_guidance=case["recon"],
+                 replacement_distribution=case.get("replacement", "conditional"), reconstruction_guidance=case["recon"],
                  reconstruction_weight=case["recon_weight"], gradient_schedule=case["grad_schedule"],
                  diffusion_steps=1000, stop_recguidance_at=case["stop_recguidance_at"])
     loop = diffusion.ddim_sample_loop if case["sampler"] == "ddim" else diffusion.p_sample_loop
@@ -341,7 +341,7 @@ def run_chain(cases, name, precision):
 
 
 @pytest.mark.parametrize("name", ["chain_uncond_ddpm", "chain_impute_only", "chain_edit_recon",
-                                  "chain_ddim_eta0", "chain_ddim_eta05", "chain_skip_init"])
+                                  "chain_ddim_eta0", "chain_ddim_eta05", "chain_skip_init", "chain_marginal_recon"])
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_chain_vs_reference(cases, name, precision):
     final, dumps, g = run_chain(cases, name, precision)
@@ -349,6 +349,238 @@ def test_chain_vs_reference(cases, name, precision):
     assert len(dumps) == g["pred_xstart"].shape[0]
     for k, d in enumerate(dumps):
         assert rel_l2(d, g["pred_xstart"][k]) <= 1e-4, (k, rel_l2(d, g["pred_xstart"][k]))
+
+
+# ---- BASELINE shapes and chain lengths vs the reference (tests/golden/make_golden_big.py) ------------------
+def big_setup(cases, name, precision):
+    case = cases.BIG_CASES[name]
+    inp = cases.make_big_inputs(case)
+    g = load_golden(name)
+    assert np.array_equal(g["fingerprint"], cases.fingerprint(inp)), f"inputs of {name} drifted"
+    model, _ = make_model(case, precision=precision)
+    gd, rs = sub("diffusion.gaussian_diffusion"), sub("diffusion.respace")
+    conf = gd.DiffusionConfig(betas=gd.get_named_beta_schedule("cosine", 1000))
+    if case.get("mean_type") == "eps":
+        conf.model_mean_type = gd.ModelMeanType.EPSILON
+    diffusion = rs.SpacedDiffusion(rs.space_timesteps(1000, case.get("respacing") or [1000]), conf)
+    B = case["B"]
+    y = {"mask": tt(inp["len_mask"]), "lengths": tt(inp["lengths"])}
+    if case["text"]:
+        y.update(text_embed=tt(inp["enc_text"]), text_scale=tt(inp["text_scale"]))
+    if case.get("edit"):
+        y.update(inpainting_mask=tt(inp["inpaint_mask"]), inpainted_motion=tt(inp["x0"]), imputate=case["imputate"],
+                 stop_imputation_at=case["stop_imputation_at"], replacement_distribution='conditional',
+                 reconstruction_guidance=case["recon"], reconstruction_weight=case["recon_weight"],
+                 gradient_schedule=case["grad_schedule"], diffusion_steps=1000,
+                 stop_recguidance_at=case["stop_recguidance_at"])
+    n = diffusion.num_timesteps - case.get("skip", 0)
+    noise = torch.from_numpy(np.stack([cases.big_draw(case, 1 + k) for k in range(n)]))
+    diffusion.injected_noise = noise.to(DEV)
+    kw = dict(noise=tt(inp["draw0"]), clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=case.get("skip", 0),
+              init_image=tt(inp["init_image"]) if "init_image" in inp else None)
+    if case["sampler"] == "ddim":
+        kw["eta"] = case["eta"]
+    return case, inp, g, model, diffusion, kw
+
+
+def stats_close(got, want, tol):
+    """Per-sample (sum, sum^2) of every sample vs the reference's float64 values: |d sum| <= tol * sqrt(N * sum^2)
+    (the scale of a sum of N terms), |d sum^2| <= tol * sum^2."""
+    n = 263 * 196
+    return bool(np.all(np.abs(got[:, 0] - want[:, 0]) <= tol * np.sqrt(n * want[:, 1])) and
+                np.all(np.abs(got[:, 1] - want[:, 1]) <= tol * want[:, 1]))
+
+
+@pytest.mark.parametrize("name", ["big_c2", "big_c3"])
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_baseline_shape_chain_vs_reference(cases, name, precision):
+    """BASELINE configs 2 and 3 at their own shape (B=32, T=196, CFG; c3 = imputation + reconstruction guidance),
+    20 steps of the 1000-step chain, ragged lengths: p_sample_loop takes the engine's one-call path, which at this
+    size cuts the batch into TWO independent pipelines (api.hip n_parts / part_forward / part_backward) — compared
+    here with values of the real reference: six stored samples (three per pipeline) and (sum, sum^2) of all 32."""
+    case, inp, g, model, diffusion, kw = big_setup(cases, name, precision)
+    loop = diffusion.p_sample_loop
+    final = loop(model, inp["draw0"].shape, **kw)
+    eng = model.model._engine
+    assert eng.pipeline_parts() == 2, "the two-pipeline schedule was not taken at the BASELINE shape"
+    final = final.cpu().numpy()
+    keep = list(case["keep"])
+    err = rel_l2(final[keep], g["final"])
+    per = [rel_l2(final[k], g["final"][i]) for i, k in enumerate(keep)]
+    assert err <= 1e-4 and max(per) <= 2e-4, (err, per)
+    assert stats_close(cases.sample_stats(final), g["stats"], 2e-4)
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_forced_two_pipelines_on_small_golden(cases, precision, monkeypatch):
+    """CMDI_GROUPS=2 forces the part_forward / part_backward schedule on a small reference chain (B=2: one sample per
+    pipeline) with imputation + reconstruction guidance and ragged lengths."""
+    monkeypatch.setenv("CMDI_GROUPS", "2")
+    name = "chain_edit_recon"
+    case = cases.CASES[name]
+    inp = cases.make_inputs(case)
+    model, _ = make_model(case, precision=precision)
+    diffusion = make_diffusion(case["respacing"])
+    y = {"mask": tt(inp["len_mask"]), "lengths": tt(inp["lengths"]), "text_embed": tt(inp["enc_text"]),
+         "text_scale": tt(inp["text_scale"]), "inpainting_mask": tt(inp["inpaint_mask"]), "inpainted_motion": tt(inp["x0"]),
+         "imputate": True, "stop_imputation_at": case["stop_imputation_at"], "replacement_distribution": "conditional",
+         "reconstruction_guidance": True, "reconstruction_weight": case["recon_weight"], "gradient_schedule": None,
+         "diffusion_steps": 1000, "stop_recguidance_at": case["stop_recguidance_at"]}
+    diffusion.injected_noise = tt(inp["noise"])
+    final = diffusion.p_sample_loop(model, inp["x_T"].shape, noise=tt(inp["x_T"]), clip_denoised=False,
+                                    model_kwargs={"y": y})
+    assert model.model._engine.pipeline_parts() == 2
+    g = load_golden(name)
+    assert rel_l2(final.cpu().numpy(), g["final"]) <= 1e-4, rel_l2(final.cpu().numpy(), g["final"])
+
+
+# measured drift (gpurun_out/drift_*.json, DESIGN.md section 4): bound = 4x the larger of the two engines' measured value
+LONG_TOL = {"long_ddpm": 1e-4, "long_ddim100": 1e-4}
+
+
+@pytest.mark.parametrize("name", ["long_ddpm", "long_ddim100"])
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_long_chain_drift_vs_reference(cases, name, precision):
+    """The FULL 1000-step ancestral chain (and ddim_sample_loop on 'ddim100') on shared noise: x_t every 100 (10) steps
+    against the reference's fp32 chain and against the same chain run by the reference in float64 (ground truth).
+    SURVEY 8c: 'measure, do not assume' — the per-checkpoint errors are written to gpurun_out/ for DESIGN.md."""
+    import json
+    import os
+    case, inp, g, model, diffusion, kw = big_setup(cases, name, precision)
+    prog = diffusion.ddim_sample_loop_progressive if case["sampler"] == "ddim" else diffusion.p_sample_loop_progressive
+    at = {int(i): k for k, i in enumerate(g["dump_at"])}
+    rows, final = [], None
+    for i, out in enumerate(prog(model, inp["draw0"].shape, **kw)):
+        final = out["sample"]
+        if i in at:
+            x = out["sample"][:1].cpu().numpy()
+            k = at[i]
+            rows.append({"step": i + 1, "vs_ref_f32": rel_l2(x, g["dumps"][k]), "vs_ref_f64": rel_l2(x, g["dumps_f64"][k]),
+                         "ref_f32_vs_f64": rel_l2(g["dumps"][k], g["dumps_f64"][k]),
+                         "max_abs_vs_f64": max_abs(x, g["dumps_f64"][k])})
+    final = final.cpu().numpy()
+    summary = {"case": name, "precision": precision, "final_vs_ref_f32": rel_l2(final, g["final"]),
+               "final_vs_ref_f64": rel_l2(final, g["final_f64"]),
+               "ref_f32_vs_f64": rel_l2(g["final"], g["final_f64"]), "rows": rows}
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(f"gpurun_out/drift_{name}_{precision}.json", "w") as fh:
+        json.dump(summary, fh, indent=1)
+    print(json.dumps(summary))
+    assert np.isfinite(final).all()
+    assert summary["final_vs_ref_f64"] <= LONG_TOL[name], summary
+    assert summary["final_vs_ref_f32"] <= LONG_TOL[name], summary
+    # the one-call loop (what p_sample_loop runs) gives the same chain as the per-step generator
+    whole = (diffusion.ddim_sample_loop if case["sampler"] == "ddim" else diffusion.p_sample_loop)(
+        model, inp["draw0"].shape, **kw).cpu().numpy()
+    assert np.array_equal(whole, final)
+
+
+@pytest.mark.parametrize("name", ["eps_ddpm", "eps_ddim"])
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_epsilon_model_chain_vs_reference(cases, name, precision):
+    """ModelMeanType.EPSILON through the native loop (sampler.hip: x0 = sra x - srm1a eps) vs the real reference."""
+    case, inp, g, model, diffusion, kw = big_setup(cases, name, precision)
+    prog = diffusion.ddim_sample_loop_progressive if case["sampler"] == "ddim" else diffusion.p_sample_loop_progressive
+    at = {int(i): k for k, i in enumerate(g["dump_at"])}
+    final = None
+    for i, out in enumerate(prog(model, inp["draw0"].shape, **kw)):
+        final = out["sample"]
+        if i in at:
+            assert rel_l2(out["sample"][:1].cpu().numpy(), g["dumps"][at[i]]) <= 1e-4
+    assert rel_l2(final.cpu().numpy(), g["final"]) <= 1e-4, rel_l2(final.cpu().numpy(), g["final"])
+    # imputation / reconstruction guidance on an eps-model: refused like the reference (:407,430)
+    y = dict(kw["model_kwargs"]["y"], imputate=True, stop_imputation_at=0, inpainting_mask=torch.zeros(inp["draw0"].shape, dtype=torch.bool, device=DEV),
+             inpainted_motion=tt(inp["draw0"]), replacement_distribution='conditional')
+    with pytest.raises(AssertionError, match="X_start"):
+        diffusion.p_sample_loop(model, inp["draw0"].shape, **dict(kw, model_kwargs={"y": y}))
+    # clip_denoised on an eps-model is NotImplemented outside abs_3d trajectory models (:500-505)
+    with pytest.raises(NotImplementedError):
+        diffusion.p_sample_loop(model, inp["draw0"].shape, **dict(kw, clip_denoised=True))
+
+
+def test_epsilon_clip_bit_exact():
+    """process_xstart's clamp for abs_3d trajectory eps-models (clip_x0 of cmdi_schedule) vs the oracle, bit for bit."""
+    Engine, N = sub("engine").Engine, sub("_native")
+    gd, rs = sub("diffusion.gaussian_diffusion"), sub("diffusion.respace")
+    B, C, T = 2, 263, 40
+    rng = np.random.default_rng(11)
+    conf = gd.DiffusionConfig(betas=gd.get_named_beta_schedule("cosine", 1000), model_mean_type=gd.ModelMeanType.EPSILON,
+                              abs_3d=True, traj_only=True, clip_range=6.0)
+    diff = rs.SpacedDiffusion(rs.space_timesteps(1000, "ddim100"), conf)
+    sch = do.Schedule(do.named_betas("cosine", 1000), do.space_timesteps(1000, "ddim100"))
+    e = Engine(n_layers=0, d_model=0, d_ff=0, n_heads=0, n_feats=C, max_frames=T, max_batch=B, device=DEV)
+    e.set_schedule(diff.engine_tables(diff._clip_x0(True)))
+    e.set_condition(batch=B, n_frames=T)
+    shape = (B, C, 1, T)
+    x, eps, nz = (rng.standard_normal(shape).astype(np.float32) for _ in range(3))
+    for step in (90, 40, 0):
+        want, want_x0 = do.step_update(sch, step, x, eps, nz, mean_eps=True, clip=6.0)
+        xd, pred = tt(x).clone(), torch.empty(shape, device=DEV)
+        e.sampler_update(xd, tt(eps), step, noise=tt(nz), pred_xstart=pred)
+        assert np.array_equal(pred.cpu().numpy(), want_x0) and np.array_equal(xd.cpu().numpy(), want), step
+    assert float(np.abs(want_x0).max()) <= 6.0
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_forward_b256_vs_reference(cases, precision):
+    """One CFG evaluation at BASELINE config 4's batch (B=256: GEMM height M = 2 * 256 * 197 = 100,864 rows)."""
+    case = cases.BIG_CASES["fwd_b256"]
+    inp = cases.make_big_inputs(case)
+    g = load_golden("fwd_b256")
+    assert np.array_equal(g["fingerprint"], cases.fingerprint(inp))
+    model, _ = make_model(case, cfg=True, precision=precision)
+    out = model(tt(inp["x"]), tt(inp["t"]), y={"text_embed": tt(inp["enc_text"]), "text_scale": tt(inp["text_scale"])})
+    out = out.cpu().numpy()
+    keep = list(case["keep"])
+    assert max_abs(out[keep], g["out_cfg"]) <= 2e-4 and rel_l2(out[keep], g["out_cfg"]) <= 2e-5, \
+        (max_abs(out[keep], g["out_cfg"]), rel_l2(out[keep], g["out_cfg"]))
+    assert stats_close(cases.sample_stats(out), g["stats"], 5e-5)
+
+
+def test_sharded_p_sample_loop_equals_the_full_batch():
+    """the documented multi-GPU flow (same torch seed on every rank + dist_util.shard_call) must reproduce
+    the single-device batch — y['first_sample'] keys x_T and every step's noise by the GLOBAL sample index."""
+    du = sub("utils.dist_util")
+    case = dict(text=True, weight_seed=23, cfg=True)
+    model, _ = make_model(case, layers=2)
+    diffusion = make_diffusion([5])
+    B, T = 6, 40
+    rng = np.random.default_rng(3)
+    y = {"mask": torch.ones(B, 1, 1, T, dtype=torch.bool, device=DEV), "lengths": torch.full((B,), T),
+         "text_embed": tt(rng.standard_normal((B, 512)).astype(np.float32)), "text_scale": torch.full((B,), 2.5, device=DEV)}
+    shape = (B, 263, 1, T)
+
+    def run(lo, hi):
+        torch.manual_seed(1234)                       # utils.fixseed(seed) on every rank
+        kw = du.shard_batch({"y": y}, 0, 1, B)
+        kw = {"y": {k: (v[lo:hi] if torch.is_tensor(v) and v.shape[0] == B else v) for k, v in kw["y"].items()}}
+        kw["y"]["first_sample"] = lo
+        return diffusion.p_sample_loop(model, (hi - lo,) + shape[1:], clip_denoised=False, model_kwargs=kw)
+
+    full = run(0, B)
+    parts = torch.cat([run(0, 2), run(2, 6)])
+    assert torch.isfinite(full).all() and torch.equal(full, parts)
+    assert not torch.equal(full[:2], full[2:4])       # different samples do get different noise
+    # the progressive (per-step) path keys the noise the same way
+    torch.manual_seed(1234)
+    *_, last = diffusion.p_sample_loop_progressive(model, (4,) + shape[1:], clip_denoised=False,
+                                                   model_kwargs={"y": dict({k: (v[2:6] if torch.is_tensor(v) and v.shape[0] == B else v)
+                                                                            for k, v in y.items()}, first_sample=2)})
+    assert torch.equal(last["sample"], full[2:6])
+
+
+def test_out_of_range_timestep_is_reported():
+    """The reference raises IndexError at pe[timesteps]; the engine clamps the row and raises the status bit."""
+    case = dict(text=False, weight_seed=5)
+    model, _ = make_model(case, layers=1)
+    x = torch.randn(2, 263, 1, 20, device=DEV)
+    model(x, torch.tensor([5, 4999], device=DEV), y={})
+    model._engine.check_range()
+    model(x, torch.tensor([5, 5000], device=DEV), y={})
+    with pytest.raises(IndexError):
+        model._engine.check_range()
+    with pytest.raises(IndexError):
+        model(x, torch.tensor([5, 5000]), y={})      # host tensor: checked before the launch
 
 
 # ---- full-size properties (BASELINE config 2 shape: B=32, T=196, CFG) --------------------------------

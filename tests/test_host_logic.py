@@ -191,6 +191,29 @@ def test_compat_falls_through_to_the_callers_tree(tmp_path):
     assert lines[-2].endswith("amd.utils.editing_util | callers tree 3") and lines[-1] == "AttributeError", out.stdout
 
 
+@pytest.mark.parametrize("order", ["path_first", "install_first"])
+def test_compat_keeps_non_aliased_submodules_importable(tmp_path, order):
+    """the synthetic parents (`utils`, `model`, `diffusion`) must not hide the caller's other submodules —
+    sample/edit.py:10 does `from utils.parser_util import ...` right after the aliased imports."""
+    import subprocess
+    import sys
+    for pkg, mod in (("utils", "parser_util"), ("utils", "misc"), ("model", "mdm_unet_extra"), ("diffusion", "nn")):
+        (tmp_path / pkg).mkdir(exist_ok=True)
+        (tmp_path / pkg / f"{mod}.py").write_text(f"WHO = 'caller {pkg}.{mod}'\n")
+    ins = "sys.path.insert(0, %r);" % str(tmp_path)
+    inst = "importlib.import_module('diffusion-motion-inbetweening_amd.compat').install_reference_aliases();"
+    code = ("import importlib, sys; sys.path.insert(0, %r);" % str(REPO)
+            + (ins + inst if order == "path_first" else inst + ins)
+            + "from utils.fixseed import fixseed; from utils.parser_util import WHO as a; import utils.misc as m;"
+              "import model.mdm_unet_extra as u; from diffusion.nn import WHO as d; from model.cfg_sampler import ClassifierFreeSampleModel as C;"
+              "print(a, '|', m.WHO, '|', u.WHO, '|', d, '|', fixseed.__module__, '|', C.__module__)")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    got = out.stdout.strip().splitlines()[-1].split(" | ")
+    assert got[:4] == ["caller utils.parser_util", "caller utils.misc", "caller model.mdm_unet_extra", "caller diffusion.nn"]
+    assert got[4].endswith("amd.utils.fixseed") and got[5].endswith("amd.model.cfg_sampler")
+
+
 def test_get_keyframes_mask_bit_exact_vs_reference(cases):
     """Every inference edit_mode of get_keyframes_mask (the step before the loop) against masks
     produced by the real reference (tests/golden/make_golden_keyframes.py): ragged lengths incl. sequences shorter

@@ -113,7 +113,7 @@ def run_chain(cases, name):
         kw = dict(mask=mask, inpaint=inp["x0"], imputate=case["imputate"],
                   stop_imputation_at=case["stop_imputation_at"], recon_guidance=case["recon"],
                   stop_recguidance_at=case["stop_recguidance_at"], recon_weight=case["recon_weight"],
-                  grad_schedule=case["grad_schedule"])
+                  grad_schedule=case["grad_schedule"], marginal=case.get("replacement") == "marginal")
     final, preds = do.sample_loop(
         sch, m, x, inp["noise"], sampler=case["sampler"], eta=case.get("eta", 0.0),
         enc_text=inp.get("enc_text"), text_scale=inp.get("text_scale"), cfg=case["cfg"],
@@ -122,12 +122,35 @@ def run_chain(cases, name):
 
 
 @pytest.mark.parametrize("name", ["chain_uncond_ddpm", "chain_edit_recon", "chain_impute_only",
-                                  "chain_ddim_eta0", "chain_ddim_eta05", "chain_skip_init"])
+                                  "chain_ddim_eta0", "chain_ddim_eta05", "chain_skip_init", "chain_marginal_recon"])
 def test_chain(cases, name):
     final, preds, g = run_chain(cases, name)
     assert rel_l2(final, g["final"]) <= 2e-5, rel_l2(final, g["final"])
     for k, step in enumerate(cases.CHAIN_DUMPS[name]):
         assert rel_l2(preds[step], g["pred_xstart"][k]) <= 2e-5, (step, rel_l2(preds[step], g["pred_xstart"][k]))
+
+
+@pytest.mark.parametrize("name", ["eps_ddpm", "eps_ddim"])
+def test_epsilon_chain(cases, name):
+    """ModelMeanType.EPSILON (reference :536-555): x0 = sqrt(1/ab) x - sqrt(1/ab - 1) eps in front of the posterior /
+    DDIM update; chain from t = 666 off a noised init_image."""
+    case = cases.BIG_CASES[name]
+    inp = cases.make_big_inputs(case)
+    g = load_golden(name)
+    assert np.array_equal(g["fingerprint"], cases.fingerprint(inp))
+    m = MDMOracle(weights.make_state_dict(case["weight_seed"], text=False))
+    sch = do.Schedule(do.named_betas("cosine", 1000), do.space_timesteps(1000, case["respacing"]))
+    first = sch.n - 1 - case["skip"]
+    x = do.q_sample(sch, first, inp["init_image"], inp["draw0"])
+    noise = [cases.big_draw(case, 1 + k) for k in range(first + 1)]
+    final, xs = do.sample_loop(sch, m, x, noise, sampler=case["sampler"], eta=case.get("eta", 0.0), first_step=first,
+                               mean_eps=True, collect=True, collect_samples=True)
+    assert rel_l2(final, g["final"]) <= 2e-5, rel_l2(final, g["final"])
+    for k, step in enumerate(g["dump_at"]):
+        assert rel_l2(xs[step][:1], g["dumps"][k]) <= 2e-5
+    # the clamp of process_xstart (clip_denoised with an abs_3d trajectory model) acts on the derived x0 only
+    x1, x0 = do.step_update(sch, first, x, x * 0 + 3.0, noise[0], mean_eps=True, clip=6.0)
+    assert float(np.abs(x0).max()) <= 6.0 and np.isfinite(x1).all()
 
 
 def test_philox_known_answers():

@@ -46,6 +46,14 @@ def _worker(rank, world, port, n):
         out = du.all_gather_batch(full[lo:hi].clone(), n)
         assert torch.equal(out, full), (rank, out.shape)
         assert du.world() == (rank, world)
+        # the documented torchrun flow: shard_call sets the global sample offset the sampler forwards to the engine
+        kw = {"y": {"mask": torch.ones(n, 1, 1, 2, dtype=torch.bool), "text": ["t%d" % i for i in range(n)],
+                    "imputate": True}, "obs_x0": full.clone()}
+        shape, local, nz, init = du.shard_call((n, 3, 1, 2), kw, noise=full)
+        assert shape == (hi - lo, 3, 1, 2) and local["y"]["first_sample"] == lo and init is None
+        assert torch.equal(nz, full[lo:hi]) and torch.equal(local["obs_x0"], full[lo:hi])
+        assert local["y"]["text"] == ["t%d" % i for i in range(lo, hi)] and local["y"]["imputate"] is True
+        assert "first_sample" not in kw["y"]          # the caller's dict is not mutated
     finally:
         dist.destroy_process_group()
 
