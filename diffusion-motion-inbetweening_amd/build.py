@@ -17,6 +17,9 @@ PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 REPO = PKG_DIR.parent
 LIB_PATH = CSRC / "libcondmdi_hip.so"
+# bench-only instrumentation (ablation switches, cycle stamps, tile-tuning environment knobs) is compiled ONLY into
+# this second library (-DCMDI_PROBES), which tools/ load through CMDI_PROBES_LIB=1; the product library has none of it
+PROBES_LIB_PATH = CSRC / "libcondmdi_hip_probes.so"
 
 # translation unit -> extra flags
 UNITS = {
@@ -51,12 +54,13 @@ def _deps_newer(obj: Path, src: Path) -> bool:
     return any(d.stat().st_mtime > t for d in deps)
 
 
-def _compile(unit: str, flags, verbose: bool) -> Path:
+def _compile(unit: str, flags, verbose: bool, probes: bool = False) -> Path:
     src = CSRC / unit
-    obj = CSRC / "build" / (src.stem + ".o")
+    obj = CSRC / ("build_probes" if probes else "build") / (src.stem + ".o")
     obj.parent.mkdir(exist_ok=True)
     if _deps_newer(obj, src):
-        cmd = [_hipcc(), *COMMON, *flags, "-I", str(CSRC), "-c", str(src), "-o", str(obj)]
+        cmd = [_hipcc(), *COMMON, *flags, *(["-DCMDI_PROBES"] if probes else []), "-I", str(CSRC), "-c", str(src),
+               "-o", str(obj)]
         if verbose:
             print("[condmdi build]", " ".join(cmd), flush=True)
         res = subprocess.run(cmd, capture_output=True, text=True)
@@ -67,22 +71,25 @@ def _compile(unit: str, flags, verbose: bool) -> Path:
     return obj
 
 
-def build_native(verbose: bool = False, force: bool = False) -> Path:
-    """Compile every HIP translation unit for gfx950 and link libcondmdi_hip.so."""
-    if force and (CSRC / "build").exists():
-        shutil.rmtree(CSRC / "build")
+def build_native(verbose: bool = False, force: bool = False, probes: bool = False) -> Path:
+    """Compile every HIP translation unit for gfx950 and link libcondmdi_hip.so (probes=True: the instrumented
+    libcondmdi_hip_probes.so for tools/ instead)."""
+    bdir = CSRC / ("build_probes" if probes else "build")
+    lib = PROBES_LIB_PATH if probes else LIB_PATH
+    if force and bdir.exists():
+        shutil.rmtree(bdir)
     with ThreadPoolExecutor(max_workers=min(len(UNITS), os.cpu_count() or 1)) as ex:
-        objs = list(ex.map(lambda kv: _compile(kv[0], kv[1], verbose), UNITS.items()))
-    if force or not LIB_PATH.exists() or any(o.stat().st_mtime > LIB_PATH.stat().st_mtime for o in objs):
+        objs = list(ex.map(lambda kv: _compile(kv[0], kv[1], verbose, probes), UNITS.items()))
+    if force or not lib.exists() or any(o.stat().st_mtime > lib.stat().st_mtime for o in objs):
         cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc",
-               *map(str, objs), "-o", str(LIB_PATH)]
+               *map(str, objs), "-o", str(lib)]
         if verbose:
             print("[condmdi build]", " ".join(cmd), flush=True)
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError(f"link failed:\n{res.stdout}\n{res.stderr}")
-    return LIB_PATH
+    return lib
 
 
 if __name__ == "__main__":
-    print(build_native(verbose=True, force="--force" in sys.argv))
+    print(build_native(verbose=True, force="--force" in sys.argv, probes="--probes" in sys.argv))

@@ -692,17 +692,24 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
     e->L = desc->n_layers; e->d = desc->d_model; e->f = desc->d_ff; e->H = desc->n_heads;
     e->C = desc->n_feats; e->Cpad = (desc->n_feats + 31) / 32 * 32;
     e->Tmax = desc->max_frames; e->Bmax = desc->max_batch;
+    // Runtime configuration read from the environment: CMDI_PRECISION, CMDI_GROUPS, CMDI_PIPELINES, CMDI_GRAPH (all
+    // select between complete, parity-tested schedules).  Tile / fusion tuning knobs exist in the probes build only.
     auto env_int = [](const char* name, int dflt) {
         const char* v = std::getenv(name);
         return v ? std::atoi(v) : dflt;
     };
-    e->gemm_tile = env_int("CMDI_GEMM_TILE", 0);
-    e->tile_inproj = env_int("CMDI_TILE_INPROJ", e->gemm_tile);
-    e->tile_proj = env_int("CMDI_TILE_PROJ", e->gemm_tile);
-    e->tile_ffn1 = env_int("CMDI_TILE_FFN1", e->gemm_tile);
-    e->tile_ffn2 = env_int("CMDI_TILE_FFN2", e->gemm_tile);
+#ifdef CMDI_PROBES
+    auto env_probe = env_int;
+#else
+    auto env_probe = [](const char*, int dflt) { return dflt; };
+#endif
+    e->gemm_tile = env_probe("CMDI_GEMM_TILE", 0);
+    e->tile_inproj = env_probe("CMDI_TILE_INPROJ", e->gemm_tile);
+    e->tile_proj = env_probe("CMDI_TILE_PROJ", e->gemm_tile);
+    e->tile_ffn1 = env_probe("CMDI_TILE_FFN1", e->gemm_tile);
+    e->tile_ffn2 = env_probe("CMDI_TILE_FFN2", e->gemm_tile);
     e->n_groups = env_int("CMDI_GROUPS", 0);  // 0 = automatic
-    e->io_pipe = env_int("CMDI_IO_PIPE", 0);
+    e->io_pipe = env_probe("CMDI_IO_PIPE", 0);
     e->use_graph = env_int("CMDI_GRAPH", 0);
     e->pipelines = env_int("CMDI_PIPELINES", 1);
     {
@@ -717,12 +724,12 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
             return fail(CMDI_E_INVALID, "f16x3 precision needs d_model and d_ff multiples of 32");
         e->precision = prec;
     }
-    e->h3_tile_qkv = env_int("CMDI_H3_TILE_QKV", env_int("CMDI_H3_TILE", 0));
-    e->h3_tile_proj = env_int("CMDI_H3_TILE_PROJ", env_int("CMDI_H3_TILE", 0));
-    e->h3_tile_ffn1 = env_int("CMDI_H3_TILE_FFN1", env_int("CMDI_H3_TILE", 0));
-    e->h3_tile_ffn2 = env_int("CMDI_H3_TILE_FFN2", env_int("CMDI_H3_TILE", 0));
-    e->ln_fuse = env_int("CMDI_LN_FUSE", 0) && desc->d_model == 512;
-    e->io_h3 = e->precision == CMDI_PREC_F16X3 && !e->ln_fuse && env_int("CMDI_IO_H3", 1);
+    e->h3_tile_qkv = env_probe("CMDI_H3_TILE_QKV", env_probe("CMDI_H3_TILE", 0));
+    e->h3_tile_proj = env_probe("CMDI_H3_TILE_PROJ", env_probe("CMDI_H3_TILE", 0));
+    e->h3_tile_ffn1 = env_probe("CMDI_H3_TILE_FFN1", env_probe("CMDI_H3_TILE", 0));
+    e->h3_tile_ffn2 = env_probe("CMDI_H3_TILE_FFN2", env_probe("CMDI_H3_TILE", 0));
+    e->ln_fuse = env_probe("CMDI_LN_FUSE", 0) && desc->d_model == 512;
+    e->io_h3 = e->precision == CMDI_PREC_F16X3 && !e->ln_fuse && env_probe("CMDI_IO_H3", 1);
     const int d = e->d, f = e->f, C = e->C;
     const size_t nseq = 2 * (size_t)e->Bmax, Smax = e->Tmax + 1, Mmax = nseq * Smax;
     *out = e;  // so that cmdi_destroy can free a half-built engine
@@ -1560,11 +1567,13 @@ int cmdi_gemm_h3(const void* d_a_split, const void* d_w_split, const float* d_bi
     p.W = static_cast<const _Float16*>(d_w_split);
     p.bias = d_bias; p.C = d_c; p.Cs = static_cast<_Float16*>(d_c_split); p.R = d_resid;
     p.M = m; p.N = n; p.K = k; p.ldc = n;
+#ifdef CMDI_PROBES
     { const char* v = std::getenv("CMDI_H3_DBG"); p.dbg = v ? std::atoi(v) : 0; }
     if (p.dbg & 16) {   // bench-only: the timestamp buffer rides in d_resid's place when epi != 3
         p.dbg_buf = (epi != 3) ? reinterpret_cast<long long*>(const_cast<float*>(d_resid)) : nullptr;
         if (epi != 3) p.R = nullptr;
     }
+#endif
     int kind;
     switch (epi) {
         case 0: kind = d_c_split ? H3_PLAIN_SPLIT : H3_PLAIN; break;
@@ -1625,7 +1634,11 @@ int cmdi_attention_fwd_h3(const void* d_qkv_split, float* d_out, int32_t n_seq, 
         return fail(CMDI_E_INVALID, "bad argument");
     // (CMDI_ATTN_DBG & 16, bench only: 32 B of cycle stamps per block are written BEHIND the output,
     // the caller allocates n_seq * n_heads * 32 extra bytes)
+#ifdef CMDI_PROBES
     static const bool stamps = std::getenv("CMDI_ATTN_DBG") && (std::atoi(std::getenv("CMDI_ATTN_DBG")) & 16);
+#else
+    constexpr bool stamps = false;
+#endif
     HIPCHK(launch_attention_h3(static_cast<const _Float16*>(d_qkv_split), d_out, nullptr, nullptr,
                                stamps ? d_out + (size_t)n_seq * seq_len * n_heads * 128 : nullptr, n_seq, seq_len, n_heads,
                                static_cast<hipStream_t>(stream)));

@@ -75,7 +75,12 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void attention_h3_kernel(const _Floa
                                                               _Float16* __restrict__ out_s,
                                                               int* __restrict__ range_flag,
                                                               float* __restrict__ row_stats, int S,
-                                                              int H, float scale, int dbg) {
+                                                              int H, float scale, int dbg_arg) {
+#ifdef CMDI_PROBES
+    const int dbg = dbg_arg;   // bench-only ablations / cycle stamps (probes build only, see gemm_h3.hpp)
+#else
+    constexpr int dbg = 0;
+#endif
     extern __shared__ __attribute__((aligned(16))) char lds[];  // [2][K tile | V tile]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -719,7 +724,11 @@ hipError_t launch_attention_h3(const _Float16* qkv_split, float* out, _Float16* 
     dim3 grid(n_seq * H, (S + 32 * NWAVE - 1) / (32 * NWAVE));
     const float scale = 1.0f / sqrtf((float)DH);
     constexpr size_t lds = (size_t)NSTG * STAGE;  // 128 KiB: one block per CU
+#ifdef CMDI_PROBES
     static const int dbg = std::getenv("CMDI_ATTN_DBG") ? std::atoi(std::getenv("CMDI_ATTN_DBG")) : 0;
+#else
+    constexpr int dbg = 0;
+#endif
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_h3_kernel<true>),

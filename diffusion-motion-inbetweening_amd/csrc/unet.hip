@@ -576,9 +576,12 @@ hipError_t pack(UnetModel* u, Conv& c, hipStream_t s) {
 UnetModel* unet_new(int n_feats, int added, int dim, const int mults[4], int max_seq, bool text, bool want_grad) {
     UnetModel* u = new UnetModel();
     u->J = n_feats; u->added = added; u->dim = dim; u->max_seq = max_seq; u->text = text; u->want_grad = want_grad;
+#ifdef CMDI_PROBES   // tuning knobs: probes build only
     if (const char* v = std::getenv("CMDI_UNET_KSPLIT")) u->ksplit_ok = std::atoi(v);
     if (const char* v = std::getenv("CMDI_UNET_TILE")) u->big_tile = std::atoi(v);
     if (const char* v = std::getenv("CMDI_UNET_MFAST")) u->m_fast = std::atoi(v);
+#endif
+    // both GroupNorm schedules (separate kernels / fused epilogue) are complete and parity-tested
     if (const char* v = std::getenv("CMDI_UNET_FUSE_GN")) u->fuse_gn = std::atoi(v);
     u->C[0] = n_feats + added;
     for (int i = 0; i < 4; ++i) u->C[i + 1] = dim * mults[i];

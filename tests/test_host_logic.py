@@ -152,6 +152,20 @@ def test_no_cpu_fallback():
         diffusion.p_sample_loop(model, (1, 263, 1, 8), model_kwargs={})
 
 
+def test_product_library_has_no_instrumentation(condmdi):
+    """ablation switches (CMDI_H3_DBG / CMDI_ATTN_DBG) and the tile-tuning knobs are compiled only into
+    libcondmdi_hip_probes.so (build.py --probes); the library the product and the bench load holds none of them."""
+    import subprocess
+    lib = condmdi._native.LIB_PATH
+    assert lib.name == "libcondmdi_hip.so" and lib.exists()
+    names = subprocess.run(["strings", "-a", str(lib)], capture_output=True, text=True, check=True).stdout
+    for knob in ("_DBG", "CMDI_H3_TILE", "CMDI_TILE_", "CMDI_GEMM_TILE", "CMDI_LN_FUSE", "CMDI_IO_", "CMDI_UNET_TILE",
+                 "CMDI_UNET_KSPLIT"):
+        assert knob not in names, knob
+    for kept in ("CMDI_PRECISION", "CMDI_GROUPS", "CMDI_GRAPH", "CMDI_PIPELINES"):
+        assert kept in names, kept
+
+
 def test_compat_aliases_resolve_reference_import_names():
     import subprocess
     import sys

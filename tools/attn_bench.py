@@ -1,4 +1,5 @@
 """Attention core microbenchmark (B=32 CFG shape): fp32-MFMA kernel vs the split-f16 kernel."""
+import os as _os; _os.environ.setdefault("CMDI_PROBES_LIB", "1")   # instrumented library (build.py --probes)
 import importlib, sys
 from pathlib import Path
 import torch

@@ -1,5 +1,6 @@
 """Launch the U-Net's level-0 k=5 convolution GEMM (64 framed sequences x 256 rows, 1024 -> 1024 channels) a few times
 for rocprofv3 --pmc passes:  rocprofv3 --pmc FETCH_SIZE --output-format csv -d out -- python tools/conv_pmc.py"""
+import os as _os; _os.environ.setdefault("CMDI_PROBES_LIB", "1")   # instrumented library (build.py --probes)
 import importlib, os, sys
 from pathlib import Path
 import torch

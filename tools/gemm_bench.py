@@ -1,4 +1,5 @@
 """GEMM microbenchmark on the denoiser's shapes: TFLOP/s per tile / pipeline variant and epilogue."""
+import os as _os; _os.environ.setdefault("CMDI_PROBES_LIB", "1")   # instrumented library (build.py --probes)
 import importlib
 import sys
 from pathlib import Path

@@ -1,4 +1,5 @@
 """Launch a few GEMM variants once each (after warm-up) for rocprofv3 --pmc."""
+import os as _os; _os.environ.setdefault("CMDI_PROBES_LIB", "1")   # instrumented library (build.py --probes)
 import importlib, sys
 from pathlib import Path
 import torch

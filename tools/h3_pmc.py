@@ -1,5 +1,6 @@
 """Launch the split-f16 GEMMs of one encoder layer (and the attention core) a few times each, for
 rocprofv3 --pmc / --kernel-trace runs:  rocprofv3 --pmc <counters> --output-format csv -d out -- python tools/h3_pmc.py"""
+import os as _os; _os.environ.setdefault("CMDI_PROBES_LIB", "1")   # instrumented library (build.py --probes)
 import importlib, os, sys
 from pathlib import Path
 import torch

@@ -1,5 +1,6 @@
 """How much of a GEMM's time is wave quantization?  Times the in_proj / linear1 shapes at row counts that
 fill an integer number of rounds (512 block slots) and at the real M."""
+import os as _os; _os.environ.setdefault("CMDI_PROBES_LIB", "1")   # instrumented library (build.py --probes)
 import importlib, sys
 from pathlib import Path
 import torch

@@ -1,5 +1,6 @@
 """Time one CFG denoising step (B=32, T=196) under different engine knobs (env vars read at
 cmdi_create): sequence groups / streams and per-GEMM tile variants."""
+import os as _os; _os.environ.setdefault("CMDI_PROBES_LIB", "1")   # instrumented library (build.py --probes)
 import importlib
 import os
 import sys

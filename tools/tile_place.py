@@ -1,3 +1,4 @@
+import os as _os; _os.environ.setdefault("CMDI_PROBES_LIB", "1")   # instrumented library (build.py --probes)
 import importlib, os, sys
 from pathlib import Path
 import numpy as np

@@ -1,4 +1,5 @@
 """Per-block timeline of one split-f16 GEMM launch (CMDI_H3_DBG=16: s_memtime stamps written by the kernel)."""
+import os as _os; _os.environ.setdefault("CMDI_PROBES_LIB", "1")   # instrumented library (build.py --probes)
 import importlib, os, sys
 from pathlib import Path
 import numpy as np
