@@ -1,6 +1,6 @@
 """Throughput of the CondMDI sampling hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4|c5|unet|unet_recon] [--no-cpu] [--no-pmc]
 
 Workload (BASELINE.json configs[1], "c2"): HumanML3D shape B=32 x 263 feats x 196 frames per GPU,
 1000-step DDPM chain, text-conditioned classifier-free guidance (2 denoiser passes per step),
@@ -11,19 +11,27 @@ entered at step K-1 (t = K-1 .. 0), bracketed by barrier + torch.cuda.synchroniz
 the maximum over ranks is the time.  value = N * K / time (weak scaling: every rank runs its own
 B=32 slice; no collective inside the loop, one RCCL all-gather of the samples afterwards).
 
-Prints ONE JSON line on rank 0 (see the task contract) with two extra objects:
-  roofline      the dominant kernel = the self-attention in_proj GEMM (fp32 MFMA), timed with HIP
-                events on its own stream inside a second, instrumented pass over the same K steps
+Prints ONE JSON line on rank 0 (see the task contract) with these extra objects:
+  roofline      the dominant kernel = the self-attention in_proj GEMM, timed with HIP events on its own stream inside
+                a second, instrumented pass over the same K steps; `traffic` (HBM bytes per launch), `mfma_busy` and
+                `hbm_gbps` come from rocprofv3 --pmc sub-runs of THIS config (separate passes: FETCH_SIZE doubled per
+                the gfx950 correction of MI355X_MICROARCH.md | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE)
+  f32_exact     the same K steps on the exact-fp32 engine (CMDI_PREC_F32: v_mfma_f32_32x32x2_f32 products) with its own
+                roofline against the 157.3 TFLOP/s fp32-matrix peak (transformer configs, N=1)
   cpu_baseline  the reference's CPU path restated on torch CPU kernels (oracle/torch_cpu_port.py) on the
                 host cores, a bounded sample of the same workload (1 warm-up + 3 full CFG steps at B=32)
 """
 from __future__ import annotations
 
 import argparse
+import csv
 import importlib
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 from pathlib import Path
 from types import SimpleNamespace
@@ -48,6 +56,10 @@ CONFIGS = {
                desc="benchmark_sparse imputation + reconstruction guidance, 1000-step DDPM, B=32/GPU, CFG"),
     "c4": dict(B=256, respacing="ddim100", sampler="ddim", cfg=True, edit=False,
                desc="DDIM-100 respaced, B=256/GPU, text CFG"),
+    # BASELINE configs[4]: batch 1024 = 8 x 128 sharded over the node.  STRONG scaling: the global batch stays 1024, every
+    # rank samples 1024 / N of it (one GPU holds all 1024: 19 GB of workspace), one all-gather at the end
+    "c5": dict(B=1024, respacing=[1000], sampler="ddpm", cfg=True, edit=False, strong=True,
+               desc="conditional_synthesis batch 1024 sharded over the GPUs (1024/N per GPU), 1000-step DDPM, text CFG"),
     # the denoiser CondMDI trains / releases (configs/model.py motion_unet_adagn_xl)
     "unet": dict(B=32, respacing=[1000], sampler="ddpm", cfg=True, edit=False, unet=True,
                  desc="MDM_UNET (dim_mults 2,2,2,2, keyframe-conditioned), HumanML3D 196x263, 1000-step DDPM, "
@@ -201,6 +213,100 @@ def cpu_baseline_unet(sd, B, n_steps=2):
                       f"on a host with {host} logical CPUs)"}
 
 
+N_SIMD = 1024            # 256 CUs x 4 SIMDs
+N_XCD = 8
+
+
+def pmc_counters(config: str, precision: str, batch: int, timeout_s: float = 150.0):
+    """rocprofv3 --pmc sub-runs of `bench.py --pmc-child` for THIS config and precision (counters serialise kernels, so
+    they never run inside the timed region): per launch of the dominant GEMM (the largest-grid gemm kernel = the
+    in_proj projection) FETCH_SIZE, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES and GRBM_GUI_ACTIVE, each in its own pass
+    (MI355X_MICROARCH.md: FETCH_SIZE takes 3 of the 4 TCC slots).  Returns {} if rocprofv3 is unavailable."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"pmc_error": "rocprofv3 not found"}
+    res, t_end = {}, time.time() + timeout_s
+    tmp = tempfile.mkdtemp(prefix="cmdi_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    env = dict(os.environ, TMPDIR=tmp, CMDI_GROUPS="1")
+    env.pop("CMDI_PROBES_LIB", None)
+    try:
+        for i, ctrs in enumerate((["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"])):
+            left = t_end - time.time()
+            if left < 20:
+                res["pmc_error"] = "time budget exhausted"
+                break
+            out_dir = os.path.join(tmp, f"p{i}")
+            cmd = [exe, "--pmc", *ctrs, "--output-format", "csv", "-d", out_dir, "-o", "p", "--", sys.executable,
+                   str(REPO / "bench.py"), "--pmc-child", "--config", config, "--precision", precision,
+                   "--batch", str(batch)]
+            try:
+                r = subprocess.run(cmd, cwd=tmp, env=env, capture_output=True, text=True, timeout=left)
+            except subprocess.TimeoutExpired:
+                res["pmc_error"] = "rocprofv3 pass timed out"
+                break
+            if r.returncode != 0:
+                res["pmc_error"] = f"rocprofv3 rc={r.returncode}: {r.stderr[-300:]}"
+                break
+            files = [os.path.join(dp, f) for dp, _, fs in os.walk(out_dir) for f in fs if f.endswith("counter_collection.csv")]
+            rows = []
+            for fcsv in files:
+                with open(fcsv, newline="") as fh:
+                    rows += [r_ for r_ in csv.DictReader(fh) if "gemm" in r_["Kernel_Name"]]
+            if not rows:
+                res["pmc_error"] = "no gemm dispatches in the counter file"
+                break
+            gmax = max(int(r_["Grid_Size"]) for r_ in rows)
+            for c in ctrs:
+                vals = [float(r_["Counter_Value"]) for r_ in rows if int(r_["Grid_Size"]) == gmax and r_["Counter_Name"] == c]
+                if vals:
+                    res[c] = sum(vals) / len(vals)
+                    res["pmc_launches"] = len(vals)
+            res["pmc_kernel"] = next(r_["Kernel_Name"] for r_ in rows if int(r_["Grid_Size"]) == gmax)[:160]
+            res["pmc_grid"] = gmax
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return res
+
+
+def roofline_from(eng, run_loop, split, is_unet, pmc):
+    """Instrumented pass (HIP events around every in_proj GEMM launch, or one level-0 convolution GEMM per U-Net
+    evaluation) + the PMC numbers of the same config."""
+    eng.profile_enable(True)
+    run_loop()
+    torch.cuda.synchronize()
+    ms, launches, (m, n, k) = eng.profile_read()
+    eng.profile_enable(False)
+    avg_s = ms / max(launches, 1) * 1e-3
+    flop_launch = 2.0 * m * n * k
+    ach = flop_launch / avg_s / 1e12
+    traffic = mfma_busy = clock = None
+    if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+        # rocprofv3 reports KiB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B (MI355X_MICROARCH.md, HBM) -> x2
+        traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in pmc and "GRBM_GUI_ACTIVE" in pmc and pmc["GRBM_GUI_ACTIVE"] > 0:
+        cyc = pmc["GRBM_GUI_ACTIVE"] / N_XCD              # the counter is summed over the 8 XCDs
+        mfma_busy = pmc["SQ_VALU_MFMA_BUSY_CYCLES"] / (N_SIMD * cyc)
+    rl = {"bound": "mfma", "achieved": ach, "unit": "TFLOP/s", "traffic": traffic, "launches": launches,
+          "avg_launch_us": avg_s * 1e6, "flops_per_launch": flop_launch,
+          "algorithmic_bytes": 4.0 * (m * k + n * k + m * n),
+          "mfma_busy": mfma_busy, "hbm_gbps": (traffic / avg_s / 1e9) if traffic else None,
+          "pmc": {k_: v for k_, v in pmc.items() if k_.startswith("pmc_") or k_ in ("FETCH_SIZE", "WRITE_SIZE",
+                  "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE")}}
+    if split:
+        # algorithmic flops = 2MNK of the fp32 product; the kernel executes 3 f16 MFMA products per algorithmic
+        # product, so its ceiling is the dense f16 peak / 3
+        peak = F16_MFMA_PEAK_TFLOPS / 3.0
+        what = ("unet.downs.0.1.blocks.1 Conv1d k=5 as a tap-shifted GEMM" if is_unet else "self_attn.in_proj")
+        rl.update(kernel=f"gemm_h3_kernel ({what}, M={m} N={n} K={k}, 3x v_mfma_f32_32x32x16_f16 per fp32-equivalent "
+                         "product" + ("" if is_unet else ", split-rows output") + ")",
+                  peak=peak, frac=ach / peak, executed_f16_tflops=3.0 * ach, f16_dense_peak=F16_MFMA_PEAK_TFLOPS,
+                  vs_fp32_mfma_peak=ach / FP32_MFMA_PEAK_TFLOPS)
+    else:
+        rl.update(kernel=f"gemm_nt_kernel (self_attn.in_proj, M={m} N={n} K={k}, fp32 MFMA 32x32x2)",
+                  peak=FP32_MFMA_PEAK_TFLOPS, frac=ach / FP32_MFMA_PEAK_TFLOPS)
+    return rl
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -209,15 +315,15 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc sub-runs (traffic / mfma_busy = null)")
+    ap.add_argument("--no-f32", action="store_true", help="skip the exact-fp32 engine's leg")
     ap.add_argument("--graph", action="store_true", help="replay each denoising step as a hipGraph")
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch of the config (exploration)")
     ap.add_argument("--precision", default=None, choices=["f32", "f16x3"],
                     help="encoder GEMM arithmetic (include/condmdi.h CMDI_PREC_*); default: the library's")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
-    if args.batch > 0:
-        cfg["B"] = args.batch
-        cfg["desc"] += f" [batch overridden to {args.batch}]"
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -231,23 +337,31 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", init_method="env://", device_id=dev)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    n_ranks_seen = dist.get_world_size() if world > 1 else 1
 
-    B, K, W = cfg["B"], args.steps, args.warmup
     gd, rs, du = sub("diffusion.gaussian_diffusion"), sub("diffusion.respace"), sub("utils.dist_util")
     N = sub("_native")
-    model, sd = build_unet(dev) if cfg.get("unet") else build_model(cfg["cfg"], dev)
+    strong = bool(cfg.get("strong"))
+    if args.batch > 0:
+        cfg["B"] = args.batch
+        if not args.pmc_child:
+            cfg["desc"] += f" [batch overridden to {args.batch}]"
+    global_batch = cfg["B"] if strong else world * cfg["B"]
+    lo, hi = du.shard_bounds(global_batch, rank, world)
+    B = hi - lo                      # this rank's samples [lo, hi) of the global batch
+    K, W = args.steps, args.warmup
+    if args.pmc_child:
+        K, W = 3, 2
+    is_unet = bool(cfg.get("unet"))
+    model, sd = build_unet(dev) if is_unet else build_model(cfg["cfg"], dev)
     diffusion = rs.SpacedDiffusion(rs.space_timesteps(1000, cfg["respacing"]),
                                    gd.DiffusionConfig(betas=gd.get_named_beta_schedule("cosine", 1000)))
     n_chain = diffusion.num_timesteps
     assert K + W <= n_chain, f"steps + warmup must be <= {n_chain}"
-    model.native_precision = args.precision
-    eng = model.engine(dev, max_batch=B, max_frames=T_FRAMES, want_grad=cfg["edit"])
-    is_unet = bool(cfg.get("unet"))
-    split = eng.precision == "f16x3"
-    eng.set_graph(args.graph)
-    eng.set_schedule(diffusion.engine_tables(), key="bench")
+    sampler = N.CMDI_SAMPLER_DDIM if cfg["sampler"] == "ddim" else N.CMDI_SAMPLER_DDPM
+    seed = 20260925
 
-    # synthetic per-rank inputs keyed by GLOBAL sample index (rank r owns samples [r*B, (r+1)*B))
+    # synthetic per-rank inputs keyed by GLOBAL sample index (this rank owns samples [lo, hi))
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     enc = torch.randn(B, 512, generator=g).to(dev)
     scale = torch.full((B,), 2.5, device=dev)
@@ -266,39 +380,52 @@ def main():
         cond.update(inpaint_mask=mask.to(dev), inpaint_motion=x0, imputate=True, stop_imputation_at=1,
                     recon_guidance=True, stop_recguidance_at=0,
                     recon_w=np.full((n_chain,), 20.0, dtype=np.float32))
-    eng.set_condition(**cond)
-    sampler = N.CMDI_SAMPLER_DDIM if cfg["sampler"] == "ddim" else N.CMDI_SAMPLER_DDPM
-    seed, first = 20260925, rank * B
-    x = eng.randn((B, N_FEATS, 1, T_FRAMES), seed=seed, first_sample=first)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # warm-up: W steps from the top of the chain (untimed)
-    if W > 0:
-        eng.sample_loop(x, n_chain - 1, n_chain - W, sampler=sampler, seed=seed, first_sample=first)
-    barrier()
-    t0 = time.perf_counter()
-    eng.sample_loop(x, K - 1, 0, sampler=sampler, seed=seed, first_sample=first)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    assert torch.isfinite(x).all(), "non-finite samples"
-    eng.check_range()
+    def timed_run(precision):
+        """W untimed warm-up steps from the top of the chain, then exactly K timed steps (the last K of the chain),
+        barrier + synchronize on both sides, max over ranks.  Returns (seconds, engine, samples, loop closure)."""
+        model.native_precision = precision
+        eng = model.engine(dev, max_batch=B, max_frames=T_FRAMES, want_grad=cfg["edit"])
+        eng.set_graph(args.graph)
+        eng.set_schedule(diffusion.engine_tables(), key=None)
+        eng.set_condition(**cond)
+        x = eng.randn((B, N_FEATS, 1, T_FRAMES), seed=seed, first_sample=lo)
+        if W > 0:
+            eng.sample_loop(x, n_chain - 1, n_chain - W, sampler=sampler, seed=seed, first_sample=lo)
+        loop = lambda: eng.sample_loop(x, K - 1, 0, sampler=sampler, seed=seed, first_sample=lo)
+        barrier()
+        t0 = time.perf_counter()
+        loop()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        assert torch.isfinite(x).all(), "non-finite samples"
+        eng.check_range()
+        return elapsed, eng, x, loop
+
+    elapsed, eng, x, loop = timed_run(args.precision)
+    if args.pmc_child:
+        return
+    split = eng.precision == "f16x3"
 
     # the path's only collective: reassemble the generated sequences (outside the timed steps)
     t1 = time.perf_counter()
-    full = du.all_gather_batch(x, world * B)
+    full = du.all_gather_batch(x, global_batch)
     torch.cuda.synchronize(dev)
     gather_ms = (time.perf_counter() - t1) * 1e3
-    assert full.shape[0] == world * B
+    assert full.shape[0] == global_batch
 
-    steps_per_s = world * K / elapsed
+    # whole-job throughput.  Weak scaling: every rank steps its own batch, so the job advances N batch-steps per
+    # step time; strong scaling (c5): ONE global batch, so steps/s is 1 / step time and motions/s carries the scaling
+    steps_per_s = (1 if strong else world) * K / elapsed
     passes = 2 if cfg["cfg"] else 1
     flop_step = B * passes * flops_per_sample_eval() * (30.68 / 14.706 if cfg["edit"] else 1.0)
     if is_unet:   # the input-VJP repeats every convolution GEMM once (dX only, no weight gradients)
@@ -306,63 +433,55 @@ def main():
     out = {
         "metric": "diffusion denoising steps/sec", "value": steps_per_s, "unit": "steps/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": ("f32 (products as 3 split-f16 MFMAs on 22-bit operand pairs, fp32 accumulate; same "
                   "parity tolerances as exact fp32)") if split else "f32",
         "precision_mode": eng.precision, "hip_graph": bool(args.graph),
         "data": "synthetic (random-init MDM weights, z-scored N(0,1) motions, fake CLIP embeddings)",
-        "config": {"workload": cfg["desc"], "batch_per_gpu": B, "global_batch": world * B,
+        "config": {"workload": cfg["desc"], "batch_per_gpu": B, "global_batch": global_batch,
                    "n_frames": T_FRAMES, "n_feats": N_FEATS, "chain_steps": n_chain,
                    "parallelism": f"batch-sharded x{world}"},
-        "motions_per_sec": world * B / (n_chain * elapsed / K),
+        "motions_per_sec": global_batch / (n_chain * elapsed / K),
         "step_tflops": flop_step / (elapsed / K) / 1e12,
         "step_frac_of_fp32_mfma_peak": flop_step / (elapsed / K) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-        "allgather_ms": gather_ms,
+        "allgather_ms": gather_ms, "n_ranks_seen": n_ranks_seen,
+        "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if world > 1 else None,
+        "pipeline_parts": eng.pipeline_parts(),
     }
 
+    want_pmc = rank == 0 and world == 1 and not args.no_pmc and not args.no_roofline and not is_unet
     if rank == 0 and not args.no_roofline:
-        # instrumented second pass over the same K steps: HIP events around every in_proj GEMM (transformer) or
-        # around one level-0 k=5 convolution GEMM per evaluation (U-Net: downs.0.1 blocks.1)
-        eng.profile_enable(True)
-        eng.sample_loop(x, K - 1, 0, sampler=sampler, seed=seed, first_sample=first)
-        torch.cuda.synchronize(dev)
-        ms, launches, (m, n, k) = eng.profile_read()
-        eng.profile_enable(False)
-        avg_s = ms / max(launches, 1) * 1e-3
-        flop_launch = 2.0 * m * n * k
-        traffic = None
-        pmc = REPO / "profiles" / "pmc_inproj_gemm.json"
-        if pmc.exists():
-            traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
-        ach = flop_launch / avg_s / 1e12
-        if is_unet:   # PMC passes of the level-0 convolution GEMM (tools/conv_pmc.py)
+        pmc = pmc_counters(args.config, eng.precision, B) if want_pmc else {}
+        out["roofline"] = roofline_from(eng, loop, split, is_unet, pmc)
+        if is_unet:   # PMC passes of the level-0 convolution GEMM were taken by tools/conv_pmc.py (round 1)
             pmc_u = REPO / "profiles" / "pmc_unet_conv_gemm.json"
-            traffic = json.loads(pmc_u.read_text()).get("hbm_bytes_per_launch") if pmc_u.exists() else None
-        if split:
-            # algorithmic flops = 2MNK of the fp32 product; the kernel executes 3 f16 MFMA products
-            # per algorithmic product, so its ceiling is the dense f16 peak / 3
-            peak = F16_MFMA_PEAK_TFLOPS / 3.0
-            what = ("unet.downs.0.1.blocks.1 Conv1d k=5 as a tap-shifted GEMM" if is_unet else "self_attn.in_proj")
-            out["roofline"] = {
-                "kernel": f"gemm_h3_kernel ({what}, M={m} N={n} K={k}, 3x v_mfma_f32_32x32x16_f16 "
-                          "per fp32-equivalent product" + ("" if is_unet else ", split-rows output") + ")",
-                "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                "traffic": traffic, "launches": launches, "avg_launch_us": avg_s * 1e6,
-                "flops_per_launch": flop_launch, "executed_f16_tflops": 3.0 * ach,
-                "f16_dense_peak": F16_MFMA_PEAK_TFLOPS, "vs_fp32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS,
-            }
-        else:
-            out["roofline"] = {
-                "kernel": f"gemm_nt_kernel (self_attn.in_proj, M={m} N={n} K={k}, fp32 MFMA 32x32x2)",
-                "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS,
-                "traffic": traffic, "launches": launches, "avg_launch_us": avg_s * 1e6,
-                "flops_per_launch": flop_launch,
-            }
+            out["roofline"]["traffic"] = json.loads(pmc_u.read_text()).get("hbm_bytes_per_launch") if pmc_u.exists() else None
+            out["roofline"]["traffic_source"] = "profiles/pmc_unet_conv_gemm.json (round 1, not re-measured in this run)"
     if world > 1:
         dist.barrier()
+
+    # the exact-fp32 engine on the same K steps (CMDI_PREC_F32): its own driver-timed number beside the default's
+    if rank == 0 and world == 1 and split and not is_unet and not args.no_f32 and args.precision is None:
+        e32, eng32, x32, loop32 = timed_run("f32")
+        f32 = {"value": K / e32, "unit": "steps/s", "ms_per_step": e32 / K * 1e3, "precision_mode": eng32.precision,
+               "dtype": "f32 (v_mfma_f32_32x32x2_f32: exact fp32 products)",
+               "step_tflops": flop_step / (e32 / K) / 1e12,
+               "step_frac_of_fp32_mfma_peak": flop_step / (e32 / K) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+               "max_abs_diff_vs_default": float((x32 - x).abs().max()),
+               "rel_l2_vs_default": float((x32 - x).norm() / x.norm())}
+        if not args.no_roofline:
+            pmc32 = pmc_counters(args.config, "f32", B) if want_pmc else {}
+            f32["roofline"] = roofline_from(eng32, loop32, False, False, pmc32)
+        out["f32_exact"] = f32
+        model.native_precision = None
+
     if rank == 0 and world == 1 and not args.no_cpu and not (is_unet and cfg["edit"]):
-        out["cpu_baseline"] = cpu_baseline_unet(sd, B) if is_unet else cpu_baseline(sd, B)
+        Bc = min(B, 32)   # bounded sample: at most the c2 batch (c4/c5: per-sample cost is the same, scaled below)
+        base = cpu_baseline_unet(sd, Bc) if is_unet else cpu_baseline(sd, Bc)
+        if Bc != B:
+            base["value"] *= Bc / B
+            base["sample"] += f"; measured at B={Bc} and scaled by {Bc}/{B} to this config's batch (cost is linear in B)"
+        out["cpu_baseline"] = base
         out["gpu_over_cpu"] = steps_per_s / out["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -617,6 +617,24 @@ def test_full_size_batch_independence_and_sharding(precision):
     assert torch.equal(full[5:6], single), "a sample depends on its batch neighbours"
 
 
+# ---- bench.py ------------------------------------------------------------------------------------------
+def test_bench_c5_runs_on_one_gpu():
+    """BASELINE configs[4] (batch 1024 sharded over the node, strong scaling): the driver's 8-GPU run must not be the
+    first execution of this path — one GPU takes the whole global batch (N = 1 point of the strong-scaling curve)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import REPO
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "1", "--config", "c5", "--steps", "4",
+                        "--warmup", "1", "--no-cpu", "--no-pmc", "--no-f32"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["scaling"] == "strong" and line["n_gpus"] == 1 and line["steps"] == 4
+    assert line["config"]["global_batch"] == 1024 and line["config"]["batch_per_gpu"] == 1024
+    assert line["value"] > 0 and abs(line["value"] * line["ms_per_step"] - 1000.0) < 1e-6 * 1000
+    assert line["roofline"]["frac"] > 0.05 and line["pipeline_parts"] == 2
+
+
 # ---- hipGraph replay -----------------------------------------------------------------------------------
 @pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("sampler", ["ddpm", "ddim"])
