@@ -230,7 +230,11 @@ def pmc_counters(config: str, precision: str, batch: int, timeout_s: float = 150
     env = dict(os.environ, TMPDIR=tmp, CMDI_GROUPS="1")
     env.pop("CMDI_PROBES_LIB", None)
     try:
-        for i, ctrs in enumerate((["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"])):
+        # pass 0 identifies the dominant kernel: SQ_VALU_MFMA_BUSY_CYCLES is an exact function of a launch's MFMA count,
+        # and the in_proj projection (largest M*N*K of the step) has the largest — its Dispatch_Ids (the launch order is
+        # deterministic) select the same launches in the FETCH_SIZE / WRITE_SIZE passes
+        dominant = None
+        for i, ctrs in enumerate((["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"], ["FETCH_SIZE"], ["WRITE_SIZE"])):
             left = t_end - time.time()
             if left < 20:
                 res["pmc_error"] = "time budget exhausted"
@@ -255,14 +259,22 @@ def pmc_counters(config: str, precision: str, batch: int, timeout_s: float = 150
             if not rows:
                 res["pmc_error"] = "no gemm dispatches in the counter file"
                 break
-            gmax = max(int(r_["Grid_Size"]) for r_ in rows)
+            if dominant is None:
+                busy = {int(r_["Dispatch_Id"]): float(r_["Counter_Value"]) for r_ in rows
+                        if r_["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES"}
+                top = max(busy.values())
+                dominant = {d for d, v in busy.items() if v == top}
+                first = next(r_ for r_ in rows if int(r_["Dispatch_Id"]) in dominant)
+                res["pmc_kernel"], res["pmc_grid"] = first["Kernel_Name"][:160], int(first["Grid_Size"])
+                res["pmc_launches"] = len(dominant)
             for c in ctrs:
-                vals = [float(r_["Counter_Value"]) for r_ in rows if int(r_["Grid_Size"]) == gmax and r_["Counter_Name"] == c]
-                if vals:
-                    res[c] = sum(vals) / len(vals)
-                    res["pmc_launches"] = len(vals)
-            res["pmc_kernel"] = next(r_["Kernel_Name"] for r_ in rows if int(r_["Grid_Size"]) == gmax)[:160]
-            res["pmc_grid"] = gmax
+                vals = [float(r_["Counter_Value"]) for r_ in rows if int(r_["Dispatch_Id"]) in dominant and r_["Counter_Name"] == c]
+                if len(vals) != len(dominant):
+                    res["pmc_error"] = f"dispatch ids moved between passes ({c}: {len(vals)} of {len(dominant)})"
+                    break
+                res[c] = sum(vals) / len(vals)
+            if "pmc_error" in res:
+                break
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return res

@@ -491,6 +491,7 @@ def test_epsilon_model_chain_vs_reference(cases, name, precision):
     # imputation / reconstruction guidance on an eps-model: refused like the reference (:407,430)
     y = dict(kw["model_kwargs"]["y"], imputate=True, stop_imputation_at=0, inpainting_mask=torch.zeros(inp["draw0"].shape, dtype=torch.bool, device=DEV),
              inpainted_motion=tt(inp["draw0"]), replacement_distribution='conditional')
+    kw.pop("eta", None)
     with pytest.raises(AssertionError, match="X_start"):
         diffusion.p_sample_loop(model, inp["draw0"].shape, **dict(kw, model_kwargs={"y": y}))
     # clip_denoised on an eps-model is NotImplemented outside abs_3d trajectory models (:500-505)
