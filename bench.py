@@ -313,6 +313,13 @@ def roofline_from(eng, run_loop, split, is_unet, pmc):
                          "product" + ("" if is_unet else ", split-rows output") + ")",
                   peak=peak, frac=ach / peak, executed_f16_tflops=3.0 * ach, f16_dense_peak=F16_MFMA_PEAK_TFLOPS,
                   vs_fp32_mfma_peak=ach / FP32_MFMA_PEAK_TFLOPS)
+    elif eng.precision == "bf16x6":
+        # six exact bf16 partial products per fp32 product: ceiling = dense bf16 peak / 6
+        peak = F16_MFMA_PEAK_TFLOPS / 6.0
+        rl.update(kernel=f"gemm_x6_kernel (self_attn.in_proj, M={m} N={n} K={k}, 6x v_mfma_f32_32x32x16_bf16 per fp32 "
+                         "product on exact three-plane bf16 operands)",
+                  peak=peak, frac=ach / peak, executed_bf16_tflops=6.0 * ach, bf16_dense_peak=F16_MFMA_PEAK_TFLOPS,
+                  vs_fp32_mfma_peak=ach / FP32_MFMA_PEAK_TFLOPS)
     else:
         rl.update(kernel=f"gemm_nt_kernel (self_attn.in_proj, M={m} N={n} K={k}, fp32 MFMA 32x32x2)",
                   peak=FP32_MFMA_PEAK_TFLOPS, frac=ach / FP32_MFMA_PEAK_TFLOPS)
@@ -331,7 +338,7 @@ def main():
     ap.add_argument("--no-f32", action="store_true", help="skip the exact-fp32 engine's leg")
     ap.add_argument("--graph", action="store_true", help="replay each denoising step as a hipGraph")
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch of the config (exploration)")
-    ap.add_argument("--precision", default=None, choices=["f32", "f16x3"],
+    ap.add_argument("--precision", default=None, choices=["f32", "f16x3", "bf16x6"],
                     help="encoder GEMM arithmetic (include/condmdi.h CMDI_PREC_*); default: the library's")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -446,8 +453,10 @@ def main():
         "metric": "diffusion denoising steps/sec", "value": steps_per_s, "unit": "steps/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-        "dtype": ("f32 (products as 3 split-f16 MFMAs on 22-bit operand pairs, fp32 accumulate; same "
-                  "parity tolerances as exact fp32)") if split else "f32",
+        "dtype": {"f16x3": "f32 (products as 3 split-f16 MFMAs on 22-bit operand pairs, fp32 accumulate)",
+                  "bf16x6": "f32 (operands carried exactly as three bf16 planes, 6 bf16 MFMA partial products per fp32 "
+                            "product, fp32 accumulate)",
+                  "f32": "f32 (v_mfma_f32_32x32x2_f32)"}[eng.precision],
         "precision_mode": eng.precision, "hip_graph": bool(args.graph),
         "data": "synthetic (random-init MDM weights, z-scored N(0,1) motions, fake CLIP embeddings)",
         "config": {"workload": cfg["desc"], "batch_per_gpu": B, "global_batch": global_batch,

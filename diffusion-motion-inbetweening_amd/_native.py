@@ -20,10 +20,11 @@ if __import__("os").environ.get("CMDI_PROBES_LIB") == "1":   # tools/ only: the 
 
 CMDI_MEAN_START_X, CMDI_MEAN_EPSILON = 0, 1
 CMDI_SAMPLER_DDPM, CMDI_SAMPLER_DDIM = 0, 1
-CMDI_PREC_DEFAULT, CMDI_PREC_F32, CMDI_PREC_F16X3 = 0, 1, 2
+CMDI_PREC_DEFAULT, CMDI_PREC_F32, CMDI_PREC_F16X3, CMDI_PREC_BF16X6 = 0, 1, 2, 3
 CMDI_ARCH_TRANS_ENC, CMDI_ARCH_UNET = 0, 1
 PRECISIONS = {None: CMDI_PREC_DEFAULT, "default": CMDI_PREC_DEFAULT, "f32": CMDI_PREC_F32,
-              "f16x3": CMDI_PREC_F16X3}
+              "f16x3": CMDI_PREC_F16X3, "bf16x6": CMDI_PREC_BF16X6}
+PRECISION_NAMES = {CMDI_PREC_F32: "f32", CMDI_PREC_F16X3: "f16x3", CMDI_PREC_BF16X6: "bf16x6"}
 
 
 class NativeError(RuntimeError):
@@ -84,6 +85,8 @@ SIGNATURES = {
     "cmdi_range_status": (C.c_int, [_VP, C.POINTER(_I32), _VP]),
     "cmdi_split_f16": (C.c_int, [_VP, _VP, _I64, _I32, _VP]),
     "cmdi_gemm_h3": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _VP]),
+    "cmdi_pack_x6": (C.c_int, [_VP, _VP, _I64, _I32, _VP]),
+    "cmdi_gemm_x6": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _VP]),
     "cmdi_philox4x32_10": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "cmdi_workspace_bytes": (_I64, [_VP]),
     "cmdi_pipeline_parts": (C.c_int, [_VP]),

@@ -26,6 +26,7 @@ UNITS = {
     "api.hip": [],
     "gemm_f32.hip": [],
     "gemm_h3.hip": [],
+    "gemm_x6.hip": [],
     "attention_f32.hip": [],
     "attention_h3.hip": [],
     "attention_bwd_f32.hip": [],

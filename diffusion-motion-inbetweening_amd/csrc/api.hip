@@ -28,6 +28,10 @@ int fail(int code, const std::string& msg) {
             return fail(CMDI_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));   \
     } while (0)
 
+// Library default of cmdi_model_desc.precision = CMDI_PREC_DEFAULT (the measured 1000-step drift of the
+// 22-bit f16x3 mode exceeds the exact-fp32 engine's, so it is opt-in; DESIGN.md section 4 has the table)
+constexpr int kDefaultPrecision = CMDI_PREC_F32;
+
 struct LayerW {
     float *in_w = nullptr, *in_b = nullptr, *out_w = nullptr, *out_b = nullptr;
     float *l1_w = nullptr, *l1_b = nullptr, *l2_w = nullptr, *l2_b = nullptr;
@@ -37,6 +41,9 @@ struct LayerW {
     // split-f16 copies (hi | lo*2^11 rows, gemm_h3.hpp) for the f16-pipe forward GEMMs
     _Float16 *in_ws = nullptr, *out_ws = nullptr, *l1_ws = nullptr, *l2_ws = nullptr;
     _Float16 *in_wTs = nullptr, *out_wTs = nullptr, *l1_wTs = nullptr, *l2_wTs = nullptr;  // want_grad
+    // bf16x6: three-plane bf16 copies (gemm_x6.hpp) of the forward weights and, want_grad, of their transposes
+    void *in_wx = nullptr, *out_wx = nullptr, *l1_wx = nullptr, *l2_wx = nullptr;
+    void *in_wTx = nullptr, *out_wTx = nullptr, *l1_wTx = nullptr, *l2_wTx = nullptr;
 };
 struct LayerStash {
     float *qkv = nullptr, *attn = nullptr, *row_stats = nullptr;
@@ -110,6 +117,7 @@ struct cmdi_engine {
     // motion-layout epilogues in gemm_h3.hpp); CMDI_IO_H3=0 keeps them on the fp32 MFMA kernels
     int io_h3 = 0;
     _Float16 *w_in_s = nullptr, *w_out_s = nullptr, *xS = nullptr;
+    int x6_variant = 1;   // K-loop schedule of the bf16x6 GEMM (CMDI_X6_VAR)
     int gemm_tile = 0;
     int tile_inproj = 0, tile_proj = 0, tile_ffn1 = 0, tile_ffn2 = 0;  // per-GEMM overrides (0 = auto)
 
@@ -180,6 +188,17 @@ GemmParams gp(const float* A, const float* W, const float* bias, float* C, int M
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc;
     p.out_scale = 1.0f;
     return p;
+}
+
+// fp32-engine GEMM: on the bf16 pipe with exact three-plane operands when the packed weight is given (CMDI_PREC_BF16X6),
+// else the fp32 MFMA kernel
+hipError_t gemm_any(const cmdi_engine* e, GemmKind kind, GemmParams p, const void* wx, int tile, hipStream_t s) {
+    if (wx) {
+        p.Wx = wx;
+        if (gemm_x6_supports(kind, p)) return launch_gemm_x6(kind, p, s, e->x6_variant);
+        p.Wx = nullptr;
+    }
+    return launch_gemm(kind, p, tile, s);
 }
 
 // ---- encoder layers over sequences [seq0, seq0 + nseq) on stream s -----------------------------
@@ -286,8 +305,8 @@ int run_layers(cmdi_engine* e, int seq0, int nseq, bool keep, bool prof, hipStre
             }
             HIPCHK(hipEventRecord(e->ev_pool[e->ev_used], s));
         }
-        HIPCHK(launch_gemm(GK_PLAIN, gp(tokA, w.in_w, w.in_b, qkv, M, 3 * d, d, d, d, 3 * d),
-                           e->tile_inproj, s));
+        HIPCHK(gemm_any(e, GK_PLAIN, gp(tokA, w.in_w, w.in_b, qkv, M, 3 * d, d, d, d, 3 * d), w.in_wx,
+                        e->tile_inproj, s));
         if (prof) {
             HIPCHK(hipEventRecord(e->ev_pool[e->ev_used + 1], s));
             e->ev_used += 2;
@@ -297,19 +316,19 @@ int run_layers(cmdi_engine* e, int seq0, int nseq, bool keep, bool prof, hipStre
         {
             GemmParams p = gp(attn, w.out_w, w.out_b, pre1, M, d, d, d, d, d);
             p.R = tokA;
-            HIPCHK(launch_gemm(GK_RESID, p, e->tile_proj, s));
+            HIPCHK(gemm_any(e, GK_RESID, p, w.out_wx, e->tile_proj, s));
         }
         HIPCHK(launch_layernorm(pre1, w.n1_g, w.n1_b, bufH, nullptr, nullptr, keep ? st->stats1 + r0 * 2 : nullptr, M, d, s));
         // feed-forward block: x = norm2(x + linear2(gelu(linear1(x))))
         {
             GemmParams p = gp(bufH, w.l1_w, w.l1_b, ffn, M, f, d, d, d, f);
             p.aux = keep ? st->aux + r0 * f : nullptr;
-            HIPCHK(launch_gemm(GK_GELU, p, e->tile_ffn1, s));
+            HIPCHK(gemm_any(e, GK_GELU, p, w.l1_wx, e->tile_ffn1, s));
         }
         {
             GemmParams p = gp(ffn, w.l2_w, w.l2_b, pre2, M, d, f, f, f, d);
             p.R = bufH;
-            HIPCHK(launch_gemm(GK_RESID, p, e->tile_ffn2, s));
+            HIPCHK(gemm_any(e, GK_RESID, p, w.l2_wx, e->tile_ffn2, s));
         }
         HIPCHK(launch_layernorm(pre2, w.n2_g, w.n2_b, tokA, nullptr, nullptr, keep ? st->stats2 + r0 * 2 : nullptr, M, d, s));
     }
@@ -492,18 +511,18 @@ int run_layers_bwd(cmdi_engine* e, int seq0, int nseq, hipStream_t s) {
         {
             GemmParams p = gp(dB, w.l2_wT, nullptr, dffn, M, f, d, d, d, f);
             p.aux = st.aux + r0 * f;
-            HIPCHK(launch_gemm(GK_GELUGRAD, p, tile, s));
+            HIPCHK(gemm_any(e, GK_GELUGRAD, p, w.l2_wTx, tile, s));
         }
         // linear1 + residual: dH = dffn · W1 + dB
         {
             GemmParams p = gp(dffn, w.l1_wT, nullptr, dH, M, d, f, f, f, d);
             p.R = dB;
-            HIPCHK(launch_gemm(GK_ACCUM, p, tile, s));
+            HIPCHK(gemm_any(e, GK_ACCUM, p, w.l1_wTx, tile, s));
         }
         // norm1
         HIPCHK(launch_layernorm_bwd(st.pre1 + r0 * d, st.stats1 + r0 * 2, w.n1_g, dH, dB, nullptr, M, d, s));
         // out_proj: d attn = dB · Wo   (no bias, no residual) -> reuse dH as d attn
-        HIPCHK(launch_gemm(GK_PLAIN, gp(dB, w.out_wT, nullptr, dH, M, d, d, d, d, d), tile, s));
+        HIPCHK(gemm_any(e, GK_PLAIN, gp(dB, w.out_wT, nullptr, dH, M, d, d, d, d, d), w.out_wTx, tile, s));
         // attention core
         HIPCHK(launch_attention_bwd(st.qkv + r0 * 3 * d, st.attn + r0 * d,
                                     st.row_stats + (size_t)seq0 * e->H * S * 2, dH, dqkv,
@@ -512,7 +531,7 @@ int run_layers_bwd(cmdi_engine* e, int seq0, int nseq, hipStream_t s) {
         {
             GemmParams p = gp(dqkv, w.in_wT, nullptr, dA, M, d, 3 * d, 3 * d, 3 * d, d);
             p.R = dB;
-            HIPCHK(launch_gemm(GK_ACCUM, p, tile, s));
+            HIPCHK(gemm_any(e, GK_ACCUM, p, w.in_wTx, tile, s));
         }
     }
     return CMDI_OK;
@@ -618,7 +637,7 @@ int build_coef(cmdi_engine* e, int sampler, int step, float eta, bool impute, bo
 extern "C" {
 
 const char* cmdi_last_error(void) { return g_err.c_str(); }
-const char* cmdi_version(void) { return "condmdi-hip 0.2 (gfx950, fp32 MFMA + split-f16 MFMA)"; }
+const char* cmdi_version(void) { return "condmdi-hip 0.3 (gfx950: fp32 MFMA | exact bf16x6 MFMA | split-f16 MFMA)"; }
 
 int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
     if (!desc || !out) return fail(CMDI_E_INVALID, "null argument");
@@ -716,10 +735,13 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
         int prec = desc->precision;
         if (prec == CMDI_PREC_DEFAULT) {
             const char* v = std::getenv("CMDI_PRECISION");
-            prec = (v && std::string(v) == "f32") ? CMDI_PREC_F32 : CMDI_PREC_F16X3;
+            const std::string name = v ? v : "";
+            prec = name == "f32" ? CMDI_PREC_F32 : name == "f16x3" ? CMDI_PREC_F16X3 : name == "bf16x6" ? CMDI_PREC_BF16X6
+                                                                                                        : kDefaultPrecision;
         }
-        if (prec != CMDI_PREC_F32 && prec != CMDI_PREC_F16X3)
-            return fail(CMDI_E_INVALID, "precision must be CMDI_PREC_DEFAULT, _F32 or _F16X3");
+        if (prec != CMDI_PREC_F32 && prec != CMDI_PREC_F16X3 && prec != CMDI_PREC_BF16X6)
+            return fail(CMDI_E_INVALID, "precision must be CMDI_PREC_DEFAULT, _F32, _F16X3 or _BF16X6");
+        e->x6_variant = env_int("CMDI_X6_VAR", 1);
         if (prec == CMDI_PREC_F16X3 && (desc->d_model % 32 != 0 || desc->d_ff % 32 != 0))
             return fail(CMDI_E_INVALID, "f16x3 precision needs d_model and d_ff multiples of 32");
         e->precision = prec;
@@ -764,6 +786,21 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
     ALLOC(e->range_flag, 1);
     ALLOC(e->gs_bits, 16);
     HIPCHK(hipMemset(e->range_flag, 0, sizeof(int)));
+    if (e->precision == CMDI_PREC_BF16X6) {
+        auto xalloc = [&](void** ptr, size_t elems) { return dalloc(e, ptr, elems * 6); };
+        for (LayerW& w : e->layers) {
+            int rc = xalloc(&w.in_wx, (size_t)3 * d * d); if (rc != CMDI_OK) return rc;
+            rc = xalloc(&w.out_wx, (size_t)d * d); if (rc != CMDI_OK) return rc;
+            rc = xalloc(&w.l1_wx, (size_t)f * d); if (rc != CMDI_OK) return rc;
+            rc = xalloc(&w.l2_wx, (size_t)d * f); if (rc != CMDI_OK) return rc;
+            if (desc->want_grad) {
+                rc = xalloc(&w.in_wTx, (size_t)3 * d * d); if (rc != CMDI_OK) return rc;
+                rc = xalloc(&w.out_wTx, (size_t)d * d); if (rc != CMDI_OK) return rc;
+                rc = xalloc(&w.l1_wTx, (size_t)f * d); if (rc != CMDI_OK) return rc;
+                rc = xalloc(&w.l2_wTx, (size_t)d * f); if (rc != CMDI_OK) return rc;
+            }
+        }
+    }
     if (e->precision == CMDI_PREC_F16X3) {
         for (LayerW& w : e->layers) {
             ALLOC(w.in_ws, (size_t)3 * d * d * 2); ALLOC(w.out_ws, (size_t)d * d * 2);
@@ -933,6 +970,20 @@ int cmdi_finalize_weights(cmdi_handle e, int32_t n_time_rows, cmdi_stream stream
                 HIPCHK(launch_split_f16(w.out_wT, w.out_wTs, d, d, d, e->range_flag, s));
                 HIPCHK(launch_split_f16(w.l1_wT, w.l1_wTs, d, f, f, e->range_flag, s));
                 HIPCHK(launch_split_f16(w.l2_wT, w.l2_wTs, f, d, d, e->range_flag, s));
+            }
+        }
+    }
+    if (e->precision == CMDI_PREC_BF16X6) {
+        for (LayerW& w : e->layers) {
+            HIPCHK(launch_pack_x6(w.in_w, w.in_wx, 3 * d, d, d, s));
+            HIPCHK(launch_pack_x6(w.out_w, w.out_wx, d, d, d, s));
+            HIPCHK(launch_pack_x6(w.l1_w, w.l1_wx, f, d, d, s));
+            HIPCHK(launch_pack_x6(w.l2_w, w.l2_wx, d, f, f, s));
+            if (e->desc.want_grad) {
+                HIPCHK(launch_pack_x6(w.in_wT, w.in_wTx, d, 3 * d, 3 * d, s));
+                HIPCHK(launch_pack_x6(w.out_wT, w.out_wTx, d, d, d, s));
+                HIPCHK(launch_pack_x6(w.l1_wT, w.l1_wTx, d, f, f, s));
+                HIPCHK(launch_pack_x6(w.l2_wT, w.l2_wTx, f, d, d, s));
             }
         }
     }
@@ -1517,6 +1568,33 @@ int cmdi_gemm_nt(const float* d_a, const float* d_w, const float* d_bias, const 
     p.R = d_resid;
     hipError_t err = launch_gemm(kind, p, tile, static_cast<hipStream_t>(stream));
     if (err != hipSuccess) return fail(CMDI_E_HIP, std::string("launch_gemm: ") + hipGetErrorString(err));
+    return CMDI_OK;
+}
+
+int cmdi_pack_x6(const float* d_src, void* d_dst, int64_t rows, int32_t cols, cmdi_stream stream) {
+    if (!d_src || !d_dst || rows < 1 || cols < 32 || cols % 32 != 0)
+        return fail(CMDI_E_INVALID, "bad argument (cols must be a positive multiple of 32)");
+    HIPCHK(launch_pack_x6(d_src, d_dst, rows, cols, cols, static_cast<hipStream_t>(stream)));
+    return CMDI_OK;
+}
+
+int cmdi_gemm_x6(const float* d_a, const void* d_w_packed, const float* d_bias, const float* d_resid, float* d_c,
+                 int32_t m, int32_t n, int32_t k, int32_t epi, int32_t variant, cmdi_stream stream) {
+    if (!d_a || !d_w_packed || !d_c) return fail(CMDI_E_INVALID, "null tensor");
+    GemmKind kind;
+    switch (epi) {
+        case 0: kind = GK_PLAIN; break;
+        case 1: kind = GK_GELU; break;
+        case 3: kind = GK_RESID; break;
+        default: return fail(CMDI_E_INVALID, "epi must be 0 (bias), 1 (bias+gelu) or 3 (bias+residual)");
+    }
+    if (kind == GK_RESID && !d_resid) return fail(CMDI_E_INVALID, "residual epilogue needs d_resid");
+    GemmParams p = gp(d_a, nullptr, d_bias, d_c, m, n, k, k, k, n);
+    p.R = d_resid;
+    p.Wx = d_w_packed;
+    if (!gemm_x6_supports(kind, p)) return fail(CMDI_E_INVALID, "bf16x6 GEMM needs K % 32 == 0 and N % 4 == 0");
+    hipError_t err = launch_gemm_x6(kind, p, static_cast<hipStream_t>(stream), variant);
+    if (err != hipSuccess) return fail(CMDI_E_HIP, std::string("launch_gemm_x6: ") + hipGetErrorString(err));
     return CMDI_OK;
 }
 

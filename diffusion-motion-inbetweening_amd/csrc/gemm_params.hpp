@@ -38,6 +38,7 @@ struct GemmParams {
     float out_scale;    // EPI_MOTION: multiplies v (1 for the forward pass)
     const unsigned* gs_bits;  // optional gradient scale (common.hpp grad_scale_from_bits):
                               // EPI_TOKOUT multiplies v by it, EPI_MOTION divides v by it
+    const void* Wx;           // bf16x6 path (gemm_x6.hpp): W pre-split into three bf16 planes [N][K/32][3][32], or null
 };
 
 // ---- split-f16 (fp32-equivalent) GEMM family, gemm_h3.hpp ----------------------------------------

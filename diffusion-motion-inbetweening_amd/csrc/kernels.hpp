@@ -23,6 +23,12 @@ enum GemmKind {
 hipError_t launch_gemm(GemmKind kind, const GemmParams& p, int tile, hipStream_t stream);
 int gemm_auto_tile(int M, int N);
 
+// ---- gemm_x6.hip (exact fp32 operands as three bf16 planes, six bf16 MFMA products per fp32 product) -----------
+// p.Wx = launch_pack_x6(W): [N][K/32][3][32] bf16; A stays plain fp32.  Kinds: PLAIN, GELU, RESID, ACCUM, GELUGRAD.
+bool gemm_x6_supports(GemmKind kind, const GemmParams& p);
+hipError_t launch_gemm_x6(GemmKind kind, const GemmParams& p, hipStream_t stream, int variant = 0);
+hipError_t launch_pack_x6(const float* src, void* dst, int64_t rows, int cols, int64_t ld, hipStream_t stream);
+
 // ---- gemm_h3.hip (split-f16, fp32-equivalent) ---------------------------------------------------
 // epi: H3Epi; tile: 0 auto, 1 = 128x128 (2 stages), 2 = 256x128 8 waves (3 stages), 3 = same (2 stages),
 // 4 = 128x64 (2), 5 = 128x64 (3), 6 = 64x128 (2), 7 = 128x128 8 waves (3), 8 = same (2), 9 = 128x256 8 waves (2),

@@ -53,9 +53,10 @@ class Engine:
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             N.check(self.lib.cmdi_create(C.byref(self.desc), C.byref(self._h)))
-        # "f32" (exact fp32 MFMA) or "f16x3" (fp32-equivalent split-f16 MFMA); None = library default
-        self.precision = {N.CMDI_PREC_F32: "f32", N.CMDI_PREC_F16X3: "f16x3"}.get(
-            self.lib.cmdi_precision(self._h), "f32") if (n_layers > 0 or arch == "unet") else "f32"
+        # "f32" (fp32 MFMA), "bf16x6" (exact three-plane bf16 operands, six MFMA products) or "f16x3" (22-bit split-f16
+        # operands, three products); None = library default
+        self.precision = N.PRECISION_NAMES.get(self.lib.cmdi_precision(self._h), "f32") \
+            if (n_layers > 0 or arch == "unet") else "f32"
         self.n_steps = 0
         self.batch = 0
         self.n_frames = 0
@@ -310,6 +311,34 @@ def gemm_nt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
     with torch.cuda.device(a.device):
         N.check(lib.cmdi_gemm_nt(N.ptr(a), N.ptr(w), N.ptr(bias), N.ptr(resid), N.ptr(c), m, n, k,
                                  int(epi), int(tile), N.current_stream(a.device)))
+    return c
+
+
+def pack_x6(w: torch.Tensor) -> torch.Tensor:
+    """fp32 [rows, cols] -> three bf16 planes [rows, cols/32, 3, 32] with w = p0 + p1 + p2 exactly (test hook)."""
+    lib = N.load()
+    assert w.is_cuda and w.dtype == torch.float32 and w.dim() == 2 and w.shape[1] % 32 == 0
+    w = w.contiguous()
+    out = torch.empty((w.shape[0], w.shape[1] // 32, 3, 32), dtype=torch.bfloat16, device=w.device)
+    with torch.cuda.device(w.device):
+        N.check(lib.cmdi_pack_x6(N.ptr(w), N.ptr(out), w.shape[0], w.shape[1], N.current_stream(w.device)))
+    return out
+
+
+def gemm_x6(a: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor] = None, epi: int = 0,
+            resid: Optional[torch.Tensor] = None, variant: int = 1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """C = epi(A[M,K] · Wᵀ + bias) on the bf16 pipe with exact three-plane operands (test / bench hook);
+    w_packed = pack_x6(W[N,K]); epi 0 = bias, 1 = bias + GELU, 3 = bias + residual."""
+    lib = N.load()
+    assert a.is_cuda and a.dtype == torch.float32 and w_packed.dtype == torch.bfloat16
+    a = a.contiguous()
+    m, k = a.shape
+    n = w_packed.shape[0]
+    assert w_packed.shape[1] * 32 == k
+    c = out if out is not None else torch.empty((m, n), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        N.check(lib.cmdi_gemm_x6(N.ptr(a), N.ptr(w_packed), N.ptr(bias), N.ptr(resid), N.ptr(c), m, n, k, int(epi),
+                                 int(variant), N.current_stream(a.device)))
     return c
 
 

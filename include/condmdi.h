@@ -45,8 +45,14 @@ enum {
  *                    a product is three v_mfma_f32_32x32x16_f16 accumulated in fp32 — error below
  *                    the fp32 accumulation roundoff of the same dot product, valid for |x| < 65504
  *                    (checked: CMDI_E_RANGE at cmdi_finalize_weights, cmdi_range_status after a run).
- *   CMDI_PREC_DEFAULT  F16X3 unless the environment variable CMDI_PRECISION=f32 is set. */
-enum { CMDI_PREC_DEFAULT = 0, CMDI_PREC_F32 = 1, CMDI_PREC_F16X3 = 2 };
+ *   CMDI_PREC_BF16X6 every fp32 operand is carried EXACTLY as three bf16 (8 + 8 + 8 = 24 significant bits, fp32's
+ *                    exponent range: no range limit) and a product is six v_mfma_f32_32x32x16_bf16 (the three dropped
+ *                    partial products are < 2^-26 of the product), fp32 accumulate, leading and small terms apart —
+ *                    fp32-class results without operand truncation at 2.65x the fp32-MFMA peak (csrc/gemm_x6.hpp).
+ *                    Attention, LayerNorm and the I/O projections run the CMDI_PREC_F32 kernels.
+ *   CMDI_PREC_DEFAULT  the environment variable CMDI_PRECISION = f32 | bf16x6 | f16x3 if set, else the library default
+ *                    (cmdi_precision reports it). */
+enum { CMDI_PREC_DEFAULT = 0, CMDI_PREC_F32 = 1, CMDI_PREC_F16X3 = 2, CMDI_PREC_BF16X6 = 3 };
 enum { CMDI_ARCH_TRANS_ENC = 0, CMDI_ARCH_UNET = 1 };
 
 /* Model geometry.  Replaces the keyword arguments of MDM.__init__ (model/mdm.py:11-36) that the
@@ -242,6 +248,13 @@ int cmdi_split_f16(const float* d_src, void* d_dst, int64_t rows, int32_t cols, 
 int cmdi_gemm_h3(const void* d_a_split, const void* d_w_split, const float* d_bias,
                  const float* d_resid, float* d_c, void* d_c_split, int32_t m, int32_t n, int32_t k,
                  int32_t epi, int32_t tile, cmdi_stream stream);
+/* bf16x6 GEMM alone (test / bench hooks).  cmdi_pack_x6: fp32 W [rows, cols] -> three bf16 planes
+ * [rows][cols/32][3][32] with W = p0 + p1 + p2 exactly (cols % 32 == 0; d_dst holds rows * cols * 6 bytes).
+ * cmdi_gemm_x6: C[M,N] = epi(A[M,K] · W[N,K]^T + bias[N]) with A plain fp32 and W packed; epi as cmdi_gemm_nt
+ * (0 bias, 1 bias + GELU, 3 bias + residual); variant 0 / 1 = the two K-loop schedules of gemm_x6.hpp. */
+int cmdi_pack_x6(const float* d_src, void* d_dst, int64_t rows, int32_t cols, cmdi_stream stream);
+int cmdi_gemm_x6(const float* d_a, const void* d_w_packed, const float* d_bias, const float* d_resid, float* d_c,
+                 int32_t m, int32_t n, int32_t k, int32_t epi, int32_t variant, cmdi_stream stream);
 /* Self-attention core alone (test / bench hook): d_qkv [n_seq*S, 3*H*128] -> d_out [n_seq*S, H*128]. */
 int cmdi_attention_fwd(const float* d_qkv, float* d_out, int32_t n_seq, int32_t seq_len,
                        int32_t n_heads, cmdi_stream stream);

@@ -31,7 +31,7 @@ def tt(a, dev=DEV):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
-PRECISIONS = ["f16x3", "f32"]
+PRECISIONS = ["f16x3", "f32", "bf16x6"]
 
 
 def make_model(case, cfg=None, layers=8, precision=None):
@@ -131,6 +131,49 @@ def test_gemm_h3(tile, shape):
     assert rel_l2(out.numpy(), torch.nn.functional.gelu(ref).numpy()) <= 2e-6
     out = eng.unsplit_f16(eng.gemm_h3(a_s, w_s, b.to(DEV), tile=tile, split_out=True)).cpu()
     assert rel_l2(out.numpy(), ref.numpy()) <= 2e-6
+
+
+# ---- bf16x6: exact three-plane bf16 operands, six MFMA products (fp32-class, no operand truncation) -----------------
+def test_pack_x6_is_exact():
+    """W = p0 + p1 + p2 EXACTLY for every finite binary32 (24 significant bits = three bf16 mantissas), over the whole
+    fp32 exponent range — no range limit, unlike the split-f16 format."""
+    eng = sub("engine")
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(129, 512, generator=g) * torch.pow(10.0, torch.rand(129, 512, generator=g) * 60 - 30)
+    x[0, :8] = torch.tensor([0.0, -0.0, 65504.0, -7e4, 3.4e38, 1e-30, 2.0 ** -14, 1.0])
+    planes = eng.pack_x6(x.to(DEV)).cpu()
+    assert planes.shape == (129, 16, 3, 32) and planes.dtype == torch.bfloat16
+    back = planes.double().sum(dim=2).reshape(129, 512)
+    assert torch.equal(back, x.double())
+    assert torch.equal(planes[:, :, 0].reshape(129, 512), x.bfloat16())   # leading plane = round-to-nearest bf16
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("shape", [(333, 512, 512), (197 * 4, 1536, 512), (1000, 512, 1024), (130, 256, 32),
+                                   (12608, 1536, 64), (12608, 1024, 512), (257 * 128 + 5, 512, 512)])
+def test_gemm_x6(variant, shape):
+    """Same inputs, float64 reference and 2e-6 bound as the fp32-MFMA kernels; the bf16x6 error must not exceed the
+    fp32-MFMA kernel's by more than 10 % (it carries all 24 bits of both operands)."""
+    eng = sub("engine")
+    m, n, k = shape
+    g = torch.Generator().manual_seed(m * 7 + n)
+    a = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g) * (torch.arange(n).float()[:, None] % 7 + 1)  # asymmetric
+    b = torch.randn(n, generator=g)
+    r = torch.randn(m, n, generator=g)
+    ref = (a.double() @ w.double().T + b.double())
+    wx = eng.pack_x6(w.to(DEV))
+    out = eng.gemm_x6(a.to(DEV), wx, b.to(DEV), variant=variant).cpu()
+    e_x6 = rel_l2(out.numpy(), ref.numpy())
+    e_f32 = rel_l2(eng.gemm_nt(a.to(DEV), w.to(DEV), b.to(DEV)).cpu().numpy(), ref.numpy())
+    assert e_x6 <= 2e-6 and e_x6 <= 1.1 * e_f32 + 1e-8, (e_x6, e_f32)
+    out = eng.gemm_x6(a.to(DEV), wx, b.to(DEV), epi=3, resid=r.to(DEV), variant=variant).cpu()
+    assert rel_l2(out.numpy(), (ref + r.double()).numpy()) <= 2e-6
+    out = eng.gemm_x6(a.to(DEV), wx, b.to(DEV), epi=1, variant=variant).cpu()
+    assert rel_l2(out.numpy(), torch.nn.functional.gelu(ref).numpy()) <= 2e-6
+    # no range limit: operands far outside the f16 range
+    big = eng.gemm_x6((a * 1e6).to(DEV), eng.pack_x6((w * 1e5).to(DEV)), None, variant=variant).cpu()
+    assert rel_l2(big.numpy(), (ref - b.double()).numpy() * 1e11) <= 2e-6
 
 
 @pytest.mark.parametrize("shape", [(333, 512), (12608, 1024), (64, 32)])
