@@ -18,6 +18,8 @@ Prints ONE JSON line on rank 0 (see the task contract) with these extra objects:
                 the gfx950 correction of MI355X_MICROARCH.md | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE)
   f32_exact     the same K steps on the exact-fp32 engine (CMDI_PREC_F32: v_mfma_f32_32x32x2_f32 products) with its own
                 roofline against the 157.3 TFLOP/s fp32-matrix peak (transformer configs, N=1)
+  bf16x6        the same on the CMDI_PREC_BF16X6 engine (exact three-plane bf16 operands, six bf16 MFMA products per
+                fp32 product: no operand truncation, no range limit)
   cpu_baseline  the reference's CPU path restated on torch CPU kernels (oracle/torch_cpu_port.py) on the
                 host cores, a bounded sample of the same workload (1 warm-up + 3 full CFG steps at B=32)
 """
@@ -481,19 +483,24 @@ def main():
     if world > 1:
         dist.barrier()
 
-    # the exact-fp32 engine on the same K steps (CMDI_PREC_F32): its own driver-timed number beside the default's
-    if rank == 0 and world == 1 and split and not is_unet and not args.no_f32 and args.precision is None:
-        e32, eng32, x32, loop32 = timed_run("f32")
-        f32 = {"value": K / e32, "unit": "steps/s", "ms_per_step": e32 / K * 1e3, "precision_mode": eng32.precision,
-               "dtype": "f32 (v_mfma_f32_32x32x2_f32: exact fp32 products)",
-               "step_tflops": flop_step / (e32 / K) / 1e12,
-               "step_frac_of_fp32_mfma_peak": flop_step / (e32 / K) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-               "max_abs_diff_vs_default": float((x32 - x).abs().max()),
-               "rel_l2_vs_default": float((x32 - x).norm() / x.norm())}
-        if not args.no_roofline:
-            pmc32 = pmc_counters(args.config, "f32", B) if want_pmc else {}
-            f32["roofline"] = roofline_from(eng32, loop32, False, False, pmc32)
-        out["f32_exact"] = f32
+    # the other two arithmetic modes on the same K steps, each with its own driver-timed number and roofline:
+    #   f32_exact  CMDI_PREC_F32: v_mfma_f32_32x32x2_f32 products
+    #   bf16x6     CMDI_PREC_BF16X6: exact three-plane bf16 operands, six MFMA products (what the f16-range guard of the
+    #              default mode falls back to)
+    if rank == 0 and world == 1 and not is_unet and not args.no_f32 and args.precision is None:
+        for key, prec in (("bf16x6", "bf16x6"), ("f32_exact", "f32")):
+            if prec == eng.precision:
+                continue
+            e2, eng2, x2, loop2 = timed_run(prec)
+            leg = {"value": K / e2, "unit": "steps/s", "ms_per_step": e2 / K * 1e3, "precision_mode": eng2.precision,
+                   "step_tflops": flop_step / (e2 / K) / 1e12,
+                   "step_frac_of_fp32_mfma_peak": flop_step / (e2 / K) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                   "max_abs_diff_vs_default": float((x2 - x).abs().max()),
+                   "rel_l2_vs_default": float((x2 - x).norm() / x.norm())}
+            if not args.no_roofline:
+                pmc2 = pmc_counters(args.config, prec, B) if (want_pmc and prec == "f32") else {}
+                leg["roofline"] = roofline_from(eng2, loop2, False, False, pmc2)
+            out[key] = leg
         model.native_precision = None
 
     if rank == 0 and world == 1 and not args.no_cpu and not (is_unet and cfg["edit"]):

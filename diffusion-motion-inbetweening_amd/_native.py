@@ -31,6 +31,14 @@ class NativeError(RuntimeError):
     """A libcondmdi_hip.so call returned a negative status."""
 
 
+class RangeError(NativeError):
+    """f16x3 only: a weight or an activation left the f16 range (|x| >= 65504).  The samplers answer by re-running the
+    chain on a bf16x6 engine (exact three-plane operands, fp32's exponent range) — never on a CPU."""
+
+
+CMDI_E_RANGE = -6
+
+
 class ModelDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n_layers", "d_model", "d_ff", "n_heads", "n_feats", "max_frames", "max_batch", "pe_rows",
@@ -119,7 +127,8 @@ def load() -> ctypes.CDLL:
 def check(rc: int) -> None:
     if rc != 0:
         msg = load().cmdi_last_error()
-        raise NativeError(f"libcondmdi_hip: error {rc}: {msg.decode() if msg else '?'}")
+        kind = RangeError if rc == CMDI_E_RANGE else NativeError
+        raise kind(f"libcondmdi_hip: error {rc}: {msg.decode() if msg else '?'}")
 
 
 def ptr(t) -> int:

@@ -46,6 +46,12 @@ constexpr float kLoInv = 1.0f / 2048.0f;
 __host__ __device__ __forceinline__ int split_pos(int k) { return ((k >> 5) << 6) + (k & 31); }
 
 __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
+    // x must be ONE rounded fp32 value for both lines below.  Without this barrier hipcc (-ffp-contract=fast) fuses a
+    // product that feeds x into the conversions — the residual was taken against RN16(exact a*b) (v_fma_mixlo_f16 +
+    // v_fma_mix_f32) while the stored hi was RN16(RN32(a*b)) (v_cvt_pk_f16_f32): whenever the two roundings part, hi and lo
+    // belong to different splits and the value is off by a whole f16 ulp.  Found in round 2 behind the GELU epilogue
+    // (rel-L2 1.65e-6 instead of 1.7e-7 on linear1, tools/x6_bench.py); every caller whose x is a product was exposed.
+    asm volatile("" : "+v"(x));
     hi = (_Float16)x;                         // round to nearest even
     lo = (_Float16)((x - (float)hi) * kLoScale);
 }

@@ -83,7 +83,7 @@ static hipError_t launch_x6_var(GemmKind kind, const GemmParams& p, hipStream_t 
 
 hipError_t launch_gemm_x6(GemmKind kind, const GemmParams& p, hipStream_t s, int variant) {
     if (!gemm_x6_supports(kind, p)) return hipErrorInvalidValue;
-    return variant == 1 ? launch_x6_var<1>(kind, p, s) : launch_x6_var<0>(kind, p, s);
+    return variant == 2 ? launch_x6_var<2>(kind, p, s) : variant == 1 ? launch_x6_var<1>(kind, p, s) : launch_x6_var<0>(kind, p, s);
 }
 
 }  // namespace cmdi

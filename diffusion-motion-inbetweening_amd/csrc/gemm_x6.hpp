@@ -38,6 +38,25 @@ __device__ __forceinline__ void split_bf16x3(float x, __bf16& b0, __bf16& b1, __
     b2 = (__bf16)r2;                      // at most 8 significant bits remain: exact
 }
 
+// the six partial products of one k-substep (16 columns) for one A fragment and TN W fragments; consecutive MFMAs
+// alternate between the column fragments
+template <int TN>
+__device__ __forceinline__ void x6_products(const bf16x8 (&a)[3], const bf16x8 (&w)[TN][3], f32x16 (&acc0)[TN],
+                                            f32x16 (&acc1)[TN]) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc0[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], w[j][0], acc0[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], w[j][1], acc1[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], w[j][0], acc1[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], w[j][1], acc1[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], w[j][2], acc1[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], w[j][0], acc1[j], 0, 0, 0);
+}
+
 struct X6Tile {
     static constexpr int BM = 128, BN = 128, BK = 32, WM = 4, WN = 2;
     static constexpr int NW = WM * WN, NT = 64 * NW;          // 8 waves, 32 x 64 outputs each
@@ -52,6 +71,11 @@ struct X6Tile {
 //        sched_group_barrier: the 9 fragment reads of k-substep 0 first, then one MFMA per remaining read, then the
 //        split arithmetic of the next K step (VALU), its LDS writes and the global loads of the step after it woven
 //        between the remaining MFMAs — the matrix pipe covers the staging work of the same wave.
+// VAR 2: the K step is rotated so that its ONE barrier sits in the middle of the MFMA stream: first half = the products of
+//        k-substep 0 (fragments read during the previous half) + this step's k-substep-1 reads + staging of step it+1;
+//        barrier; second half = the products of k-substep 1 + the k-substep-0 reads of step it+1 (from the stage the
+//        barrier just released) + the global loads of step it+2.  The matrix pipe has 12 MFMAs on either side of the
+//        barrier, so neither the LDS latency after it nor the arrival skew before it is exposed.
 template <int EPI, int VAR>
 __global__ __launch_bounds__(X6Tile::NT, 2) void gemm_x6_kernel(const GemmParams p) {
     using TC = X6Tile;
@@ -139,6 +163,16 @@ __global__ __launch_bounds__(X6Tile::NT, 2) void gemm_x6_kernel(const GemmParams
     const int frag_a = (wm * 32 + l31) * ROWB + hi * 16;                 // + plane * 64 + ks * 32
     const int frag_w = (BM + wn * (TN * 32) + l31) * ROWB + hi * 16;     // + j * 32 * ROWB + plane * 64 + ks * 32
 
+    bf16x8 f0a[3], f0w[TN][3];          // VAR 2: k-substep-0 fragments of the step about to be multiplied
+    if constexpr (VAR == 2) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            f0a[pl] = *reinterpret_cast<const bf16x8*>(lds + frag_a + pl * 64);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) f0w[j][pl] = *reinterpret_cast<const bf16x8*>(lds + frag_w + j * 32 * ROWB + pl * 64);
+        }
+    }
+
     int it = 0;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         int m0, n0;
@@ -149,6 +183,47 @@ __global__ __launch_bounds__(X6Tile::NT, 2) void gemm_x6_kernel(const GemmParams
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc0[j][r] = 0.f; acc1[j][r] = 0.f; }
 
+        if constexpr (VAR == 2) {
+            for (int kt = 0; kt < nk; ++kt, ++it) {
+                const char* st = lds + (it & 1) * STAGE;
+                const char* sn = lds + ((it + 1) & 1) * STAGE;
+                // ---- first half: products of k-substep 0 | reads of k-substep 1 | stage step it+1 -------------------
+                bf16x8 a1[3], w1[TN][3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    a1[pl] = *reinterpret_cast<const bf16x8*>(st + frag_a + pl * 64 + 32);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        w1[j][pl] = *reinterpret_cast<const bf16x8*>(st + frag_w + j * 32 * ROWB + pl * 64 + 32);
+                }
+                x6_products<TN>(f0a, f0w, acc0, acc1);
+                store_step((it + 1) & 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 3 + 3 * TN, 0);     // the 9 reads up front
+#pragma unroll
+                for (int q = 0; q < 6 * TN - 2; ++q) {                           // split arithmetic under the MFMAs
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x200, 6, 0);               // stage it+1 -> LDS
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __syncthreads();
+                // ---- second half: products of k-substep 1 | k-substep-0 reads of step it+1 | request step it+2 -----
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    f0a[pl] = *reinterpret_cast<const bf16x8*>(sn + frag_a + pl * 64);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        f0w[j][pl] = *reinterpret_cast<const bf16x8*>(sn + frag_w + j * 32 * ROWB + pl * 64);
+                }
+                load_step(ld_m0, ld_n0, ld_kt);
+                advance_load();
+                x6_products<TN>(a1, w1, acc0, acc1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 3 + 3 * TN, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 5, 0);               // global loads of step it+2
+                __builtin_amdgcn_sched_group_barrier(0x008, 6 * TN - 2, 0);
+            }
+        } else
         for (int kt = 0; kt < nk; ++kt, ++it) {
             // step it+1 (in registers since the previous iteration) goes to the other stage, step it+2 is requested
             if constexpr (VAR == 0) {
@@ -167,28 +242,7 @@ __global__ __launch_bounds__(X6Tile::NT, 2) void gemm_x6_kernel(const GemmParams
                         w[ks][j][pl] = *reinterpret_cast<const bf16x8*>(st + frag_w + j * 32 * ROWB + pl * 64 + ks * 32);
                 }
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                // product order: consecutive MFMAs alternate between the column fragments, so two MFMAs on the same
-                // accumulator are never adjacent
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc0[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][0], w[ks][j][0], acc0[j], 0, 0, 0);
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][0], w[ks][j][1], acc1[j], 0, 0, 0);
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][1], w[ks][j][0], acc1[j], 0, 0, 0);
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][1], w[ks][j][1], acc1[j], 0, 0, 0);
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][0], w[ks][j][2], acc1[j], 0, 0, 0);
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][2], w[ks][j][0], acc1[j], 0, 0, 0);
-            }
+            for (int ks = 0; ks < 2; ++ks) x6_products<TN>(a[ks], w[ks], acc0, acc1);
             if constexpr (VAR == 1) {
                 store_step((it + 1) & 1);
                 load_step(ld_m0, ld_n0, ld_kt);

@@ -462,6 +462,22 @@ class GaussianDiffusion:
 
     def _loop(self, sampler, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs,
               device, progress, eta, skip_timesteps, init_image, randomize_class, dump_steps):
+        # The default precision (f16x3) is range-limited; if an activation leaves the f16 range the chain is re-run —
+        # same torch RNG state, hence same engine seed and noise — on a bf16x6 engine (exact operands, fp32 range).
+        mdm, _ = _unwrap_model(model)
+        rng_state = torch.random.get_rng_state()
+        try:
+            return self._loop_once(sampler, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs,
+                                   device, progress, eta, skip_timesteps, init_image, randomize_class, dump_steps)
+        except N.RangeError:
+            if mdm is None or not hasattr(mdm, "range_fallback") or not mdm.range_fallback():
+                raise
+            torch.random.set_rng_state(rng_state)
+            return self._loop_once(sampler, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs,
+                                   device, progress, eta, skip_timesteps, init_image, randomize_class, dump_steps)
+
+    def _loop_once(self, sampler, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs,
+                   device, progress, eta, skip_timesteps, init_image, randomize_class, dump_steps):
         final, dump = None, []
         gen = self._sample_loop_progressive(
             sampler, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device,

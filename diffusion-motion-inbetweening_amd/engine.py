@@ -102,9 +102,9 @@ class Engine:
             raise IndexError("a timestep outside the time-embedding table reached the denoiser "
                              "(the reference raises at pe[timesteps], model/mdm.py:352)")
         if flag.value & 1 and self.precision == "f16x3":
-            raise N.NativeError(
+            raise N.RangeError(
                 "an activation left the f16 range (|x| >= 65504 or non-finite) in the split-f16 GEMM "
-                "path: results are invalid; re-run with precision='f32' (CMDI_PRECISION=f32)")
+                "path: results are invalid; re-run with precision='bf16x6' (CMDI_PRECISION=bf16x6)")
 
     def set_graph(self, on: bool):
         """hipGraph replay of whole denoising steps in sample_loop (bitwise identical results)."""

@@ -211,6 +211,8 @@ class MDM(nn.Module):
         n_time_rows = pe_rows
         eng = self._engine
         precision = getattr(self, "native_precision", None)  # None = library default (f16x3)
+        if precision is None and getattr(self, "_range_fallback", False):
+            precision = "bf16x6"   # the weights or an earlier run left the f16 range: stay on the unrestricted mode
         need_new = (eng is None or eng.device != device or eng.max_batch < max_batch
                     or eng.max_frames < max_frames or (want_grad and not eng.want_grad)
                     or (precision is not None and eng.precision != precision)
@@ -221,12 +223,27 @@ class MDM(nn.Module):
                 max_frames = max(max_frames, eng.max_frames)
                 want_grad = want_grad or eng.want_grad
                 eng.close()
-            eng = Engine(n_layers=self.num_layers, d_model=self.latent_dim, d_ff=self.ff_size,
-                         n_heads=self.num_heads, n_feats=self.input_feats, max_frames=max_frames,
-                         max_batch=max_batch, pe_rows=pe_rows, text_cond='text' in self.cond_mode,
-                         want_grad=want_grad, precision=precision, device=device)
             sd = {k: v for k, v in self.state_dict().items() if not k.startswith('clip_model.')}
-            eng.load_state_dict(sd, n_time_rows=n_time_rows)
+
+            def build(prec):
+                e = Engine(n_layers=self.num_layers, d_model=self.latent_dim, d_ff=self.ff_size,
+                           n_heads=self.num_heads, n_feats=self.input_feats, max_frames=max_frames,
+                           max_batch=max_batch, pe_rows=pe_rows, text_cond='text' in self.cond_mode,
+                           want_grad=want_grad, precision=prec, device=device)
+                try:
+                    e.load_state_dict(sd, n_time_rows=n_time_rows)
+                except Exception:
+                    e.close()
+                    raise
+                return e
+
+            try:
+                eng = build(precision)
+            except N.RangeError:
+                if precision is not None:
+                    raise              # the caller asked for f16x3 explicitly: report, do not switch silently
+                self._range_fallback = True
+                eng = build("bf16x6")  # a weight beyond the f16 range: the default falls back to exact bf16 planes
             self._engine = eng
             self._engine_key = self._weights_key(n_time_rows)
         return eng
@@ -239,6 +256,15 @@ class MDM(nn.Module):
         if self._engine is not None:
             self._engine.close()
         self._engine, self._engine_key = None, None
+
+    def range_fallback(self) -> bool:
+        """After a RangeError of the default (f16x3) engine: switch this module to bf16x6 for good and report whether a
+        retry makes sense (False if the caller pinned a precision or the fallback is already active)."""
+        if getattr(self, "native_precision", None) is not None or getattr(self, "_range_fallback", False):
+            return False
+        self._range_fallback = True
+        self.invalidate_engine()
+        return True
 
     def _forward_native(self, x, timesteps, y, cfg):
         if y is None:

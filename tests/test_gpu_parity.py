@@ -140,7 +140,7 @@ def test_pack_x6_is_exact():
     eng = sub("engine")
     g = torch.Generator().manual_seed(4)
     x = torch.randn(129, 512, generator=g) * torch.pow(10.0, torch.rand(129, 512, generator=g) * 60 - 30)
-    x[0, :8] = torch.tensor([0.0, -0.0, 65504.0, -7e4, 3.4e38, 1e-30, 2.0 ** -14, 1.0])
+    x[0, :8] = torch.tensor([0.0, -0.0, 65504.0, -7e4, 3.38e38, 1e-30, 2.0 ** -14, 1.0])   # bf16 max = 3.3895e38
     planes = eng.pack_x6(x.to(DEV)).cpu()
     assert planes.shape == (129, 16, 3, 32) and planes.dtype == torch.bfloat16
     back = planes.double().sum(dim=2).reshape(129, 512)
@@ -148,7 +148,7 @@ def test_pack_x6_is_exact():
     assert torch.equal(planes[:, :, 0].reshape(129, 512), x.bfloat16())   # leading plane = round-to-nearest bf16
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("shape", [(333, 512, 512), (197 * 4, 1536, 512), (1000, 512, 1024), (130, 256, 32),
                                    (12608, 1536, 64), (12608, 1024, 512), (257 * 128 + 5, 512, 512)])
 def test_gemm_x6(variant, shape):
@@ -195,18 +195,59 @@ def test_fused_layernorm_gemm(shape):
 
 
 def test_f16x3_range_guard():
-    """|x| >= 65504 cannot be split: weights are refused at finalize, activations raise after the run."""
+    """|x| >= 65504 cannot be split: an engine PINNED to f16x3 refuses such weights at finalize; the default precision
+    falls back to bf16x6 (exact three-plane operands, fp32's exponent range) and matches the oracle."""
     N = sub("_native")
     case = dict(text=False, weight_seed=5)
-    model, _ = make_model(case, layers=1, precision="f16x3")
+    model, sd = make_model(case, layers=1, precision="f16x3")
     with torch.no_grad():
         model.seqTransEncoder.layers[0].linear1.weight[3, 7] = 7e4
-    with pytest.raises(N.NativeError, match="f16 range"):
+    with pytest.raises(N.RangeError, match="f16 range"):
         model.engine(torch.device(DEV), max_batch=2, max_frames=20)
-    model.native_precision = "f32"   # the exact-fp32 mode takes the same weights
-    model.invalidate_engine()
-    out = model(torch.randn(2, 263, 1, 20, device=DEV), torch.tensor([5, 9], device=DEV), y={})
-    assert torch.isfinite(out).all()
+    x, t = torch.randn(2, 263, 1, 20, device=DEV), torch.tensor([5, 9], device=DEV)
+    sd2 = dict(sd)
+    sd2["seqTransEncoder.layers.0.linear1.weight"] = sd["seqTransEncoder.layers.0.linear1.weight"].copy()
+    sd2["seqTransEncoder.layers.0.linear1.weight"][3, 7] = 7e4
+    want = MDMOracle(sd2).forward(x.cpu().numpy(), t.cpu().numpy())
+    for precision in (None, "bf16x6", "f32"):     # None = library default: f16x3, falling back to bf16x6 here
+        model.native_precision = precision
+        model.invalidate_engine()
+        out = model(x, t, y={})
+        assert model._engine.precision == (precision or "bf16x6")
+        assert rel_l2(out.cpu().numpy(), want) <= 2e-5, (precision, rel_l2(out.cpu().numpy(), want))
+
+
+@pytest.mark.parametrize("scale,expect", [(5.0e3, "f16x3"), (4.0e4, "bf16x6")])
+def test_real_scale_activations_and_range_fallback(scale, expect):
+    """'real-scale weights: a range test with LayerNorm-free FFN pre-activations near 1e4'.  linear1 is scaled
+    so that the FFN pre-activations (and the GELU outputs the f16x3 path has to split) reach ~1e4: still inside the f16
+    range -> the default engine stays f16x3 and matches the oracle; scaled 20x further they pass 65504, the device flag
+    fires and p_sample_loop re-runs the SAME chain (same seed) on a bf16x6 engine — result again within tolerance."""
+    case = dict(text=False, weight_seed=6)
+    model, sd = make_model(case, layers=2)
+    key = "seqTransEncoder.layers.0.linear1.weight"
+    sd = dict(sd)
+    sd[key] = sd[key] * np.float32(scale)
+    sub("utils.model_util").load_model_wo_clip(model, weights.to_torch(sd))
+    model.to(DEV).eval()
+    diffusion = make_diffusion([3])
+    B, T = 2, 40
+    rng = np.random.default_rng(8)
+    shape = (B, 263, 1, T)
+    x_T = rng.standard_normal(shape).astype(np.float32)
+    noise = rng.standard_normal((3,) + shape).astype(np.float32)
+    y = {"mask": torch.ones(B, 1, 1, T, dtype=torch.bool, device=DEV), "lengths": torch.full((B,), T)}
+    diffusion.injected_noise = tt(noise)
+    out = diffusion.p_sample_loop(model, shape, noise=tt(x_T), clip_denoised=False, model_kwargs={"y": y}).cpu().numpy()
+    assert model._engine.precision == expect
+    oracle = MDMOracle(sd)
+    keep = []
+    oracle.forward(x_T, np.full(B, 999), keep=keep)
+    pre = np.abs(keep[0]["u"]).max()          # linear1 output of layer 0 = the FFN pre-activation
+    assert (pre < 65504.0) == (expect == "f16x3") and pre > 5e3, pre
+    sch = do.Schedule(do.named_betas("cosine", 1000), do.space_timesteps(1000, [3]))
+    want = do.sample_loop(sch, oracle, x_T, noise)
+    assert rel_l2(out, want) <= 1e-4, rel_l2(out, want)
 
 
 # ---- attention -----------------------------------------------------------------------------------

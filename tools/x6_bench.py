@@ -51,16 +51,24 @@ def main():
         row = [f"{name:14s} M={m:6d} N={n:5d} K={k:5d}"]
         out32 = eng.gemm_nt(a, w, b, epi=epi, resid=r)
         row.append(f"err f32 {rel(out32, ref):.2e}")
-        for var in (0, 1):
+        for var in (0, 1, 2):
             out = eng.gemm_x6(a, wx, b, epi=epi, resid=r, variant=var)
             row.append(f"x6v{var} {rel(out, ref):.2e}")
         a_s, w_s = eng.split_f16(a), eng.split_f16(w)
         o3 = eng.gemm_h3(a_s, w_s, b, epi=epi, resid=r)
         o3 = eng.unsplit_f16(o3) if epi == 1 else o3
         row.append(f"h3 {rel(o3, ref):.2e}")
+        if epi == 1:   # where does the f16x3 GELU + split output lose accuracy?
+            pre = eng.gemm_h3(a_s, w_s, b, epi=0)
+            pre_ref = a.double() @ w.double().T + b.double()
+            gpre = torch.nn.functional.gelu(pre)
+            d = (o3.double() - ref).abs()
+            i = int(d.argmax())
+            row.append(f"[h3 pre {rel(pre, pre_ref):.2e} torch-gelu(h3 pre) {rel(gpre, ref):.2e} unsplit-vs-that {rel(o3, gpre.double()):.2e} "
+                       f"worst |d|={float(d.flatten()[i]):.3e} at ref={float(ref.flatten()[i]):.4e} pre={float(pre_ref.flatten()[i]):.4e} got={float(o3.flatten()[i]):.6e}]")
         t32 = timeit(lambda: eng.gemm_nt(a, w, b, epi=epi, resid=r, out=c), iters=iters)
         row.append(f"| us f32 {t32 * 1e6:7.1f}")
-        for var in (0, 1):
+        for var in (0, 1, 2):
             t = timeit(lambda: eng.gemm_x6(a, wx, b, epi=epi, resid=r, variant=var, out=c), iters=iters)
             row.append(f"x6v{var} {t * 1e6:7.1f} ({2.0 * m * n * k / t / 1e12:5.1f} TF)")
         cs = torch.empty(m, 2 * n, device=dev, dtype=torch.float16)
