@@ -9,8 +9,13 @@ on the host, cast to fp32 exactly like the reference's ``_extract_into_tensor`` 
 every denoising step (denoiser + classifier-free combine + imputation / reconstruction guidance +
 posterior update + noise) runs inside libcondmdi_hip.so on the model's HIP device.
 
-Out of scope here (reference-only): training losses / VLB (:1805-2212), PLMS (:1589-1803) and the
-GMD ``p_sample_with_grad`` / ``cond_fn`` branches (:715-1120).
+``cond_fn`` guidance (the GMD legacy the reference keeps: ``p_sample_with_grad`` :715-800 /
+``condition_mean_with_grad`` :579-603, ``ddim_sample_with_grad`` / ``condition_score_with_grad`` :636-660,1358-1416) is
+served too: the denoiser and its input-VJP stay native (torch.autograd reaches them through ``_NativeDenoise``), only the
+few elementwise lines that combine the caller's gradient with the posterior run as torch ops on the device.
+
+Out of scope here (reference-only): training losses / VLB (:1805-2212), PLMS (:1589-1803) and the GMD post-sampling
+imputation of ``p_sample_with_grad`` (:800-1105: needs the GMD data transforms).
 """
 from __future__ import annotations
 
@@ -279,10 +284,7 @@ class GaussianDiffusion:
     # ---- the loop -------------------------------------------------------------------------------
     def _sample_loop_progressive(self, sampler, model, shape, noise, clip_denoised, denoised_fn,
                                  cond_fn, model_kwargs, device, progress, eta, skip_timesteps,
-                                 init_image, randomize_class, fast):
-        if cond_fn is not None:
-            raise NotImplementedError("cond_fn guidance (GMD p_sample_with_grad) is out of scope "
-                                      "for the MI355X sampling engine")
+                                 init_image, randomize_class, fast, cond_fn_with_grad=False):
         if randomize_class:
             raise NotImplementedError("randomize_class is not supported")
         if model_kwargs is None or 'y' not in model_kwargs:
@@ -300,7 +302,10 @@ class GaussianDiffusion:
         mdm, cfg = _unwrap_model(model)
 
         use_recon = bool(y.get('reconstruction_guidance', False))
-        eng = self._engine_for(model, device, B, J * F, T, want_grad=use_recon and mdm is not None,
+        # (cond_fn differentiates through the denoiser: the engine needs its activation stash from the start, or the first
+        # guided model call would rebuild it)
+        eng = self._engine_for(model, device, B, J * F, T,
+                               want_grad=(use_recon or cond_fn is not None) and mdm is not None,
                                clip_denoised=clip_denoised)
         cond = self._condition_from_kwargs(y, mdm, cfg, B, J * F, T, device)
         _add_observations(cond, mdm, model_kwargs, B, J * F, T)
@@ -324,6 +329,22 @@ class GaussianDiffusion:
             img = eng.q_sample(init_image, img, indices[0])
 
         sampler_id = N.CMDI_SAMPLER_DDIM if sampler == "ddim" else N.CMDI_SAMPLER_DDPM
+        if cond_fn is not None:
+            # p_sample asserts cond_fn is None (:685): the ancestral loop honours it only through p_sample_with_grad, i.e.
+            # with cond_fn_with_grad=True (or the 'gmd' key, :1280-1282); the DDIM loop always takes the with-grad form (:1572)
+            if sampler == "ddpm" and not (cond_fn_with_grad or 'gmd' in y):
+                raise AssertionError("only support the case where cond_fn is None")
+            if progress:
+                from tqdm.auto import tqdm
+                indices = tqdm(indices)
+            for i in indices:
+                nz = draws.next() if draws.active else eng.randn(shape, seed=seed, first_sample=first, step=i)
+                out = self._guided_step(sampler, model, img, i, cond_fn, model_kwargs, eta, nz)
+                img = out["sample"]
+                yield out
+            if mdm is not None and mdm._engine is not None:
+                mdm._engine.check_range()
+            return
         if mdm is not None and fast and not progress:
             # whole loop in one native call, nothing materialised per step
             stream = draws.take(len(indices)) if draws.active else None
@@ -347,6 +368,57 @@ class GaussianDiffusion:
             yield {"sample": img.clone(), "pred_xstart": pred}
         if mdm is not None:
             eng.check_range()
+
+    def _guided_step(self, sampler, model, img, i, cond_fn, model_kwargs, eta, noise):
+        """One step of p_sample_with_grad (:715-800, without its GMD post-imputation) or ddim_sample_with_grad
+        (:1358-1416) with a caller-supplied cond_fn(x, t, p_mean_var, **model_kwargs) -> gradient.  The model call
+        (and, through torch.autograd inside cond_fn, its input-VJP) is native; the lines below restate the reference's
+        elementwise fp32 arithmetic in its evaluation order."""
+        y = model_kwargs['y']
+        if editing_util.uses_imputation(y) or editing_util.uses_reconstruction_guidance(y):
+            raise NotImplementedError("cond_fn together with imputation / reconstruction guidance is not supported")
+        if 'inpainting_mask' in y and 'inpainted_motion' in y:
+            # the reference would run the GMD post-sampling imputation here (:800-1105), which needs data_transform_fn
+            raise NotImplementedError("GMD post-sampling imputation (inpainting_mask with cond_fn) is reference-only")
+        if self.model_mean_type != ModelMeanType.START_X:
+            raise NotImplementedError("cond_fn guidance is implemented for START_X models")
+        dev, B = img.device, img.shape[0]
+        t = torch.full((B,), i, device=dev, dtype=torch.long)
+        t_model = torch.as_tensor(self._timestep_map(), device=dev, dtype=torch.long)[t]
+        if self.rescale_timesteps:
+            t_model = t_model.float() * (1000.0 / self._original_num_steps())
+        f32 = lambda table: torch.tensor(float(np.float32(np.asarray(table, dtype=np.float64)[i])), device=dev)
+        nonzero = 0.0 if i == 0 else 1.0
+        with torch.enable_grad():
+            x = img.detach().requires_grad_()
+            model_output = model(x, t_model, **model_kwargs)
+            if isinstance(model_output, tuple):
+                model_output = model_output[0]
+            pred_xstart = model_output                                   # START_X, clip_denoised is a no-op (:489-492)
+            mean = f32(self.posterior_mean_coef1) * pred_xstart + f32(self.posterior_mean_coef2) * x
+            variance = f32(np.exp(self._model_log_variance()))
+            log_variance = f32(self._model_log_variance())
+            p_mean_var = {"mean": mean, "variance": variance.expand_as(x), "log_variance": log_variance.expand_as(x),
+                          "pred_xstart": pred_xstart, "model_output": model_output}
+            if sampler == "ddpm":
+                cond_until = y.get('cond_until', 1)
+                if i >= cond_until:                                      # condition_mean_with_grad, var_scale=True
+                    gradient = cond_fn(x, t, p_mean_var, **model_kwargs)
+                    mean = mean.float() + variance * gradient.float()
+                sample = mean + (nonzero * torch.exp(0.5 * log_variance)) * noise
+                return {"sample": sample.detach(), "pred_xstart": pred_xstart.detach()}
+            # ddim_sample_with_grad -> condition_score_with_grad (:636-660)
+            sra, srm1a = f32(self.sqrt_recip_alphas_cumprod), f32(self.sqrt_recipm1_alphas_cumprod)
+            alpha_bar, alpha_bar_prev = f32(self.alphas_cumprod), f32(self.alphas_cumprod_prev)
+            eps = (sra * x - pred_xstart) / srm1a
+            gradient = cond_fn(x, t, p_mean_var, **model_kwargs)
+            eps = eps - (1 - alpha_bar).sqrt() * gradient
+            new_xstart = (sra * x - srm1a * eps).detach()                # _predict_xstart_from_eps
+        eps = (sra * x.detach() - new_xstart) / srm1a
+        sigma = (eta * torch.sqrt((1 - alpha_bar_prev) / (1 - alpha_bar))) * torch.sqrt(1 - alpha_bar / alpha_bar_prev)
+        mean_pred = new_xstart * torch.sqrt(alpha_bar_prev) + torch.sqrt(1 - alpha_bar_prev - sigma ** 2) * eps
+        sample = mean_pred + (nonzero * sigma) * noise
+        return {"sample": sample, "pred_xstart": pred_xstart.detach()}   # the UNconditioned prediction (:1413-1416)
 
     def _generic_step(self, eng, model, img, i, sampler_id, eta, nz, pred, seed, model_kwargs, first=0):
         """Any callable denoiser: the model runs in torch, the sampler arithmetic in the engine."""
@@ -427,7 +499,7 @@ class GaussianDiffusion:
             raise NotImplementedError()
         return self._loop("ddpm", model, shape, noise, clip_denoised, denoised_fn, cond_fn,
                           model_kwargs, device, progress, 0.0, skip_timesteps, init_image,
-                          randomize_class, dump_steps)
+                          randomize_class, dump_steps, cond_fn_with_grad)
 
     def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True,
                                   denoised_fn=None, cond_fn=None, model_kwargs=None, device=None,
@@ -438,7 +510,8 @@ class GaussianDiffusion:
             raise NotImplementedError()
         yield from self._sample_loop_progressive(
             "ddpm", model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device,
-            progress, 0.0, skip_timesteps, init_image, randomize_class, fast=False)
+            progress, 0.0, skip_timesteps, init_image, randomize_class, fast=False,
+            cond_fn_with_grad=cond_fn_with_grad)
 
     def ddim_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None,
                          cond_fn=None, model_kwargs=None, device=None, progress=False, eta=0.0,
@@ -461,27 +534,32 @@ class GaussianDiffusion:
             progress, eta, skip_timesteps, init_image, randomize_class, fast=False)
 
     def _loop(self, sampler, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs,
-              device, progress, eta, skip_timesteps, init_image, randomize_class, dump_steps):
+              device, progress, eta, skip_timesteps, init_image, randomize_class, dump_steps,
+              cond_fn_with_grad=False):
         # The default precision (f16x3) is range-limited; if an activation leaves the f16 range the chain is re-run —
         # same torch RNG state, hence same engine seed and noise — on a bf16x6 engine (exact operands, fp32 range).
         mdm, _ = _unwrap_model(model)
         rng_state = torch.random.get_rng_state()
         try:
             return self._loop_once(sampler, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs,
-                                   device, progress, eta, skip_timesteps, init_image, randomize_class, dump_steps)
+                                   device, progress, eta, skip_timesteps, init_image, randomize_class, dump_steps,
+                                   cond_fn_with_grad)
         except N.RangeError:
             if mdm is None or not hasattr(mdm, "range_fallback") or not mdm.range_fallback():
                 raise
             torch.random.set_rng_state(rng_state)
             return self._loop_once(sampler, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs,
-                                   device, progress, eta, skip_timesteps, init_image, randomize_class, dump_steps)
+                                   device, progress, eta, skip_timesteps, init_image, randomize_class, dump_steps,
+                                   cond_fn_with_grad)
 
     def _loop_once(self, sampler, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs,
-                   device, progress, eta, skip_timesteps, init_image, randomize_class, dump_steps):
+                   device, progress, eta, skip_timesteps, init_image, randomize_class, dump_steps,
+                   cond_fn_with_grad=False):
         final, dump = None, []
         gen = self._sample_loop_progressive(
             sampler, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device,
-            progress, eta, skip_timesteps, init_image, randomize_class, fast=dump_steps is None)
+            progress, eta, skip_timesteps, init_image, randomize_class, fast=dump_steps is None,
+            cond_fn_with_grad=cond_fn_with_grad)
         for i, out in enumerate(gen):
             if dump_steps is not None and i in dump_steps:
                 dump.append(deepcopy(out["pred_xstart"]))
@@ -499,6 +577,30 @@ class GaussianDiffusion:
                     model_kwargs=None, eta=0.0, previous_xstart=None):
         """One DDIM step (reference :1300-1356)."""
         return self._single_step("ddim", model, x, t, cond_fn, model_kwargs, False, eta, clip_denoised)
+
+    def p_sample_with_grad(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                           model_kwargs=None, const_noise=False, previous_xstart=None):
+        """Reference :715-800 (cond_fn(x, t, p_mean_var, **model_kwargs) -> gradient, added as variance * gradient)."""
+        return self._single_guided("ddpm", model, x, t, cond_fn, model_kwargs, 0.0)
+
+    def ddim_sample_with_grad(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                              model_kwargs=None, eta=0.0, previous_xstart=None):
+        """Reference :1358-1416 (condition_score_with_grad)."""
+        return self._single_guided("ddim", model, x, t, cond_fn, model_kwargs, eta)
+
+    def _single_guided(self, sampler, model, x, t, cond_fn, model_kwargs, eta):
+        i = int(t.reshape(-1)[0].item())
+        assert bool((t == i).all()), "all samples of a batch share the denoising step"
+        if cond_fn is None:
+            return self._single_step(sampler, model, x, t, None, model_kwargs, False, eta)
+        draws = _NoiseSource(self.injected_noise, x.shape, x.device)
+        if draws.active:
+            nz = draws.next()
+        else:
+            eng = self._engine_for(None, x.device, x.shape[0], x.shape[1] * x.shape[2], x.shape[-1], False)
+            nz = eng.randn(x.shape, seed=_fresh_seed(), step=i,
+                           first_sample=int(model_kwargs['y'].get('first_sample', self.first_sample)))
+        return self._guided_step(sampler, model, x.detach().float(), i, cond_fn, model_kwargs, eta, nz)
 
     def _single_step(self, sampler, model, x, t, cond_fn, model_kwargs, const_noise, eta, clip_denoised=False):
         assert cond_fn is None, "only support the case where cond_fn is None"

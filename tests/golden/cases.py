@@ -43,6 +43,14 @@ CASES = {
                                  edit=True, trans_length=5, imputate=True, stop_imputation_at=1,
                                  recon=True, recon_weight=20.0, grad_schedule=None, replacement="marginal",
                                  stop_recguidance_at=5, lengths=[60, 45]),
+    # cond_fn guidance (the GMD legacy, reference gaussian_diffusion.py:579-603,636-660,715-800,1358-1416): a quadratic
+    # pull of pred_xstart towards the keyframes, gradient by torch.autograd THROUGH the (CFG) denoiser
+    "chain_condfn_ddpm": dict(kind="chain", text=True, cfg=True, weight_seed=18, B=2, T=60, respacing=[10],
+                              sampler="ddpm", seed=111, text_scale=[2.5, 2.5], cond_fn=True, trans_length=5,
+                              cond_weight=30.0, lengths=[60, 45]),
+    "chain_condfn_ddim": dict(kind="chain", text=True, cfg=True, weight_seed=18, B=2, T=60, respacing="ddim10",
+                              sampler="ddim", eta=0.0, seed=112, text_scale=[2.5, 2.5], cond_fn=True, trans_length=5,
+                              cond_weight=30.0, lengths=[60, 45]),
     "chain_ddim_eta0": dict(kind="chain", text=True, cfg=True, weight_seed=17, B=2, T=60,
                             respacing="ddim10", sampler="ddim", eta=0.0, seed=107,
                             text_scale=[2.5, 2.5]),
@@ -82,7 +90,7 @@ def make_inputs(case: dict) -> dict:
         lengths = np.asarray(case.get("lengths", [T] * B), dtype=np.int64)
         out["lengths"] = lengths
         out["len_mask"] = (np.arange(T)[None, :] < lengths[:, None]).reshape(B, 1, 1, T)
-        if case.get("edit"):
+        if case.get("edit") or case.get("cond_fn"):
             out["x0"] = f32(rng.standard_normal(shape))
             out["inpaint_mask"] = sparse_keyframe_mask(lengths, T, case["trans_length"])
         if case.get("init_image"):
@@ -91,6 +99,20 @@ def make_inputs(case: dict) -> dict:
         out["enc_text"] = f32(rng.standard_normal((B, 512)))
         out["text_scale"] = f32(case.get("text_scale", [2.5] * B))
     return out
+
+
+def make_cond_fn(target, mask, weight):
+    """cond_fn(x, t, p_mean_var, **model_kwargs) -> d/dx [ -weight/2 * sum(mask * (pred_xstart - target)^2) ]: the shape of the
+    GMD key-location guidance (sample/gmd/condition.py) reduced to a quadratic; `target`, `mask` are torch tensors on
+    the sampling device.  The gradient flows through the denoiser (pred_xstart depends on x)."""
+    import torch
+
+    def cond_fn(x, t, p_mean_var, **model_kwargs):
+        with torch.enable_grad():
+            loss = -0.5 * weight * (((p_mean_var["pred_xstart"] - target) ** 2) * mask).sum()
+            return torch.autograd.grad(loss, x)[0]
+
+    return cond_fn
 
 
 def fingerprint(inputs: dict) -> np.ndarray:

@@ -106,7 +106,8 @@ def vjp_case(ref):
 
 def chain_cases(ref):
     for name in ("chain_uncond_ddpm", "chain_edit_recon", "chain_impute_only", "chain_ddim_eta0",
-                 "chain_ddim_eta05", "chain_skip_init", "chain_marginal_recon"):
+                 "chain_ddim_eta05", "chain_skip_init", "chain_marginal_recon", "chain_condfn_ddpm",
+                 "chain_condfn_ddim"):
         case = cases.CASES[name]
         inp = cases.make_inputs(case)
         model, diffusion = build(ref, case)
@@ -132,6 +133,9 @@ def chain_cases(ref):
         kw = dict(noise=t(inp["x_T"]), clip_denoised=False, model_kwargs={"y": y},
                   skip_timesteps=case.get("skip", 0), device=torch.device("cpu"),
                   init_image=t(inp["init_image"]) if "init_image" in inp else None)
+        if case.get("cond_fn"):
+            kw.update(cond_fn=cases.make_cond_fn(t(inp["x0"]), t(inp["inpaint_mask"] & inp["len_mask"]).float(),
+                                                 case["cond_weight"]), cond_fn_with_grad=True)
         if case["sampler"] == "ddim":
             kw["eta"] = case["eta"]
         n_steps = diffusion.num_timesteps - case.get("skip", 0)

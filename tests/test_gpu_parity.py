@@ -668,6 +668,40 @@ def test_out_of_range_timestep_is_reported():
         model(x, torch.tensor([5, 5000]), y={})      # host tensor: checked before the launch
 
 
+# ---- cond_fn guidance (p_sample_with_grad / ddim_sample_with_grad) -------------------------------
+@pytest.mark.parametrize("name", ["chain_condfn_ddpm", "chain_condfn_ddim"])
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_cond_fn_chain_vs_reference(cases, name, precision):
+    """p_sample_loop(cond_fn=..., cond_fn_with_grad=True) and ddim_sample_loop(cond_fn=...) with a quadratic key-location
+    style cond_fn whose gradient is taken by torch.autograd THROUGH the native CFG denoiser (cmdi_mdm_vjp), vs the real
+    reference's chain on the same noise."""
+    case = cases.CASES[name]
+    inp = cases.make_inputs(case)
+    check_fingerprint(cases, name, inp)
+    model, _ = make_model(case, precision=precision)
+    diffusion = make_diffusion(case["respacing"])
+    y = {"mask": tt(inp["len_mask"]), "lengths": tt(inp["lengths"]), "text_embed": tt(inp["enc_text"]),
+         "text_scale": tt(inp["text_scale"])}
+    cond_fn = cases.make_cond_fn(tt(inp["x0"]), tt(inp["inpaint_mask"] & inp["len_mask"]).float(), case["cond_weight"])
+    loop = diffusion.ddim_sample_loop if case["sampler"] == "ddim" else diffusion.p_sample_loop
+    kw = dict(noise=tt(inp["x_T"]), clip_denoised=False, model_kwargs={"y": y}, cond_fn=cond_fn, cond_fn_with_grad=True)
+    if case["sampler"] == "ddim":
+        kw["eta"] = case["eta"]
+    diffusion.injected_noise = tt(inp["noise"])
+    final = loop(model, inp["x_T"].shape, **kw).cpu().numpy()
+    dumps = loop(model, inp["x_T"].shape, dump_steps=list(cases.DUMP_STEPS), **kw)
+    g = load_golden(name)
+    assert rel_l2(final, g["final"]) <= 1e-4, rel_l2(final, g["final"])
+    for k, d in enumerate(dumps):
+        assert rel_l2(d.cpu().numpy(), g["pred_xstart"][k]) <= 1e-4, (k, rel_l2(d.cpu().numpy(), g["pred_xstart"][k]))
+    # the guidance is not a no-op: the unguided chain on the same noise ends elsewhere
+    plain = loop(model, inp["x_T"].shape, **{k: v for k, v in kw.items() if k not in ("cond_fn", "cond_fn_with_grad")})
+    assert rel_l2(plain.cpu().numpy(), g["final"]) > 1e-2
+    if case["sampler"] == "ddpm":     # p_sample asserts cond_fn is None (:685): without cond_fn_with_grad the loop refuses
+        with pytest.raises(AssertionError):
+            loop(model, inp["x_T"].shape, **dict(kw, cond_fn_with_grad=False))
+
+
 # ---- full-size properties (BASELINE config 2 shape: B=32, T=196, CFG) --------------------------------
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_full_size_batch_independence_and_sharding(precision):
