@@ -45,6 +45,10 @@ class ModelDesc(C.Structure):
         "text_cond", "want_grad", "precision", "arch", "unet_added")] + [("unet_mults", C.c_int32 * 4)]
 
 
+class ClipDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("vocab_size", "width", "heads", "layers", "context", "embed_dim", "max_batch")]
+
+
 class Schedule(C.Structure):
     _fields_ = [("n_steps", C.c_int32), ("mean_type", C.c_int32)] + [
         (n, C.POINTER(C.c_float)) for n in (
@@ -93,6 +97,10 @@ SIGNATURES = {
     "cmdi_range_status": (C.c_int, [_VP, C.POINTER(_I32), _VP]),
     "cmdi_split_f16": (C.c_int, [_VP, _VP, _I64, _I32, _VP]),
     "cmdi_gemm_h3": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _VP]),
+    "cmdi_clip_create": (C.c_int, [C.POINTER(ClipDesc), C.POINTER(_VP)]),
+    "cmdi_clip_destroy": (C.c_int, [_VP]),
+    "cmdi_clip_load_weight": (C.c_int, [_VP, C.c_char_p, _VP, _I64, _VP]),
+    "cmdi_clip_encode_text": (C.c_int, [_VP, _VP, _I32, _VP, _VP]),
     "cmdi_pack_x6": (C.c_int, [_VP, _VP, _I64, _I32, _VP]),
     "cmdi_gemm_x6": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _VP]),
     "cmdi_philox4x32_10": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),

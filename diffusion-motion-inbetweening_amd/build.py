@@ -31,6 +31,7 @@ UNITS = {
     "attention_h3.hip": [],
     "attention_bwd_f32.hip": [],
     "unet.hip": [],
+    "clip_text.hip": [],
     "elementwise.hip": [],
     # reference evaluation order, every op rounded separately (see the header of sampler.hip)
     "sampler.hip": ["-ffp-contract=off"],

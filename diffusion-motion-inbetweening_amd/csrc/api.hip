@@ -1574,6 +1574,42 @@ int cmdi_gemm_nt(const float* d_a, const float* d_w, const float* d_bias, const 
     return CMDI_OK;
 }
 
+struct cmdi_clip_text { ClipText* t; };
+
+int cmdi_clip_create(const cmdi_clip_desc* desc, cmdi_clip_handle* out) {
+    if (!desc || !out) return fail(CMDI_E_INVALID, "null argument");
+    ClipText* t = clip_new(desc->vocab_size, desc->width, desc->heads, desc->layers, desc->context, desc->embed_dim,
+                           desc->max_batch);
+    if (clip_error(t)[0]) {
+        const std::string msg = clip_error(t);
+        clip_free(t);
+        return fail(msg.find("hipMalloc") != std::string::npos ? CMDI_E_NOMEM : CMDI_E_INVALID, msg);
+    }
+    *out = new cmdi_clip_text{t};
+    return CMDI_OK;
+}
+
+int cmdi_clip_destroy(cmdi_clip_handle h) {
+    if (!h) return CMDI_OK;
+    clip_free(h->t);
+    delete h;
+    return CMDI_OK;
+}
+
+int cmdi_clip_load_weight(cmdi_clip_handle h, const char* name, const float* d_src, int64_t numel, cmdi_stream stream) {
+    if (!h || !name || !d_src) return fail(CMDI_E_INVALID, "null argument");
+    const int rc = clip_load_weight(h->t, name, d_src, numel, static_cast<hipStream_t>(stream));
+    if (rc != 0) return fail(rc == -5 ? CMDI_E_UNKNOWN_WEIGHT : rc == -3 ? CMDI_E_HIP : CMDI_E_INVALID, clip_error(h->t));
+    return CMDI_OK;
+}
+
+int cmdi_clip_encode_text(cmdi_clip_handle h, const int32_t* d_tokens, int32_t batch, float* d_out, cmdi_stream stream) {
+    if (!h || !d_tokens || !d_out) return fail(CMDI_E_INVALID, "null argument");
+    const int rc = clip_encode_text(h->t, d_tokens, batch, d_out, static_cast<hipStream_t>(stream));
+    if (rc != 0) return fail(rc == -3 ? CMDI_E_HIP : CMDI_E_INVALID, clip_error(h->t));
+    return CMDI_OK;
+}
+
 int cmdi_pack_x6(const float* d_src, void* d_dst, int64_t rows, int32_t cols, cmdi_stream stream) {
     if (!d_src || !d_dst || rows < 1 || cols < 32 || cols % 32 != 0)
         return fail(CMDI_E_INVALID, "bad argument (cols must be a positive multiple of 32)");

@@ -112,6 +112,15 @@ int unet_range_flag(UnetModel* u, int* flag, hipStream_t s);
 hipError_t launch_unet_emb(float* emb, const float* time_table, const float* text_term, const int64_t* t_dev,
                            int64_t t_scalar, int n_seq, int n_per_pass, int d, int n_time_rows, hipStream_t stream);
 
+// ---- clip_text.hip: CLIP ViT-B/32 text tower (the step before the loop) ---------------------------------------
+struct ClipText;
+ClipText* clip_new(int vocab, int width, int heads, int layers, int ctx, int embed, int max_batch);
+const char* clip_error(const ClipText* c);
+void clip_free(ClipText* c);
+int clip_load_weight(ClipText* c, const char* name, const float* src, int64_t numel, hipStream_t s);
+int clip_encode_text(ClipText* c, const int32_t* tokens, int B, float* out, hipStream_t s);
+int clip_status(ClipText* c, int* flag, hipStream_t s);
+
 // ---- postprocess.hip ------------------------------------------------------------------------------
 // x [B, n_feats, 1, T] (z-scored if mean/std given) -> joint positions out [B, n_joints, 3, T]
 hipError_t launch_recover_xyz(const float* x, const float* mean, const float* std, float* out, int batch,

@@ -172,19 +172,26 @@ class MDM(nn.Module):
         return cond
 
     def encode_text(self, raw_text):
-        """CLIP encoding of prompts (reference :211-237): 20 tokens + start/end, zero-padded to 77."""
+        """CLIP encoding of prompts (reference :211-237): 20 tokens + start/end, zero-padded to 77.  `clip_model` is the
+        third-party clip package's model if that package is importable, or a native model.clip_text.CLIPTextTower
+        (attach it: ``model.clip_model = CLIPTextTower.from_state_dict(sd, bpe_path=...)``)."""
         if self.clip_model is None:
             raise N.NativeError("no CLIP model available: pass precomputed embeddings in "
-                                "model_kwargs['y']['text_embed'] ([B, 512])")
-        import clip  # type: ignore
+                                "model_kwargs['y']['text_embed'] ([B, 512]) or attach a model.clip_text.CLIPTextTower")
+        from .clip_text import CLIPTextTower
         device = next(self.parameters()).device
+        if isinstance(self.clip_model, CLIPTextTower):
+            tok = self.clip_model.tokenize
+        else:
+            import clip  # type: ignore
+            tok = clip.tokenize
         if self.dataset in ('humanml', 'kit'):
             ctx = 20 + 2
-            texts = clip.tokenize(raw_text, context_length=ctx, truncate=True).to(device)
+            texts = tok(raw_text, context_length=ctx, truncate=True).to(device)
             texts = torch.cat([texts, torch.zeros([texts.shape[0], 77 - ctx], dtype=texts.dtype,
                                                   device=device)], dim=1)
         else:
-            texts = clip.tokenize(raw_text, truncate=True).to(device)
+            texts = tok(raw_text, truncate=True).to(device)
         return self.clip_model.encode_text(texts).float()
 
     def text_embedding(self, y, batch, device):

@@ -221,6 +221,29 @@ int cmdi_recover_xyz(const float* d_sample, const float* d_mean, const float* d_
                      int32_t batch, int32_t n_feats, int32_t n_frames, int32_t n_joints, int32_t abs_3d,
                      cmdi_stream stream);
 
+/* ---- before the loop: the CLIP text tower ---------------------------------------------------------
+ * Replaces clip_model.encode_text(tokens).float() of MDM.encode_text (model/mdm.py:211-237; clip.load('ViT-B/32') at
+ * :173-186): openai/CLIP's text transformer (token + positional embedding, `layers` pre-LN residual attention blocks with
+ * a causal mask and QuickGELU MLPs, ln_final, the end-of-text row @ text_projection), fp32, on the device.  Weights go in
+ * under openai/CLIP's own state-dict names ("token_embedding.weight", "positional_embedding",
+ * "transformer.resblocks.<l>.attn.in_proj_weight", ..., "ln_final.weight", "text_projection") as fp32 device tensors;
+ * d_tokens are the int32 ids of clip.tokenize [batch, context]; d_out receives [batch, embed_dim], which is what
+ * cmdi_condition.d_enc_text takes. */
+typedef struct cmdi_clip_text* cmdi_clip_handle;
+typedef struct {
+    int32_t vocab_size;   /* 49408 */
+    int32_t width;        /* transformer_width 512 (= heads * 64) */
+    int32_t heads;        /* 8 */
+    int32_t layers;       /* 12 */
+    int32_t context;      /* context_length 77 */
+    int32_t embed_dim;    /* 512 */
+    int32_t max_batch;
+} cmdi_clip_desc;
+int cmdi_clip_create(const cmdi_clip_desc* desc, cmdi_clip_handle* out);
+int cmdi_clip_destroy(cmdi_clip_handle h);
+int cmdi_clip_load_weight(cmdi_clip_handle h, const char* name, const float* d_src, int64_t numel, cmdi_stream stream);
+int cmdi_clip_encode_text(cmdi_clip_handle h, const int32_t* d_tokens, int32_t batch, float* d_out, cmdi_stream stream);
+
 /* ---- introspection for tests / bench --------------------------------------------------------- */
 /* Raw NT GEMM used by every projection: C[M,N] = epi(A[M,K] · W[N,K]^T + bias[N]); fp32 MFMA.
  * epi: 0 = bias, 1 = bias + GELU(erf), 3 = bias + residual d_resid[M,N].  tile selects the block
