@@ -44,6 +44,10 @@ struct LayerW {
     // split-f16 copies (hi | lo*2^11 rows, gemm_h3.hpp) for the f16-pipe forward GEMMs
     _Float16 *in_ws = nullptr, *out_ws = nullptr, *l1_ws = nullptr, *l2_ws = nullptr;
     _Float16 *in_wTs = nullptr, *out_wTs = nullptr, *l1_wTs = nullptr, *l2_wTs = nullptr;  // want_grad
+    // f16x3 with the LayerNorms folded into their consumers (gemm_params.hpp): in_proj weights with the PREVIOUS layer's
+    // norm2 gamma folded in (layers >= 1), linear1 weights with this layer's norm1 gamma; c1 = row sums, c2 = W beta + b
+    _Float16 *in_wsf = nullptr, *l1_wsf = nullptr;
+    float *in_c1 = nullptr, *in_c2 = nullptr, *l1_c1 = nullptr, *l1_c2 = nullptr;
     // bf16x6: three-plane bf16 copies (gemm_x6.hpp) of the forward weights and, want_grad, of their transposes
     void *in_wx = nullptr, *out_wx = nullptr, *l1_wx = nullptr, *l2_wx = nullptr;
     void *in_wTx = nullptr, *out_wTx = nullptr, *l1_wTx = nullptr, *l2_wTx = nullptr;
@@ -115,6 +119,11 @@ struct cmdi_engine {
     // the full-row 64x512 tile it needs (197 blocks, 8 waves per CU) loses more in the GEMM than the
     // saved LayerNorm pass returns (B=32 CFG: 2.60 vs 2.29 ms per step on MI355X).
     int ln_fuse = 0;
+    // f16x3, forward without a stash: NO LayerNorm pass — the residual stream travels as its pre-LayerNorm value plus
+    // per-row partial statistics and every LayerNorm is folded into the GEMM that consumes it (gemm_params.hpp);
+    // CMDI_LN_FOLD=0 keeps the separate LayerNorm kernels
+    int ln_fold = 0;
+    float *partA = nullptr, *partB = nullptr;   // [M][16][2] partial statistics of pre1 / pre2
     int io_pipe = 0;   // 1: software-pipelined input / output projection GEMMs
     // f16x3: input / output projections on the f16 pipe too (frame rows split by pose_rows_split_kernel, token and
     // motion-layout epilogues in gemm_h3.hpp); CMDI_IO_H3=0 keeps them on the fp32 MFMA kernels
@@ -228,6 +237,58 @@ int run_layers(cmdi_engine* e, int seq0, int nseq, bool keep, bool prof, hipStre
     };
     if (h3 && !e->io_h3)  // layer 0 reads the tokens assembled by token0 + the input projection (fp32)
         HIPCHK(launch_split_f16(tokA, tokS, M, d, d, e->range_flag, s));
+    if (h3 && e->ln_fold && !keep && e->io_h3) {
+        // ---- no LayerNorm pass: P (tokS) is the layer input BEFORE its LayerNorm (layer 0: the tokens themselves) ----
+        float* partA = e->partA + r0 * 32;
+        float* partB = e->partB + r0 * 32;
+        for (int l = 0; l < e->L; ++l) {
+            const LayerW& w = e->layers[l];
+            const LayerW* prev = l > 0 ? &e->layers[l - 1] : nullptr;
+            if (prof) {
+                if (e->ev_used + 2 > e->ev_pool.size()) {
+                    hipEvent_t a, b;
+                    HIPCHK(hipEventCreate(&a));
+                    HIPCHK(hipEventCreate(&b));
+                    e->ev_pool.push_back(a);
+                    e->ev_pool.push_back(b);
+                }
+                HIPCHK(hipEventRecord(e->ev_pool[e->ev_used], s));
+            }
+            {   // qkv = in_proj(LN2_prev(P))
+                H3Params p = hp(tokS, prev ? w.in_wsf : w.in_ws, prev ? w.in_c2 : w.in_b, nullptr, qkvS, 3 * d, d);
+                if (prev) { p.ln_part = partB; p.ln_c1 = w.in_c1; }
+                HIPCHK(launch_gemm_h3(H3_PLAIN_SPLIT, p, e->h3_tile_qkv, s));
+            }
+            if (prof) {
+                HIPCHK(hipEventRecord(e->ev_pool[e->ev_used + 1], s));
+                e->ev_used += 2;
+                e->prof_m = M; e->prof_n = 3 * d; e->prof_k = d;
+            }
+            HIPCHK(launch_attention_h3(qkvS, nullptr, attnS, e->range_flag, nullptr, nseq, S, e->H, s));
+            {   // pre1 = LN2_prev(P) + out_proj(attn)   -> bufHS (+ partial statistics A)
+                H3Params p = hp(attnS, w.out_ws, w.out_b, nullptr, bufHS, d, d);
+                p.Rs = tokS;
+                if (prev) { p.ln_part = partB; p.ln_rg = prev->n2_g; p.ln_rb = prev->n2_b; }
+                p.out_part = partA;
+                HIPCHK(launch_gemm_h3(H3_RESID, p, e->h3_tile_proj, s));
+            }
+            {   // ffn = gelu(linear1(LN1(pre1)))
+                H3Params p = hp(bufHS, w.l1_wsf, w.l1_c2, nullptr, ffnS, f, d);
+                p.ln_part = partA; p.ln_c1 = w.l1_c1;
+                HIPCHK(launch_gemm_h3(H3_GELU_SPLIT, p, e->h3_tile_ffn1, s));
+            }
+            {   // pre2 = LN1(pre1) + linear2(ffn)   -> tokS (+ partial statistics B): the next layer's P
+                H3Params p = hp(ffnS, w.l2_ws, w.l2_b, nullptr, tokS, d, f);
+                p.Rs = bufHS; p.ln_part = partA; p.ln_rg = w.n1_g; p.ln_rb = w.n1_b;
+                p.out_part = partB;
+                HIPCHK(launch_gemm_h3(H3_RESID, p, e->h3_tile_ffn2, s));
+            }
+        }
+        // the encoder output is LN2 of the last layer: the one LayerNorm launch that remains (split rows in, in place)
+        const LayerW& last = e->layers[e->L - 1];
+        HIPCHK(launch_layernorm(nullptr, last.n2_g, last.n2_b, nullptr, tokS, e->range_flag, nullptr, M, d, s, tokS));
+        return CMDI_OK;
+    }
     for (int l = 0; l < e->L; ++l) {
         const LayerW& w = e->layers[l];
         const LayerStash* st = keep ? &e->stash[l] : nullptr;
@@ -755,6 +816,7 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
     e->h3_tile_ffn2 = env_probe("CMDI_H3_TILE_FFN2", env_probe("CMDI_H3_TILE", 0));
     e->ln_fuse = env_probe("CMDI_LN_FUSE", 0) && desc->d_model == 512;
     e->io_h3 = e->precision == CMDI_PREC_F16X3 && !e->ln_fuse && env_probe("CMDI_IO_H3", 1);
+    e->ln_fold = e->io_h3 && desc->d_model == 512 && env_int("CMDI_LN_FOLD", 1);
     const int d = e->d, f = e->f, C = e->C;
     const size_t nseq = 2 * (size_t)e->Bmax, Smax = e->Tmax + 1, Mmax = nseq * Smax;
     *out = e;  // so that cmdi_destroy can free a half-built engine
@@ -808,6 +870,13 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
         for (LayerW& w : e->layers) {
             ALLOC(w.in_ws, (size_t)3 * d * d * 2); ALLOC(w.out_ws, (size_t)d * d * 2);
             ALLOC(w.l1_ws, (size_t)f * d * 2); ALLOC(w.l2_ws, (size_t)d * f * 2);
+        }
+        if (e->ln_fold) {
+            for (LayerW& w : e->layers) {
+                ALLOC(w.in_wsf, (size_t)3 * d * d * 2); ALLOC(w.l1_wsf, (size_t)f * d * 2);
+                ALLOC(w.in_c1, 3 * d); ALLOC(w.in_c2, 3 * d); ALLOC(w.l1_c1, f); ALLOC(w.l1_c2, f);
+            }
+            ALLOC(e->partA, Mmax * 32); ALLOC(e->partB, Mmax * 32);
         }
         ALLOC(e->w_in_s, (size_t)d * e->Cpad * 2); ALLOC(e->w_out_s, (size_t)C * d * 2);
         ALLOC(e->xS, (size_t)e->Bmax * e->Tmax * e->Cpad * 2);
@@ -975,6 +1044,26 @@ int cmdi_finalize_weights(cmdi_handle e, int32_t n_time_rows, cmdi_stream stream
                 HIPCHK(launch_split_f16(w.l2_wT, w.l2_wTs, f, d, d, e->range_flag, s));
             }
         }
+    }
+    if (e->precision == CMDI_PREC_F16X3 && e->ln_fold && !e->unet) {
+        // LayerNorm folded into its consumers: gamma into the weights, (row sums, W beta + b) for the epilogue
+        float* tmp = nullptr;
+        const size_t tmp_n = (size_t)(3 * d > f ? 3 * d : f) * d;
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&tmp), tmp_n * sizeof(float)));
+        hipError_t fe = hipSuccess;
+        for (int l = 0; l < e->L && fe == hipSuccess; ++l) {
+            LayerW& w = e->layers[l];
+            fe = launch_fold_ln(w.l1_w, w.n1_g, w.n1_b, w.l1_b, tmp, w.l1_c1, w.l1_c2, f, d, s);
+            if (fe == hipSuccess) fe = launch_split_f16(tmp, w.l1_wsf, f, d, d, e->range_flag, s);
+            if (l > 0 && fe == hipSuccess) {
+                const LayerW& pv = e->layers[l - 1];
+                fe = launch_fold_ln(w.in_w, pv.n2_g, pv.n2_b, w.in_b, tmp, w.in_c1, w.in_c2, 3 * d, d, s);
+                if (fe == hipSuccess) fe = launch_split_f16(tmp, w.in_wsf, 3 * d, d, d, e->range_flag, s);
+            }
+        }
+        hipError_t se = hipStreamSynchronize(s);   // one-time setup: tmp must outlive the kernels
+        (void)hipFree(tmp);
+        HIPCHK(fe); HIPCHK(se);
     }
     if (e->precision == CMDI_PREC_BF16X6) {
         for (LayerW& w : e->layers) {

@@ -16,7 +16,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         float* __restrict__ y,
                                                         _Float16* __restrict__ ys,
                                                         int* __restrict__ range_flag,
-                                                        float* __restrict__ stats, int rows) {
+                                                        float* __restrict__ stats, int rows,
+                                                        const _Float16* __restrict__ xs_in) {
     constexpr int D = NV * 256;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -26,7 +27,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        v[i] = *reinterpret_cast<const float4*>(xr + i * 256 + lane * 4);
+        if (xs_in) {   // the input arrives as split rows (hi + lo * 2^-11): the pre-LayerNorm stream of the folded path
+            const _Float16* sp = xs_in + (size_t)row * (2 * D) + split_pos(i * 256 + lane * 4);
+            const h4 a = *reinterpret_cast<const h4*>(sp), b = *reinterpret_cast<const h4*>(sp + 32);
+            v[i] = make_float4((float)a[0] + (float)b[0] * kLoInv, (float)a[1] + (float)b[1] * kLoInv,
+                               (float)a[2] + (float)b[2] * kLoInv, (float)a[3] + (float)b[3] * kLoInv);
+        } else {
+            v[i] = *reinterpret_cast<const float4*>(xr + i * 256 + lane * 4);
+        }
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
     const float mean = wave_sum(s) * (1.0f / D);
@@ -129,15 +137,46 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 
 hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, float* y,
                             _Float16* y_split, int* range_flag, float* stats, int rows, int d,
-                            hipStream_t stream) {
+                            hipStream_t stream, const _Float16* x_split_in) {
     const dim3 grid((rows + 3) / 4), block(256);
     switch (d) {
-        case 256: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, stream, x, gamma, beta, y, y_split, range_flag, stats, rows); break;
-        case 512: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, stream, x, gamma, beta, y, y_split, range_flag, stats, rows); break;
-        case 768: hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, stream, x, gamma, beta, y, y_split, range_flag, stats, rows); break;
-        case 1024: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, stream, x, gamma, beta, y, y_split, range_flag, stats, rows); break;
+        case 256: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, stream, x, gamma, beta, y, y_split, range_flag, stats, rows, x_split_in); break;
+        case 512: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, stream, x, gamma, beta, y, y_split, range_flag, stats, rows, x_split_in); break;
+        case 768: hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, stream, x, gamma, beta, y, y_split, range_flag, stats, rows, x_split_in); break;
+        case 1024: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, stream, x, gamma, beta, y, y_split, range_flag, stats, rows, x_split_in); break;
         default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+// LayerNorm folded into the consuming GEMM (gemm_params.hpp): Wf = W diag(gamma), c1[n] = sum_k Wf[n,k],
+// c2[n] = sum_k W[n,k] beta[k] + bias[n].  One block per output row n; sums in double.
+__global__ __launch_bounds__(256) void fold_ln_kernel(const float* __restrict__ W, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float* __restrict__ bias,
+                                                      float* __restrict__ Wf, float* __restrict__ c1,
+                                                      float* __restrict__ c2, int K) {
+    __shared__ double red[2][4];
+    const int n = blockIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float w = W[(size_t)n * K + k];
+        const float wf = w * gamma[k];
+        Wf[(size_t)n * K + k] = wf;
+        s1 += (double)wf;
+        s2 += (double)w * (double)beta[k];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        c1[n] = (float)((red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+        c2[n] = (float)((red[1][0] + red[1][1]) + (red[1][2] + red[1][3]) + (double)(bias ? bias[n] : 0.f));
+    }
+}
+hipError_t launch_fold_ln(const float* W, const float* gamma, const float* beta, const float* bias, float* Wf, float* c1,
+                          float* c2, int N, int K, hipStream_t stream) {
+    hipLaunchKernelGGL(fold_ln_kernel, dim3(N), dim3(256), 0, stream, W, gamma, beta, bias, Wf, c1, c2, K);
     return hipGetLastError();
 }
 

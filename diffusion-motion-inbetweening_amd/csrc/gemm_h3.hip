@@ -104,6 +104,12 @@ hipError_t launch_gemm_h3(int epi, const H3Params& p, int tile, hipStream_t s) {
         return launch_h3_one<H64x512ln, H3_RESID_LN>(p, s);
     }
     if (p.ksplit > 1 && (epi != H3_PLAIN || tile == 20 || p.K / 32 < p.ksplit)) return hipErrorInvalidValue;
+    // folded LayerNorm: statistics rows are 16 blocks of 32 columns = d_model 512; residual-LN and the emitted partials
+    // belong to the residual epilogue; row statistics are per 128-row... any BM, but not the mixed-granularity grid
+    if ((p.ln_part || p.out_part) && tile == 20) return hipErrorInvalidValue;
+    if ((p.out_part && (epi != H3_RESID || p.N != 512)) || (p.ln_rg && (epi != H3_RESID || !p.Rs || !p.ln_part || p.N != 512)) ||
+        (p.ln_c1 && (!p.ln_part || p.K != 512)))
+        return hipErrorInvalidValue;
     if (tile == 0) tile = gemm_h3_auto_tile(p.M, p.N);
     if (epi == H3_CONV_GN) {   // tile rows = one framed sequence: 256 (level 0) or 128 (level 1)
         if (!p.ln_g || !p.ln_b || (!p.C && !p.Cs) || p.N % 128 != 0 || (p.gn_cg != 128 && p.gn_cg != 64) || p.M % p.tp != 0 ||

@@ -65,7 +65,8 @@ struct H3Tile {
     static constexpr int STAGE = (BM + BN) * 128;  // bytes: A rows then W rows, 128 B each
     static constexpr int PW = (BM + BN) / 8 / NW;  // LDS-DMA pieces (1 KiB = 8 rows) per wave per stage
     static constexpr size_t EPI_BYTES = (size_t)NW * 32 * 32 * TN * 4 + 2 * WN * BM * 4;  // transpose + LN sums
-    static constexpr size_t LDS_BYTES = (size_t)NSTAGE * STAGE > EPI_BYTES ? (size_t)NSTAGE * STAGE : EPI_BYTES;
+    static constexpr size_t MAIN_BYTES = (size_t)NSTAGE * STAGE > EPI_BYTES ? (size_t)NSTAGE * STAGE : EPI_BYTES;
+    static constexpr size_t LDS_BYTES = MAIN_BYTES + (size_t)BM * 8;   // + (mean, rstd) of the tile's rows (folded LayerNorm)
     static_assert(NSTAGE == 2 || NSTAGE == 3, "NSTAGE");
     static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "wave tile must be 32-aligned");
     static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "DMA pieces per wave");
@@ -154,6 +155,28 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
     }
     const int a_row = (wm * TM * 32 + l31) * 128;            // + i * 32 * 128
     const int w_row = BM * 128 + (wn * TN * 32 + l31) * 128;  // + j * 32 * 128
+
+    // folded LayerNorm: (mean, rstd) of the tile's rows from the 16 partials of each, once per block, under the first loads
+    float2* row_stats = reinterpret_cast<float2*>(lds + TC::MAIN_BYTES);
+    if (p.ln_part && tid < BM) {
+        int grow = m0 + tid;
+        grow = grow < M ? grow : M - 1;
+        const float4* pp = reinterpret_cast<const float4*>(p.ln_part + (size_t)grow * 32);
+        // (every product-sum below is an explicit fmaf: the same bits in every instantiation of this template — samples
+        // must not depend on the tile shape their batch size selects)
+        float mean_b[16], m2 = 0.f, mean = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 v = pp[q];                    // (sum, M2) of blocks 2q, 2q + 1
+            mean_b[2 * q] = v.x * (1.0f / 32.0f); mean_b[2 * q + 1] = v.z * (1.0f / 32.0f);
+            m2 += v.y + v.w;
+            mean += v.x + v.z;
+        }
+        mean *= (1.0f / 512.0f);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { const float dq = mean_b[q] - mean; m2 = __builtin_fmaf(32.0f * dq, dq, m2); }
+        row_stats[tid] = make_float2(mean, 1.0f / sqrtf(__builtin_fmaf(m2, 1.0f / 512.0f, 1e-5f)));
+    }
 
     const int nk_all = p.K / 32;
     const int kt0 = (int)((long)nk_all * kslice / nslice), nk = (int)((long)nk_all * (kslice + 1) / nslice);
@@ -322,6 +345,15 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
         float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (EPI != H3_MOTION && EPI != H3_CONV_GN && p.bias && nok && kslice == 0) bias4 = *reinterpret_cast<const float4*>(p.bias + n);
         const int npos = split_pos(n);
+        // folded LayerNorm (gemm_params.hpp): column sums of the gamma-folded weights, gamma / beta of a normalised residual
+        float4 c14 = make_float4(0.f, 0.f, 0.f, 0.f), rg4 = c14, rb4 = c14;
+        if (p.ln_c1 && nok) c14 = *reinterpret_cast<const float4*>(p.ln_c1 + n);
+        if constexpr (EPI == H3_RESID) {
+            if (p.ln_rg && nok) {
+                rg4 = *reinterpret_cast<const float4*>(p.ln_rg + n);
+                rb4 = *reinterpret_cast<const float4*>(p.ln_rb + n);
+            }
+        }
         int mo_b = 0, mo_s = 0;                  // H3_MOTION: (sequence, token) of this lane's first column
         if constexpr (EPI == H3_MOTION) { mo_b = n / p.tok_S; mo_s = n - mo_b * p.tok_S; }
         if constexpr (EPI == H3_CONV_GN) {
@@ -415,6 +447,14 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
                     if (pos < p.t_lo || pos >= p.t_hi) continue;
                 }
                 float v[4] = {t.x + bias4.x, t.y + bias4.y, t.z + bias4.z, t.w + bias4.w};
+                float2 rst = make_float2(0.f, 1.f);                        // (mean, rstd) of this row's LayerNorm input
+                if (p.ln_part) rst = row_stats[(wm * TM + i) * 32 + row];
+                if (p.ln_c1) {   // A operand was the raw P: LN(P) W^T + b = rstd (P W'^T - mean c1) + c2
+                    v[0] = __builtin_fmaf(rst.y, __builtin_fmaf(-rst.x, c14.x, t.x), bias4.x);
+                    v[1] = __builtin_fmaf(rst.y, __builtin_fmaf(-rst.x, c14.y, t.y), bias4.y);
+                    v[2] = __builtin_fmaf(rst.y, __builtin_fmaf(-rst.x, c14.z, t.z), bias4.z);
+                    v[3] = __builtin_fmaf(rst.y, __builtin_fmaf(-rst.x, c14.w, t.w), bias4.w);
+                }
                 if constexpr (EPI == H3_TOKENS) {
                     const int b = m / p.tok_T, fr = m - b * p.tok_T;
                     const float4 pe4 = *reinterpret_cast<const float4*>(p.pe + (size_t)(1 + fr) * p.N + n);
@@ -476,8 +516,17 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
                     if (p.Rs) {
                         const _Float16* rs = p.Rs + (size_t)m * (2 * p.N) + npos;
                         const h4 rh = *reinterpret_cast<const h4*>(rs), rl = *reinterpret_cast<const h4*>(rs + 32);
+                        float r4[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (float)rh[e] + (float)rl[e] * kLoInv;
+                        for (int e = 0; e < 4; ++e) r4[e] = (float)rh[e] + (float)rl[e] * kLoInv;
+                        if (p.ln_rg) {   // the residual is LayerNorm(P) of the rows read: (x - mean) * rstd * gamma + beta
+                            r4[0] = __builtin_fmaf((r4[0] - rst.x) * rst.y, rg4.x, rb4.x);
+                            r4[1] = __builtin_fmaf((r4[1] - rst.x) * rst.y, rg4.y, rb4.y);
+                            r4[2] = __builtin_fmaf((r4[2] - rst.x) * rst.y, rg4.z, rb4.z);
+                            r4[3] = __builtin_fmaf((r4[3] - rst.x) * rst.y, rg4.w, rb4.w);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += r4[e];
                     } else {
                         const float4 rr = *reinterpret_cast<const float4*>(p.R + (p.r_ld ? (size_t)m * p.r_ld + n : off));
                         v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
@@ -495,6 +544,20 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
                         _Float16* dst = p.Cs + (size_t)m * (p.cs_ld ? p.cs_ld : 2 * p.N) + npos;
                         *reinterpret_cast<h4*>(dst) = oh;
                         *reinterpret_cast<h4*>(dst + 32) = ol;
+                    }
+                    if (p.out_part) {
+                        // partial LayerNorm statistics of the row just written, over this lane group's 32 columns (8 lanes
+                        // x 4): sum, then the squared deviations from the block mean (two passes, as layernorm_kernel)
+                        float sm = (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+                        for (int o = 1; o < 8; o <<= 1) sm += __shfl_xor(sm, o, 64);
+                        const float mb = sm * (1.0f / 32.0f);
+                        const float d0 = v[0] - mb, d1 = v[1] - mb, d2 = v[2] - mb, d3 = v[3] - mb;
+                        float q = __builtin_fmaf(d0, d0, d1 * d1) + __builtin_fmaf(d2, d2, d3 * d3);
+#pragma unroll
+                        for (int o = 1; o < 8; o <<= 1) q += __shfl_xor(q, o, 64);
+                        if ((lane & 7) == 0)
+                            *reinterpret_cast<float2*>(p.out_part + ((size_t)m * 16 + (n >> 5)) * 2) = make_float2(sm, q);
                     }
                 } else {
                     if constexpr (EPI == H3_GELUGRAD_SPLIT) {

@@ -91,6 +91,18 @@ struct H3Params {
     int a_ld, a_row_mul, taps, cpt;
     int c_row_mul, c_row_add, tp, t_lo, t_hi;
     int cs_ld;          // halves per row of the split output (0 = 2N); Cs may point at a column block of a wider matrix
+    // ---- LayerNorm folded into the GEMMs around it (no LayerNorm pass, api.hip run_layers) -------------------------------
+    // The residual stream travels as its PRE-LayerNorm value P (split rows) plus per-row partial statistics: for every
+    // row 16 x (sum, sum of squared deviations) over its 32-column blocks, written by the producing GEMM's epilogue
+    // (out_part) and combined (Chan) by the consumer into (mean, rstd).  A consumer whose A operand is LN(P) multiplies
+    // the RAW P by weights with gamma folded in (W' = W diag(gamma)) and corrects in the epilogue:
+    //     LN(P) W^T + b = rstd_m (P W'^T - mean_m c1[n]) + c2[n],   c1[n] = sum_k W'[n,k],  c2 = W beta + b  (-> bias)
+    // and a consumer whose RESIDUAL is LN(P) normalises the residual rows it reads anyway.
+    const float* ln_part;   // partial statistics [M][16][2] of this GEMM's row tensor (A operand or residual), or null
+    const float* ln_c1;     // [N]: the A operand is LN(P) folded as above (bias must hold c2); null = A is used as is
+    const float* ln_rg;     // [N] gamma / beta: the residual rows Rs are P and LN(P) is what gets added; null = Rs as is
+    const float* ln_rb;
+    float* out_part;        // H3_RESID: partial statistics [M][16][2] of the value written (N == 512)
     int dbg;            // bench-only ablations: 1 = no in-loop loads, 2 = no epilogue stores, 16 = timestamps
     long long* dbg_buf; // dbg & 16: per block {start, loop start, loop end, end} (s_memtime)
 };

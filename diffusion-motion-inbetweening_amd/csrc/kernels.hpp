@@ -66,7 +66,10 @@ hipError_t launch_attention_bwd(const float* qkv, const float* o_fwd, const floa
 hipError_t launch_layernorm(const float* x, const float* gamma, const float* beta, float* y,
                             _Float16* y_split, int* range_flag,
                             float* stats /* [rows][2] mean,rstd or null */, int rows, int d,
-                            hipStream_t stream);
+                            hipStream_t stream, const _Float16* x_split_in = nullptr /* read split rows instead of x */);
+// W' = W diag(gamma), c1 = row sums of W', c2 = W beta + bias: LayerNorm folded into the GEMM that consumes it
+hipError_t launch_fold_ln(const float* W, const float* gamma, const float* beta, const float* bias, float* Wf, float* c1,
+                          float* c2, int N, int K, hipStream_t stream);
 // dx = LN backward of dy (optionally + extra residual gradient dres added to the result)
 hipError_t launch_layernorm_bwd(const float* x, const float* stats, const float* gamma,
                                 const float* dy, float* dx, _Float16* dx_split /* optional */,

@@ -312,6 +312,21 @@ def test_forward_text_cfg_vs_reference(cases, precision):
             (key, max_abs(mine, g[key]), rel_l2(mine, g[key]))
 
 
+@pytest.mark.parametrize("fold", ["0", "1"])
+def test_forward_layernorm_schedules(cases, monkeypatch, fold):
+    """f16x3 forward with the LayerNorms folded into their consuming GEMMs (default: no LayerNorm pass, the residual stream
+    travels pre-LayerNorm with per-row partial statistics) and with the separate LayerNorm kernels (CMDI_LN_FOLD=0): both
+    meet the reference's golden outputs at the same tolerance, and agree with each other far below it."""
+    monkeypatch.setenv("CMDI_LN_FOLD", fold)
+    case = cases.CASES["fwd_text"]
+    inp = cases.make_inputs(case)
+    model, _ = make_model(case, cfg=True, precision="f16x3")
+    g = load_golden("fwd_text")
+    out = model(tt(inp["x"]), tt(inp["t"]), y={"text_embed": tt(inp["enc_text"]), "text_scale": tt(inp["text_scale"])})
+    out = out.cpu().numpy()
+    assert max_abs(out, g["out_cfg"]) <= 2e-4 and rel_l2(out, g["out_cfg"]) <= 2e-5, (max_abs(out, g["out_cfg"]), rel_l2(out, g["out_cfg"]))
+
+
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_vjp_vs_reference_autograd(cases, precision):
     case = cases.CASES["vjp_text_cfg"]
