@@ -266,7 +266,11 @@ def pmc_counters(config: str, precision: str, batch: int, timeout_s: float = 150
                         if r_["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES"}
                 top = max(busy.values())
                 dominant = {d for d, v in busy.items() if v == top}
-                first = next(r_ for r_ in rows if int(r_["Dispatch_Id"]) in dominant)
+                # (with reconstruction guidance the backward dX GEMM of in_proj has the same M*N*K: keep the launches of
+                # the kernel that was dispatched first — the forward one, the launch the HIP events time)
+                first = min((r_ for r_ in rows if int(r_["Dispatch_Id"]) in dominant), key=lambda r_: int(r_["Dispatch_Id"]))
+                dominant = {int(r_["Dispatch_Id"]) for r_ in rows
+                            if int(r_["Dispatch_Id"]) in dominant and r_["Kernel_Name"] == first["Kernel_Name"]}
                 res["pmc_kernel"], res["pmc_grid"] = first["Kernel_Name"][:160], int(first["Grid_Size"])
                 res["pmc_launches"] = len(dominant)
             for c in ctrs:
