@@ -123,6 +123,8 @@ struct cmdi_engine {
     // per-row partial statistics and every LayerNorm is folded into the GEMM that consumes it (gemm_params.hpp);
     // CMDI_LN_FOLD=0 keeps the separate LayerNorm kernels
     int ln_fold = 0;
+    int qkv_head_major = 0;   // folded path: in_proj writes q | k | v head-major for the attention kernel (CMDI_QKV_HEAD_MAJOR=1;
+                              // measured: no gain — attention 36.0 vs 35.1 us, step 2.14 vs 2.07 ms — so off)
     float *partA = nullptr, *partB = nullptr;   // [M][16][2] partial statistics of pre1 / pre2
     int io_pipe = 0;   // 1: software-pipelined input / output projection GEMMs
     // f16x3: input / output projections on the f16 pipe too (frame rows split by pose_rows_split_kernel, token and
@@ -257,6 +259,7 @@ int run_layers(cmdi_engine* e, int seq0, int nseq, bool keep, bool prof, hipStre
             {   // qkv = in_proj(LN2_prev(P))
                 H3Params p = hp(tokS, prev ? w.in_wsf : w.in_ws, prev ? w.in_c2 : w.in_b, nullptr, qkvS, 3 * d, d);
                 if (prev) { p.ln_part = partB; p.ln_c1 = w.in_c1; }
+                p.cs_head_major = e->qkv_head_major;
                 HIPCHK(launch_gemm_h3(H3_PLAIN_SPLIT, p, e->h3_tile_qkv, s));
             }
             if (prof) {
@@ -264,7 +267,8 @@ int run_layers(cmdi_engine* e, int seq0, int nseq, bool keep, bool prof, hipStre
                 e->ev_used += 2;
                 e->prof_m = M; e->prof_n = 3 * d; e->prof_k = d;
             }
-            HIPCHK(launch_attention_h3(qkvS, nullptr, attnS, e->range_flag, nullptr, nseq, S, e->H, s));
+            HIPCHK(launch_attention_h3(qkvS, nullptr, attnS, e->range_flag, nullptr, nseq, S, e->H, s,
+                                       e->qkv_head_major != 0));
             {   // pre1 = LN2_prev(P) + out_proj(attn)   -> bufHS (+ partial statistics A)
                 H3Params p = hp(attnS, w.out_ws, w.out_b, nullptr, bufHS, d, d);
                 p.Rs = tokS;
@@ -817,6 +821,7 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
     e->ln_fuse = env_probe("CMDI_LN_FUSE", 0) && desc->d_model == 512;
     e->io_h3 = e->precision == CMDI_PREC_F16X3 && !e->ln_fuse && env_probe("CMDI_IO_H3", 1);
     e->ln_fold = e->io_h3 && desc->d_model == 512 && env_int("CMDI_LN_FOLD", 1);
+    e->qkv_head_major = env_int("CMDI_QKV_HEAD_MAJOR", 0);
     const int d = e->d, f = e->f, C = e->C;
     const size_t nseq = 2 * (size_t)e->Bmax, Smax = e->Tmax + 1, Mmax = nseq * Smax;
     *out = e;  // so that cmdi_destroy can free a half-built engine

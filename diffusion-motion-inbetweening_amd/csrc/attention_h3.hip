@@ -35,6 +35,7 @@ constexpr int ROWB = 512;                // bytes of one head of one token: 4 ch
 constexpr int TILE = KBLK * ROWB;        // 16 KiB per K or V tile
 constexpr int STAGE = 2 * TILE;
 constexpr int NSTG = 4;                  // LDS ring: 3 stages (96 KiB) in flight ahead of the one being used
+constexpr int kAttnSplitDefault = 0;     // see launch_attention_h3 (measured: 36.7 vs 35.1 us per layer — no gain, so off)
 
 typedef short s4v __attribute__((ext_vector_type(4)));
 typedef short s8v __attribute__((ext_vector_type(8)));
@@ -45,11 +46,12 @@ typedef short s8v __attribute__((ext_vector_type(8)));
 // 4 different 64-B quarters).
 __device__ __forceinline__ int kswz(int k) { return ((k & 3) << 2) | ((k >> 2) & 3); }
 
+template <int NW = NWAVE>
 __device__ __forceinline__ void stage_kv(char* stage, const _Float16* __restrict__ base, size_t ld,
-                                         int koff, int voff, int key0, int S, int wave, int lane) {
+                                         long koff, long voff, int key0, int S, int wave, int lane) {
 #pragma unroll
-    for (int it = 0; it < 32 / NWAVE; ++it) {
-        const int pc = it * NWAVE + wave;        // 0..15 K pieces, 16..31 V pieces (2 keys each)
+    for (int it = 0; it < 32 / NW; ++it) {
+        const int pc = it * NW + wave;           // 0..15 K pieces, 16..31 V pieces (2 keys each)
         const int mat = pc >> 4, g = pc & 15;
         const int kl = 2 * g + (lane >> 5);
         const int t = (lane & 31) ^ kswz(kl);
@@ -69,13 +71,17 @@ __device__ __forceinline__ h8 tr_pair(const char* p0, const char* p1) {
 }
 }  // namespace
 
-template <bool STASH>
-__global__ __launch_bounds__(64 * NWAVE, 2) void attention_h3_kernel(const _Float16* __restrict__ qkv,
+// NW waves per block (32 queries each) and an LDS ring of NS K/V stages.  (8, 4): one block per (sequence, head) and per
+// CU, K / V staged once, three stages in flight.  (4, 2): the queries of a (sequence, head) are split over two blocks of
+// 4 waves with a 64-KiB ring each, so TWO blocks share a CU and one's load bursts / epilogue sit under the other's key
+// loop (the pair lands on one XCD: block ids differ by gridDim.x, a multiple of 8, so the second K / V read hits its L2).
+template <bool STASH, int NW = NWAVE, int NS = NSTG>
+__global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const _Float16* __restrict__ qkv,
                                                               float* __restrict__ out,
                                                               _Float16* __restrict__ out_s,
                                                               int* __restrict__ range_flag,
                                                               float* __restrict__ row_stats, int S,
-                                                              int H, float scale, int dbg_arg) {
+                                                              int H, float scale, int dbg_arg, long head_rows) {
 #ifdef CMDI_PROBES
     const int dbg = dbg_arg;   // bench-only ablations / cycle stamps (probes build only, see gemm_h3.hpp)
 #else
@@ -88,10 +94,16 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void attention_h3_kernel(const _Floa
     const int d_model = H * DH;
     long long t0 = 0, t1 = 0, t2 = 0;
     if (dbg & 16) t0 = __builtin_readcyclecounter();
-    const size_t ld = 6 * (size_t)d_model;           // halves per token row of the split qkv
-    const int qoff = 2 * h * DH, koff = 2 * (d_model + h * DH), voff = 2 * (2 * d_model + h * DH);
+    // token-major qkv: row = token, 6 d halves, q | k | v column blocks.  head_rows > 0: HEAD-major (written so by the
+    // in_proj epilogue, gemm_params.hpp cs_head_major): operand w of head h is its own [head_rows][256-half] matrix, so
+    // the K / V of a (sequence, head) are one contiguous 100-KB stream each instead of 512-B pieces 6 KiB apart
+    const size_t ld = head_rows ? 256 : 6 * (size_t)d_model;     // halves per token row
+    const long hm = head_rows * 256;                              // halves per head matrix
+    const long qoff = head_rows ? (long)(0 * H + h) * hm : 2 * h * DH;
+    const long koff = head_rows ? (long)(1 * H + h) * hm : 2 * (d_model + h * DH);
+    const long voff = head_rows ? (long)(2 * H + h) * hm : 2 * (2 * d_model + h * DH);
     const _Float16* base = qkv + (size_t)b * S * ld;
-    const int q0 = (blockIdx.y * NWAVE + wave) * 32;
+    const int q0 = (blockIdx.y * NW + wave) * 32;
     const bool active = q0 < S;                      // wave-uniform
     const int nkb = (S + KBLK - 1) / KBLK;
 
@@ -130,22 +142,22 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void attention_h3_kernel(const _Floa
 
     // K/V of a whole (sequence, head) is only 7 stages, each a fabric round trip: keep NSTG - 1 stages
     // in flight (counted vmcnt, raw barrier) so the loop is not one memory latency per 32 keys.
-    constexpr int PCS = 32 / NWAVE;   // LDS-DMA pieces per wave per stage
+    constexpr int PCS = 32 / NW;   // LDS-DMA pieces per wave per stage
 #pragma unroll
-    for (int st = 0; st < NSTG - 1; ++st)
-        if (st < nkb) stage_kv(lds + st * STAGE, base, ld, koff, voff, st * KBLK, S, wave, lane);
+    for (int st = 0; st < NS - 1; ++st)
+        if (st < nkb) stage_kv<NW>(lds + st * STAGE, base, ld, koff, voff, st * KBLK, S, wave, lane);
     {
-        const int ahead = (nkb - 1 < NSTG - 2 ? nkb - 1 : NSTG - 2);   // stages allowed to stay in flight
+        const int ahead = (nkb - 1 < NS - 2 ? nkb - 1 : NS - 2);   // stages allowed to stay in flight
         if (ahead >= 2) wait_vmcnt<2 * PCS>(); else if (ahead == 1) wait_vmcnt<PCS>(); else wait_vmcnt<0>();
     }
     __builtin_amdgcn_s_barrier();
     if (dbg & 16) t1 = __builtin_readcyclecounter();
 
     for (int kb = 0; kb < nkb; ++kb) {
-        const int cur = kb % NSTG;
-        if (kb + NSTG - 1 < nkb)
-            stage_kv(lds + ((kb + NSTG - 1) % NSTG) * STAGE, base, ld, koff, voff, (kb + NSTG - 1) * KBLK, S,
-                     wave, lane);
+        const int cur = kb % NS;
+        if (kb + NS - 1 < nkb)
+            stage_kv<NW>(lds + ((kb + NS - 1) % NS) * STAGE, base, ld, koff, voff, (kb + NS - 1) * KBLK, S,
+                         wave, lane);
         if (active) {
             const char* kt = lds + cur * STAGE;
             const char* vt = kt + TILE;
@@ -232,7 +244,7 @@ __global__ __launch_bounds__(64 * NWAVE, 2) void attention_h3_kernel(const _Floa
             }
         }
         {   // stage kb+1 must have landed; later stages may stay in flight across the barrier
-            const int last = nkb - 1 < kb + NSTG - 1 ? nkb - 1 : kb + NSTG - 1;   // newest stage issued
+            const int last = nkb - 1 < kb + NS - 1 ? nkb - 1 : kb + NS - 1;   // newest stage issued
             const int ahead = last - (kb + 1);
             if (ahead >= 2) wait_vmcnt<2 * PCS>(); else if (ahead == 1) wait_vmcnt<PCS>(); else wait_vmcnt<0>();
         }
@@ -716,36 +728,48 @@ hipError_t launch_attention_bwd_h3(const _Float16* qkv_split, const float* o_fwd
     return hipGetLastError();
 }
 
-// (bench-only: with dbg & 16 and STASH == false, row_stats receives 4 cycle stamps per block)
-hipError_t launch_attention_h3(const _Float16* qkv_split, float* out, _Float16* out_split,
-                               int* range_flag, float* row_stats, int n_seq, int S, int H,
-                               hipStream_t stream) {
-    if (S < 1 || S > 224) return hipErrorInvalidValue;
-    dim3 grid(n_seq * H, (S + 32 * NWAVE - 1) / (32 * NWAVE));
+template <int NW, int NS>
+static hipError_t launch_attention_h3_cfg(const _Float16* qkv_split, float* out, _Float16* out_split, int* range_flag,
+                                          float* row_stats, int n_seq, int S, int H, int dbg, long head_rows,
+                                          hipStream_t stream) {
+    dim3 grid(n_seq * H, (S + 32 * NW - 1) / (32 * NW));
     const float scale = 1.0f / sqrtf((float)DH);
-    constexpr size_t lds = (size_t)NSTG * STAGE;  // 128 KiB: one block per CU
-#ifdef CMDI_PROBES
-    static const int dbg = std::getenv("CMDI_ATTN_DBG") ? std::atoi(std::getenv("CMDI_ATTN_DBG")) : 0;
-#else
-    constexpr int dbg = 0;
-#endif
+    constexpr size_t lds = (size_t)NS * STAGE;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_h3_kernel<true>),
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_h3_kernel<true, NW, NS>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_h3_kernel<false>),
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_h3_kernel<false, NW, NS>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e1 != hipSuccess) return e1;
         if (e2 != hipSuccess) return e2;
         attr_done = true;
     }
     if (row_stats && !(dbg & 16))
-        hipLaunchKernelGGL(attention_h3_kernel<true>, grid, dim3(64 * NWAVE), lds, stream, qkv_split,
-                           out, out_split, range_flag, row_stats, S, H, scale, dbg);
+        hipLaunchKernelGGL((attention_h3_kernel<true, NW, NS>), grid, dim3(64 * NW), lds, stream, qkv_split,
+                           out, out_split, range_flag, row_stats, S, H, scale, dbg, head_rows);
     else
-        hipLaunchKernelGGL(attention_h3_kernel<false>, grid, dim3(64 * NWAVE), lds, stream, qkv_split,
-                           out, out_split, range_flag, row_stats, S, H, scale, dbg);
+        hipLaunchKernelGGL((attention_h3_kernel<false, NW, NS>), grid, dim3(64 * NW), lds, stream, qkv_split,
+                           out, out_split, range_flag, row_stats, S, H, scale, dbg, head_rows);
     return hipGetLastError();
+}
+
+// (bench-only: with dbg & 16 and STASH == false, row_stats receives 4 cycle stamps per block)
+hipError_t launch_attention_h3(const _Float16* qkv_split, float* out, _Float16* out_split,
+                               int* range_flag, float* row_stats, int n_seq, int S, int H,
+                               hipStream_t stream, bool head_major) {
+    if (S < 1 || S > 224) return hipErrorInvalidValue;
+    const long head_rows = head_major ? (long)n_seq * S : 0;
+#ifdef CMDI_PROBES
+    static const int dbg = std::getenv("CMDI_ATTN_DBG") ? std::atoi(std::getenv("CMDI_ATTN_DBG")) : 0;
+#else
+    constexpr int dbg = 0;
+#endif
+    // schedule: CMDI_ATTN_SPLIT = 1 -> two 4-wave blocks per (sequence, head), two blocks per CU; 0 -> one 8-wave block
+    static const int split = std::getenv("CMDI_ATTN_SPLIT") ? std::atoi(std::getenv("CMDI_ATTN_SPLIT")) : kAttnSplitDefault;
+    if (split && S > 128)
+        return launch_attention_h3_cfg<4, 2>(qkv_split, out, out_split, range_flag, row_stats, n_seq, S, H, dbg, head_rows, stream);
+    return launch_attention_h3_cfg<NWAVE, NSTG>(qkv_split, out, out_split, range_flag, row_stats, n_seq, S, H, dbg, head_rows, stream);
 }
 
 }  // namespace cmdi

@@ -580,6 +580,9 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
                         overflow |= !(fabsf(v[e]) < 65504.0f);
                     }
                     _Float16* dst = p.Cs + (size_t)m * (p.cs_ld ? p.cs_ld : 2 * p.N) + npos;
+                    if constexpr (EPI == H3_PLAIN_SPLIT) {
+                        if (p.cs_head_major) dst = p.Cs + ((size_t)(n >> 7) * M + m) * 256 + split_pos(n & 127);
+                    }
                     *reinterpret_cast<h4*>(dst) = oh;
                     *reinterpret_cast<h4*>(dst + 32) = ol;
                 }

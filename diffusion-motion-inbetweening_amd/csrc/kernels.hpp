@@ -47,9 +47,10 @@ hipError_t launch_attention_fwd(const float* qkv, float* out, _Float16* out_spli
                                 float* row_stats, int n_seq, int S, int H, hipStream_t stream);
 // ---- attention_h3.hip (split-f16 products, fp32-equivalent) -------------------------------------
 // qkv_split: split rows [M, 2*3d] (gemm_h3.hpp format); outputs as launch_attention_fwd
+// head_major: qkv_split was written by a GEMM with cs_head_major (gemm_params.hpp) over exactly these n_seq * S rows
 hipError_t launch_attention_h3(const _Float16* qkv_split, float* out, _Float16* out_split,
                                int* range_flag, float* row_stats, int n_seq, int S, int H,
-                               hipStream_t stream);
+                               hipStream_t stream, bool head_major = false);
 // backward on the f16 pipe: everything in split rows except o_fwd / d_out (fp32, for D = rowsum(dO*O))
 hipError_t launch_attention_bwd_h3(const _Float16* qkv_split, const float* o_fwd, const float* row_stats,
                                    const float* d_out, const _Float16* d_out_split, _Float16* d_qkv_split,
