@@ -13,6 +13,7 @@ using H128x64s3 = H3Tile<128, 64, 2, 2, 3, 2>;      // 72 KiB, 2 blocks/CU
 using H64x128s2 = H3Tile<64, 128, 2, 2, 2, 2>;      // 32x64 per wave
 using H128x128w8s3 = H3Tile<128, 128, 4, 2, 3, 2>;  // 8 waves, 32x64 per wave, 96 KiB
 using H128x128w8s2 = H3Tile<128, 128, 4, 2, 2, 2>;  // 8 waves, 64 KiB, 2 blocks/CU (16 waves)
+using H128x128w8s2L = H3Tile<128, 128, 4, 2, 2, 2, 1>;  // the same, LDS-DMA requests issued among the trailing MFMAs
 using H128x256s2 = H3Tile<128, 256, 2, 4, 2, 2>;    // 8 waves, 64x64 per wave, 96 KiB
 using H64x128w8s2 = H3Tile<64, 128, 2, 4, 2, 2>;    // 8 waves, 32x32 per wave: the tail tile of the mixed grid
 using H64x512ln = H3Tile<64, 512, 2, 4, 2, 2>;      // 8 waves, 32x128 per wave: full rows of d = 512 (LN fused)
@@ -83,6 +84,7 @@ static hipError_t launch_h3_tiles(const H3Params& p, int tile, hipStream_t s) {
         case 10: return launch_h3_one<H256x128w16, EPI>(p, s);
         case 11: return launch_h3_one<H128x256w16, EPI>(p, s);
         case 20: return launch_h3_mixed<EPI>(p, s);
+        case 30: return launch_h3_one<H128x128w8s2L, EPI>(p, s);
         case 21: return launch_h3_one<H64x128w8s2, EPI>(p, s);
         default: return hipErrorInvalidValue;
     }

@@ -56,9 +56,12 @@ __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
     lo = (_Float16)((x - (float)hi) * kLoScale);
 }
 
-template <int BM_, int BN_, int WM_, int WN_, int NSTAGE_, int MINW_>
+// LATE_ = 1: the LDS-DMA requests of the next K step are issued BETWEEN the trailing MFMAs of this one (one piece per
+// MFMA) instead of in front of the fragment reads — an LDS-DMA piece costs 60 cycles of issue among bare MFMAs but
+// 100-185 inside a phase that also carries the fragment reads (MI355X_MICROARCH.md, per-instruction constants).
+template <int BM_, int BN_, int WM_, int WN_, int NSTAGE_, int MINW_, int LATE_ = 0>
 struct H3Tile {
-    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, NSTAGE = NSTAGE_, MINW = MINW_;
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, NSTAGE = NSTAGE_, MINW = MINW_, LATE = LATE_;
     static constexpr int BK = 32;                  // columns per K step = one 128-B line per row
     static constexpr int NW = WM * WN, NT = 64 * NW;
     static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -130,10 +133,14 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
         grow = grow < p.N ? grow : p.N - 1;
         w_src[q] = p.W + (size_t)grow * ldk + ((pslot ^ ((row >> 1) & 7)) << 3);
     }
+    // plain GEMM: chunk kt of the row; convolution: tap kt / cpt = one row further, chunk kt % cpt.  (cpt = "never" for
+    // the plain case keeps the address arithmetic branch-free: the requests then sit in the same scheduling region as
+    // the MFMAs around them)
+    const int cpt = p.cpt ? p.cpt : 0x40000000;
     auto issue = [&](int kt, int buf) {
         char* stage = lds + buf * STAGE;
-        // plain GEMM: chunk kt of the row; convolution: tap kt / cpt = one row further, chunk kt % cpt
-        const size_t a_off = p.cpt ? (size_t)(kt / p.cpt) * lda + (size_t)(kt % p.cpt) * 64 : (size_t)kt * 64;
+        const int tap = kt / cpt;
+        const size_t a_off = (size_t)tap * lda + (size_t)(kt - tap * cpt) * 64;
 #pragma unroll
         for (int q = 0; q < BM / 8 / NW; ++q)
             __builtin_amdgcn_global_load_lds(
@@ -190,7 +197,9 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
     int cur = 0, nxt = NSTAGE - 1;   // stage being multiplied / stage being filled
     for (int kt = kt0; kt < nk; ++kt) {
         const bool more = kt + NSTAGE - 1 < nk;
-        if (more && !(CMDI_DBG(p) & 1)) issue(kt + NSTAGE - 1, nxt);
+        if constexpr (!TC::LATE) {
+            if (more && !(CMDI_DBG(p) & 1)) issue(kt + NSTAGE - 1, nxt);
+        }
         const char* st = lds + cur * STAGE;
         h8 ah[2][TM], al[2][TM], wh[2][TN], wl[2][TN];
 #pragma unroll
@@ -232,10 +241,22 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
+        if constexpr (TC::LATE) {
+            // branch-free: past the last K step the requests re-fetch a valid step into the stage nobody reads again
+            issue(more ? kt + NSTAGE - 1 : nk - 1, nxt);
+            constexpr int REST = 6 * TM * TN - 2 * (TM + TN);
+            static_assert(REST >= PW + 1, "not enough trailing MFMAs to carry the DMA pieces");
+            __builtin_amdgcn_sched_group_barrier(0x008, REST - PW, 0);
+#pragma unroll
+            for (int q = 0; q < PW; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // (LDS-DMA counts as VMEM, not as a "VMEM read")
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
+        } else
         __builtin_amdgcn_sched_group_barrier(0x008, 6 * TM * TN - 2 * (TM + TN), 0);
         // stage kt+1 must have landed (this wave's pieces; the barrier extends it to every wave's);
         // with 3 stages the pieces of stage kt+2, issued above, stay in flight across the barrier
-        if (NSTAGE == 3 && more) wait_vmcnt<PW>(); else wait_vmcnt<0>();
+        if (NSTAGE == 3 && (more || TC::LATE)) wait_vmcnt<PW>(); else wait_vmcnt<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         cur = cur + 1 == NSTAGE ? 0 : cur + 1;
