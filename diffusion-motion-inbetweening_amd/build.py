@@ -23,7 +23,10 @@ PROBES_LIB_PATH = CSRC / "libcondmdi_hip_probes.so"
 
 # translation unit -> extra flags
 UNITS = {
-    "api.hip": [],
+    "api_engine.hip": [],
+    "api_denoiser.hip": [],
+    "api_sampler.hip": [],
+    "api_hooks.hip": [],
     "gemm_f32.hip": [],
     "gemm_h3.hip": [],
     "gemm_x6.hip": [],

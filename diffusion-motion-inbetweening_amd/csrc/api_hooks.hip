@@ -1,0 +1,222 @@
+// C-ABI of libcondmdi_hip.so, test hooks: single-kernel entry points the parity tests call (GEMMs, attention, operand
+// packing, Philox), the CLIP text tower handle, precision / range queries.
+#include "engine.hpp"
+
+using namespace cmdi;
+using namespace cmdi::host;
+
+extern "C" {
+
+int cmdi_gemm_nt(const float* d_a, const float* d_w, const float* d_bias, const float* d_resid,
+                 float* d_c, int32_t m, int32_t n, int32_t k, int32_t epi, int32_t tile,
+                 cmdi_stream stream) {
+    if (!d_a || !d_w || !d_c) return fail(CMDI_E_INVALID, "null tensor");
+    if (k % 32 != 0 || n % 32 != 0) return fail(CMDI_E_INVALID, "K and N must be multiples of 32");
+    GemmKind kind;
+    switch (epi) {
+        case 0: kind = GK_PLAIN; break;
+        case 1: kind = GK_GELU; break;
+        case 3: kind = GK_RESID; break;
+        default: return fail(CMDI_E_INVALID, "epi must be 0 (bias), 1 (bias+gelu) or 3 (bias+residual)");
+    }
+    if (kind == GK_RESID && !d_resid) return fail(CMDI_E_INVALID, "residual epilogue needs d_resid");
+    GemmParams p = gp(d_a, d_w, d_bias, d_c, m, n, k, k, k, n);
+    p.R = d_resid;
+    hipError_t err = launch_gemm(kind, p, tile, static_cast<hipStream_t>(stream));
+    if (err != hipSuccess) return fail(CMDI_E_HIP, std::string("launch_gemm: ") + hipGetErrorString(err));
+    return CMDI_OK;
+}
+
+struct cmdi_clip_text { ClipText* t; };
+
+int cmdi_clip_create(const cmdi_clip_desc* desc, cmdi_clip_handle* out) {
+    if (!desc || !out) return fail(CMDI_E_INVALID, "null argument");
+    ClipText* t = clip_new(desc->vocab_size, desc->width, desc->heads, desc->layers, desc->context, desc->embed_dim,
+                           desc->max_batch);
+    if (clip_error(t)[0]) {
+        const std::string msg = clip_error(t);
+        clip_free(t);
+        return fail(msg.find("hipMalloc") != std::string::npos ? CMDI_E_NOMEM : CMDI_E_INVALID, msg);
+    }
+    *out = new cmdi_clip_text{t};
+    return CMDI_OK;
+}
+
+int cmdi_clip_destroy(cmdi_clip_handle h) {
+    if (!h) return CMDI_OK;
+    clip_free(h->t);
+    delete h;
+    return CMDI_OK;
+}
+
+int cmdi_clip_load_weight(cmdi_clip_handle h, const char* name, const float* d_src, int64_t numel, cmdi_stream stream) {
+    if (!h || !name || !d_src) return fail(CMDI_E_INVALID, "null argument");
+    const int rc = clip_load_weight(h->t, name, d_src, numel, static_cast<hipStream_t>(stream));
+    if (rc != 0) return fail(rc == -5 ? CMDI_E_UNKNOWN_WEIGHT : rc == -3 ? CMDI_E_HIP : CMDI_E_INVALID, clip_error(h->t));
+    return CMDI_OK;
+}
+
+int cmdi_clip_encode_text(cmdi_clip_handle h, const int32_t* d_tokens, int32_t batch, float* d_out, cmdi_stream stream) {
+    if (!h || !d_tokens || !d_out) return fail(CMDI_E_INVALID, "null argument");
+    const int rc = clip_encode_text(h->t, d_tokens, batch, d_out, static_cast<hipStream_t>(stream));
+    if (rc != 0) return fail(rc == -3 ? CMDI_E_HIP : CMDI_E_INVALID, clip_error(h->t));
+    return CMDI_OK;
+}
+
+int cmdi_pack_x6(const float* d_src, void* d_dst, int64_t rows, int32_t cols, cmdi_stream stream) {
+    if (!d_src || !d_dst || rows < 1 || cols < 32 || cols % 32 != 0)
+        return fail(CMDI_E_INVALID, "bad argument (cols must be a positive multiple of 32)");
+    HIPCHK(launch_pack_x6(d_src, d_dst, rows, cols, cols, static_cast<hipStream_t>(stream)));
+    return CMDI_OK;
+}
+
+int cmdi_gemm_x6(const float* d_a, const void* d_w_packed, const float* d_bias, const float* d_resid, float* d_c,
+                 int32_t m, int32_t n, int32_t k, int32_t epi, int32_t variant, cmdi_stream stream) {
+    if (!d_a || !d_w_packed || !d_c) return fail(CMDI_E_INVALID, "null tensor");
+    GemmKind kind;
+    switch (epi) {
+        case 0: kind = GK_PLAIN; break;
+        case 1: kind = GK_GELU; break;
+        case 3: kind = GK_RESID; break;
+        default: return fail(CMDI_E_INVALID, "epi must be 0 (bias), 1 (bias+gelu) or 3 (bias+residual)");
+    }
+    if (kind == GK_RESID && !d_resid) return fail(CMDI_E_INVALID, "residual epilogue needs d_resid");
+    GemmParams p = gp(d_a, nullptr, d_bias, d_c, m, n, k, k, k, n);
+    p.R = d_resid;
+    p.Wx = d_w_packed;
+    if (!gemm_x6_supports(kind, p)) return fail(CMDI_E_INVALID, "bf16x6 GEMM needs K % 32 == 0 and N % 4 == 0");
+    hipError_t err = launch_gemm_x6(kind, p, static_cast<hipStream_t>(stream), variant);
+    if (err != hipSuccess) return fail(CMDI_E_HIP, std::string("launch_gemm_x6: ") + hipGetErrorString(err));
+    return CMDI_OK;
+}
+
+int cmdi_attention_fwd(const float* d_qkv, float* d_out, int32_t n_seq, int32_t seq_len,
+                       int32_t n_heads, cmdi_stream stream) {
+    if (!d_qkv || !d_out || n_seq < 1 || seq_len < 1 || seq_len > 224 || n_heads < 1)
+        return fail(CMDI_E_INVALID, "bad argument");
+    HIPCHK(launch_attention_fwd(d_qkv, d_out, nullptr, nullptr, nullptr, n_seq, seq_len, n_heads,
+                                static_cast<hipStream_t>(stream)));
+    return CMDI_OK;
+}
+
+int cmdi_precision(cmdi_handle e) { return e ? e->precision : CMDI_E_INVALID; }
+
+int cmdi_range_status(cmdi_handle e, int32_t* out_flag, cmdi_stream stream) {
+    if (!e || !out_flag) return fail(CMDI_E_INVALID, "null argument");
+    *out_flag = 0;
+    if (!e->range_flag) return CMDI_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int flag = 0;
+    HIPCHK(hipMemcpyAsync(&flag, e->range_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (flag) HIPCHK(hipMemsetAsync(e->range_flag, 0, sizeof(int), s));
+    if (e->unet) {
+        int uf = 0;
+        if (unet_range_flag(e->unet, &uf, s) != 0) return fail(CMDI_E_HIP, "UNET: range flag read-back failed");
+        flag |= uf;
+    }
+    *out_flag = flag;
+    return CMDI_OK;
+}
+
+int cmdi_split_f16(const float* d_src, void* d_dst, int64_t rows, int32_t cols, cmdi_stream stream) {
+    if (!d_src || !d_dst || rows < 1 || cols < 32 || cols % 32 != 0)
+        return fail(CMDI_E_INVALID, "bad argument (cols must be a positive multiple of 32)");
+    HIPCHK(launch_split_f16(d_src, static_cast<_Float16*>(d_dst), rows, cols, cols, nullptr,
+                            static_cast<hipStream_t>(stream)));
+    return CMDI_OK;
+}
+
+int cmdi_gemm_h3(const void* d_a_split, const void* d_w_split, const float* d_bias,
+                 const float* d_resid, float* d_c, void* d_c_split, int32_t m, int32_t n, int32_t k,
+                 int32_t epi, int32_t tile, cmdi_stream stream) {
+    if (!d_a_split || !d_w_split) return fail(CMDI_E_INVALID, "null tensor");
+    if (k % 32 != 0 || n % 32 != 0) return fail(CMDI_E_INVALID, "K and N must be multiples of 32");
+    H3Params p{};
+    p.A = static_cast<const _Float16*>(d_a_split);
+    p.W = static_cast<const _Float16*>(d_w_split);
+    p.bias = d_bias; p.C = d_c; p.Cs = static_cast<_Float16*>(d_c_split); p.R = d_resid;
+    p.M = m; p.N = n; p.K = k; p.ldc = n;
+#ifdef CMDI_PROBES
+    { const char* v = std::getenv("CMDI_H3_DBG"); p.dbg = v ? std::atoi(v) : 0; }
+    if (p.dbg & 16) {   // bench-only: the timestamp buffer rides in d_resid's place when epi != 3
+        p.dbg_buf = (epi != 3) ? reinterpret_cast<long long*>(const_cast<float*>(d_resid)) : nullptr;
+        if (epi != 3) p.R = nullptr;
+    }
+#endif
+    int kind;
+    switch (epi) {
+        case 0: kind = d_c_split ? H3_PLAIN_SPLIT : H3_PLAIN; break;
+        case 1: kind = H3_GELU_SPLIT; break;
+        case 3: kind = H3_RESID; break;
+        case 4: kind = H3_RESID; p.R = nullptr; p.Rs = reinterpret_cast<const _Float16*>(d_resid); break;
+        default: return fail(CMDI_E_INVALID, "epi must be 0 (bias), 1 (bias+gelu, split output), 3 (bias+residual) or 4 (bias + split-rows residual)");
+    }
+    if ((kind == H3_PLAIN || kind == H3_RESID) && !d_c) return fail(CMDI_E_INVALID, "fp32 output needs d_c");
+    if ((kind == H3_GELU_SPLIT || kind == H3_PLAIN_SPLIT) && !d_c_split)
+        return fail(CMDI_E_INVALID, "split output needs d_c_split");
+    if (kind == H3_RESID && !d_resid) return fail(CMDI_E_INVALID, "residual epilogue needs d_resid");
+    hipError_t err = launch_gemm_h3(kind, p, tile, static_cast<hipStream_t>(stream));
+    if (err != hipSuccess) return fail(CMDI_E_HIP, std::string("launch_gemm_h3: ") + hipGetErrorString(err));
+    return CMDI_OK;
+}
+
+int cmdi_conv_rows_h3(const void* d_a_split, int32_t a_ld, const void* d_w_split, const float* d_bias,
+                      const float* d_resid, float* d_c, void* d_c_split, int32_t m, int32_t n, int32_t cin,
+                      int32_t taps, int32_t pad, int32_t a_row_mul, int32_t c_row_mul, int32_t c_row_add,
+                      int32_t tp, int32_t t_lo, int32_t t_hi, int32_t tile, cmdi_stream stream) {
+    if (!d_a_split || !d_w_split || (!d_c && !d_c_split)) return fail(CMDI_E_INVALID, "null tensor");
+    if (cin % 32 != 0 || n % 32 != 0 || taps < 1 || a_ld < 2 * cin)
+        return fail(CMDI_E_INVALID, "cin and n must be multiples of 32, a_ld >= 2 * cin");
+    H3Params p{};
+    p.A = static_cast<const _Float16*>(d_a_split) - (ptrdiff_t)pad * a_ld;
+    p.W = static_cast<const _Float16*>(d_w_split);
+    p.bias = d_bias; p.C = d_c; p.Cs = static_cast<_Float16*>(d_c_split); p.R = d_resid;
+    p.M = m; p.N = n; p.K = taps * cin; p.ldc = n;
+    p.a_ld = a_ld; p.a_row_mul = a_row_mul; p.taps = taps; p.cpt = cin / 32;
+    p.c_row_mul = c_row_mul; p.c_row_add = c_row_add; p.tp = tp; p.t_lo = t_lo; p.t_hi = t_hi;
+    const int kind = d_c_split ? H3_PLAIN_SPLIT : (d_resid ? H3_RESID : H3_PLAIN);
+    hipError_t err = launch_gemm_h3(kind, p, tile, static_cast<hipStream_t>(stream));
+    if (err != hipSuccess) return fail(CMDI_E_HIP, std::string("launch_gemm_h3: ") + hipGetErrorString(err));
+    return CMDI_OK;
+}
+
+int cmdi_gemm_h3_ln(const void* d_a_split, const void* d_w_split, const float* d_bias,
+                    const float* d_resid, const float* d_gamma, const float* d_beta, float* d_y,
+                    void* d_y_split, int32_t m, int32_t n, int32_t k, cmdi_stream stream) {
+    if (!d_a_split || !d_w_split || !d_resid || !d_gamma || !d_beta || !d_y)
+        return fail(CMDI_E_INVALID, "null tensor");
+    if (n != 512 || k % 32 != 0) return fail(CMDI_E_INVALID, "the fused LayerNorm epilogue needs N = 512, K % 32 == 0");
+    H3Params p{};
+    p.A = static_cast<const _Float16*>(d_a_split);
+    p.W = static_cast<const _Float16*>(d_w_split);
+    p.bias = d_bias; p.R = d_resid; p.ln_g = d_gamma; p.ln_b = d_beta;
+    p.C = d_y; p.Cs = static_cast<_Float16*>(d_y_split);
+    p.M = m; p.N = n; p.K = k; p.ldc = n;
+    hipError_t err = launch_gemm_h3(H3_RESID_LN, p, 0, static_cast<hipStream_t>(stream));
+    if (err != hipSuccess) return fail(CMDI_E_HIP, std::string("launch_gemm_h3: ") + hipGetErrorString(err));
+    return CMDI_OK;
+}
+
+int cmdi_attention_fwd_h3(const void* d_qkv_split, float* d_out, int32_t n_seq, int32_t seq_len,
+                          int32_t n_heads, cmdi_stream stream) {
+    if (!d_qkv_split || !d_out || n_seq < 1 || seq_len < 1 || seq_len > 224 || n_heads < 1)
+        return fail(CMDI_E_INVALID, "bad argument");
+    // (CMDI_ATTN_DBG & 16, bench only: 32 B of cycle stamps per block are written BEHIND the output,
+    // the caller allocates n_seq * n_heads * 32 extra bytes)
+#ifdef CMDI_PROBES
+    static const bool stamps = std::getenv("CMDI_ATTN_DBG") && (std::atoi(std::getenv("CMDI_ATTN_DBG")) & 16);
+#else
+    constexpr bool stamps = false;
+#endif
+    HIPCHK(launch_attention_h3(static_cast<const _Float16*>(d_qkv_split), d_out, nullptr, nullptr,
+                               stamps ? d_out + (size_t)n_seq * seq_len * n_heads * 128 : nullptr, n_seq, seq_len, n_heads,
+                               static_cast<hipStream_t>(stream)));
+    return CMDI_OK;
+}
+
+void cmdi_philox4x32_10(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]) {
+    philox4x32_10_host(counter, key, out);
+}
+
+}  // extern "C"

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         o.z = rstd * (g[i].z - m1 - xh[i].z * m2);
         o.w = rstd * (g[i].w - m1 - xh[i].w * m2);
         *reinterpret_cast<float4*>(dxr + i * 256 + lane * 4) = o;
-        if (dxs) {   // split rows for the f16-pipe dX GEMMs (gradients: no range flag, see api.hip)
+        if (dxs) {   // split rows for the f16-pipe dX GEMMs (gradients: no range flag, see api_denoiser.hip)
             const float ov[4] = {o.x, o.y, o.z, o.w};
             h4 oh, ol;
 #pragma unroll

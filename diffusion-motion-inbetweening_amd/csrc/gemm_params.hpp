@@ -93,7 +93,7 @@ struct H3Params {
     int cs_ld;          // halves per row of the split output (0 = 2N); Cs may point at a column block of a wider matrix
     int cs_head_major;  // H3_PLAIN_SPLIT: write the output head-major — column block n / 128 (= q|k|v x head) is its own
                         // [M][128] split matrix (512 contiguous bytes per token): what attention_h3 streams per (sequence, head)
-    // ---- LayerNorm folded into the GEMMs around it (no LayerNorm pass, api.hip run_layers) -------------------------------
+    // ---- LayerNorm folded into the GEMMs around it (no LayerNorm pass, api_denoiser.hip run_layers) -------------------------------
     // The residual stream travels as its PRE-LayerNorm value P (split rows) plus per-row partial statistics: for every
     // row 16 x (sum, sum of squared deviations) over its 32-column blocks, written by the producing GEMM's epilogue
     // (out_part) and combined (Chan) by the consumer into (mean, rstd).  A consumer whose A operand is LN(P) multiplies

@@ -495,7 +495,7 @@ def stats_close(got, want, tol):
 def test_baseline_shape_chain_vs_reference(cases, name, precision):
     """BASELINE configs 2 and 3 at their own shape (B=32, T=196, CFG; c3 = imputation + reconstruction guidance),
     20 steps of the 1000-step chain, ragged lengths: p_sample_loop takes the engine's one-call path, which at this
-    size cuts the batch into TWO independent pipelines (api.hip n_parts / part_forward / part_backward) — compared
+    size cuts the batch into TWO independent pipelines (api_sampler.hip n_parts / part_forward / part_backward) — compared
     here with values of the real reference: six stored samples (three per pipeline) and (sum, sum^2) of all 32."""
     case, inp, g, model, diffusion, kw = big_setup(cases, name, precision)
     loop = diffusion.p_sample_loop
