@@ -22,10 +22,14 @@ for (m, n, k, epi, name) in [(12608, 1536, 512, 0, "in_proj"), (12608, 1024, 512
         eng.gemm_h3(a_s, w_s, b, tile=tile, epi=epi, resid=buf, split_out=True, out=out)
     torch.cuda.synchronize()
     raw = buf[:nblk * 6].cpu().numpy().reshape(nblk, 6).astype(np.float64)
-    t = raw[:, :4]
-    ghz = ((raw[:, 3] - raw[:, 0]) / ((raw[:, 5] - raw[:, 4]) * 10.0)).mean()   # ticks per ns
+    # per block: [0] start, [1] (xcc << 32 | hw_id), [2] K-loop cycles, [3] end (shader clock); [4], [5] start / end (100 MHz)
+    life = raw[:, 3] - raw[:, 0]
+    loop = raw[:, 2]
+    ghz = (life / ((raw[:, 5] - raw[:, 4]) * 10.0)).mean()   # ticks per ns
     span_us = (raw[:, 5].max() - raw[:, 4].min()) / 100.0
-    tot = span_us
-    pro, loop, epi_t = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2]
-    print(f"{name}: {nblk} blocks, span {tot:.1f} us, shader clock {ghz:.2f} GHz; per block mean: prologue {pro.mean():.0f}, k-loop {loop.mean():.0f} "
-          f"({loop.mean() / (k // 32):.0f}/step), epilogue {epi_t.mean():.0f}; block life {(t[:,3]-t[:,0]).mean():.0f}")
+    start_us = (raw[:, 4] - raw[:, 4].min()) / 100.0
+    first = start_us < 1.0
+    print(f"{name}: {nblk} blocks, span {span_us:.1f} us, shader clock {ghz:.2f} GHz; per block mean: life {life.mean():.0f} cycles "
+          f"({life.mean() / ghz / 1e3:.1f} us), k-loop {loop.mean():.0f} ({loop.mean() / (k // 32):.0f}/step, {100 * loop.mean() / life.mean():.0f}%), "
+          f"rest {(life - loop).mean():.0f}; first-round blocks ({first.sum()}): life {life[first].mean():.0f}, k-loop {loop[first].mean():.0f}; "
+          f"later: life {life[~first].mean():.0f}, k-loop {loop[~first].mean():.0f}")
