@@ -231,6 +231,9 @@ def pmc_counters(config: str, precision: str, batch: int, timeout_s: float = 150
     tmp = tempfile.mkdtemp(prefix="cmdi_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
     env = dict(os.environ, TMPDIR=tmp, CMDI_GROUPS="1")
     env.pop("CMDI_PROBES_LIB", None)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "MASTER_ADDR", "MASTER_PORT",
+              "TORCHELASTIC_RUN_ID"):   # the counter passes are plain single-process runs
+        env.pop(k, None)
     try:
         # pass 0 identifies the dominant kernel: SQ_VALU_MFMA_BUSY_CYCLES is an exact function of a launch's MFMA count,
         # and the in_proj projection (largest M*N*K of the step) has the largest — its Dispatch_Ids (the launch order is
@@ -353,16 +356,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # launched by torch.distributed.run (the driver's form for N > 1; a 1-process launch takes the same path, so the
+    # process group, the barrier and the collectives are exercised on a single GPU too)
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path exists)"
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    if world > 1:
+    if use_dist:
         dist.init_process_group("nccl", init_method="env://", device_id=dev)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
-    n_ranks_seen = dist.get_world_size() if world > 1 else 1
+    n_ranks_seen = dist.get_world_size() if use_dist else 1
 
     gd, rs, du = sub("diffusion.gaussian_diffusion"), sub("diffusion.respace"), sub("utils.dist_util")
     N = sub("_native")
@@ -407,7 +413,7 @@ def main():
                     recon_w=np.full((n_chain,), 20.0, dtype=np.float32))
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -428,7 +434,7 @@ def main():
         loop()
         barrier()
         elapsed = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
@@ -473,7 +479,7 @@ def main():
         "step_tflops": flop_step / (elapsed / K) / 1e12,
         "step_frac_of_fp32_mfma_peak": flop_step / (elapsed / K) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
         "allgather_ms": gather_ms, "n_ranks_seen": n_ranks_seen,
-        "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if world > 1 else None,
+        "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if use_dist else None,
         "pipeline_parts": eng.pipeline_parts(),
     }
 
@@ -485,7 +491,7 @@ def main():
             pmc_u = REPO / "profiles" / "pmc_unet_conv_gemm.json"
             out["roofline"]["traffic"] = json.loads(pmc_u.read_text()).get("hbm_bytes_per_launch") if pmc_u.exists() else None
             out["roofline"]["traffic_source"] = "profiles/pmc_unet_conv_gemm.json (round 1, not re-measured in this run)"
-    if world > 1:
+    if use_dist:
         dist.barrier()
 
     # the other two arithmetic modes on the same K steps, each with its own driver-timed number and roofline:
@@ -518,7 +524,7 @@ def main():
         out["gpu_over_cpu"] = steps_per_s / out["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

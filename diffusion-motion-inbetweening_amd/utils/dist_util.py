@@ -81,8 +81,8 @@ def all_gather_batch(local: torch.Tensor, n: int) -> torch.Tensor:
     """Reassemble the full batch on every rank: ONE all-gather (RCCL over xGMI on GPUs).  Ranks may
     own slices that differ by one sample, so slices are padded to the largest and trimmed after."""
     rank, world_size = world()
-    if world_size == 1:
-        return local
+    if world_size == 1 and not (dist.is_available() and dist.is_initialized()):
+        return local          # (an initialised 1-rank group still takes the collective: same code path as N > 1)
     sizes = [shard_bounds(n, r, world_size) for r in range(world_size)]
     biggest = max(hi - lo for lo, hi in sizes)
     pad = local

@@ -14,6 +14,8 @@ Stated fp32 tolerances (SURVEY.md §8c asks to state and measure them):
 """
 from types import SimpleNamespace
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -767,6 +769,32 @@ def test_bench_c5_runs_on_one_gpu():
     assert line["config"]["global_batch"] == 1024 and line["config"]["batch_per_gpu"] == 1024
     assert line["value"] > 0 and abs(line["value"] * line["ms_per_step"] - 1000.0) < 1e-6 * 1000
     assert line["roofline"]["frac"] > 0.05 and line["pipeline_parts"] == 2
+
+
+def test_bench_under_torchrun_one_process_uses_rccl():
+    """The driver's multi-GPU launch form (python -m torch.distributed.run ... bench.py --gpus N) with ONE process: the
+    process group (backend nccl = RCCL), the barriers, the max-over-ranks all-reduce and the all-gather of the generated
+    batch all execute on the single GPU, so the 8-GPU run is not the first time that code runs."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from conftest import REPO
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(REPO / "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--no-cpu",
+           "--no-pmc", "--no-f32"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(REPO))
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    line = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["n_ranks_seen"] == 1 and line["steps"] == 4
+    assert line["rccl_version"], "the process group was not initialised"
+    assert line["allgather_ms"] >= 0 and line["value"] > 0
 
 
 # ---- hipGraph replay -----------------------------------------------------------------------------------
