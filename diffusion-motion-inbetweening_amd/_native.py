@@ -42,7 +42,8 @@ CMDI_E_RANGE = -6
 class ModelDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n_layers", "d_model", "d_ff", "n_heads", "n_feats", "max_frames", "max_batch", "pe_rows",
-        "text_cond", "want_grad", "precision", "arch", "unet_added")] + [("unet_mults", C.c_int32 * 4)]
+        "text_cond", "want_grad", "precision", "arch", "unet_added")] + [("unet_mults", C.c_int32 * 4),
+                                                                            ("unet_attention", C.c_int32)]
 
 
 class ClipDesc(C.Structure):

@@ -59,7 +59,7 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
         ALLOC(e->gs_bits, 16);
         if (desc->want_grad) { ALLOC(e->gout, nseq * e->C * e->Tmax); ALLOC(e->gx, nseq * e->C * e->Tmax); }
         e->unet = unet_new(desc->n_feats, desc->unet_added, desc->d_model, desc->unet_mults, (int)nseq,
-                           desc->text_cond != 0, desc->want_grad != 0);
+                           desc->text_cond != 0, desc->want_grad != 0, desc->unet_attention != 0);
         if (unet_error(e->unet)[0]) return fail(CMDI_E_INVALID, std::string("UNET: ") + unet_error(e->unet));
         e->bytes += unet_bytes(e->unet);
         e->pipelines = 0;

@@ -99,7 +99,8 @@ hipError_t launch_transpose_pad(float* dst, const float* src, int rows, int cols
 
 // ---- unet.hip: MDM_UNET denoiser ------------------------------------------------------------------
 struct UnetModel;
-UnetModel* unet_new(int n_feats, int added, int dim, const int mults[4], int max_seq, bool text, bool want_grad);
+UnetModel* unet_new(int n_feats, int added, int dim, const int mults[4], int max_seq, bool text, bool want_grad,
+                    bool attention);
 const char* unet_error(const UnetModel* u);
 int64_t unet_bytes(const UnetModel* u);
 void unet_free(UnetModel* u);

@@ -13,6 +13,8 @@
 //        -> Mish, + residual_conv(x) (1x1 if channels change);  (scale, shift) = Linear(Mish(c))   :163-212
 //   downs x4 [RB, RB, (skip), Conv3 stride 2], mid [RB, RB], ups x3 [cat skip, RB, RB, ConvTranspose4 s2],
 //   final Conv5 -> GN -> Mish -> Conv1(1024 -> 263)                                 :323-345
+//   attention=True: Residual(PreNorm(LinearAttention)) behind the second block of every down / up stage and between
+//   the two middle blocks (:102-156, :262, :273-275, :298; kernels in unet_attention.hpp)
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -23,6 +25,7 @@
 #include "common.hpp"
 #include "gemm_h3.hpp"
 #include "kernels.hpp"
+#include "unet_attention.hpp"
 
 namespace cmdi {
 
@@ -409,6 +412,13 @@ struct GN { float *g = nullptr, *b = nullptr; };
 // what a ResidualTemporalBlock keeps for the input-VJP: both convolution outputs (pre-GroupNorm, possibly as split-K
 // slices) and the GroupNorm statistics
 struct RBStash { float *F1 = nullptr, *F2 = nullptr, *st1 = nullptr, *st2 = nullptr; int n1 = 1, n2 = 1; };
+// one Residual(PreNorm(LinearAttention)) site.  x / stats / qkvf are written by every forward pass and read by the input-VJP.
+struct AttnSite {
+    Conv qkv, out;         // to_qkv: Conv1d(C, 384, 1, bias=False); to_out: Conv1d(128, C, 1)
+    GN norm;               // LayerNorm over the channels: g, b [C]
+    float *x = nullptr, *stats = nullptr, *qkvf = nullptr;   // input rows (fp32), (mean, rstd) per row, q | k | v rows [.][384]
+    int level = 0;
+};
 struct ResBlock {
     Conv c1, c2, res;      // res.w == nullptr: identity residual
     GN n1, n2;
@@ -429,6 +439,10 @@ struct UnetModel {
     ResBlock down[4][2], mid[2], up[3][2];
     Conv downs[3], ups[3], fin, outc;
     GN fin_n;
+    bool attention = false;                     // attention=True: the eight LinearAttention sites below
+    AttnSite at_down[4], at_mid, at_up[3];
+    _Float16 *AYS[4] = {}, *AOS[4] = {}, *AGS[4] = {};   // per level: LayerNorm output / d y (split), core output, d qkv (split)
+    float *AGO[4] = {}, *AGN[4] = {};                    // input-VJP: d (core output) [.][128], d (LayerNorm output) [.][C]
     bool finalized = false;
     // workspace
     float *emb_h = nullptr, *cvec = nullptr, *cm = nullptr, *ss = nullptr, *stats = nullptr;
@@ -532,6 +546,16 @@ bool rb_slot(ResBlock& r, const std::string& s, Slot* o) {
     return false;
 }
 
+bool attn_slot(AttnSite& a, int C, const std::string& s, Slot* o) {
+    auto convw = [&](Conv& c) { *o = {c.w, (int64_t)c.cin * c.cout * c.k}; return c.w != nullptr; };
+    if (s == "fn.norm.g") { *o = {a.norm.g, C}; return true; }
+    if (s == "fn.norm.b") { *o = {a.norm.b, C}; return true; }
+    if (s == "fn.fn.to_qkv.weight") return convw(a.qkv);
+    if (s == "fn.fn.to_out.weight") return convw(a.out);
+    if (s == "fn.fn.to_out.bias") { *o = {a.out.b, C}; return true; }
+    return false;
+}
+
 hipError_t pack(UnetModel* u, Conv& c, hipStream_t s) {
     const int kk = (c.transposed ? 2 : c.k) * c.cin_p;
     const int n_rows = c.cout;
@@ -573,9 +597,11 @@ hipError_t pack(UnetModel* u, Conv& c, hipStream_t s) {
 
 }  // namespace
 
-UnetModel* unet_new(int n_feats, int added, int dim, const int mults[4], int max_seq, bool text, bool want_grad) {
+UnetModel* unet_new(int n_feats, int added, int dim, const int mults[4], int max_seq, bool text, bool want_grad,
+                    bool attention) {
     UnetModel* u = new UnetModel();
     u->J = n_feats; u->added = added; u->dim = dim; u->max_seq = max_seq; u->text = text; u->want_grad = want_grad;
+    u->attention = attention;
 #ifdef CMDI_PROBES   // tuning knobs: probes build only
     if (const char* v = std::getenv("CMDI_UNET_KSPLIT")) u->ksplit_ok = std::atoi(v);
     if (const char* v = std::getenv("CMDI_UNET_TILE")) u->big_tile = std::atoi(v);
@@ -621,6 +647,27 @@ UnetModel* unet_new(int n_feats, int added, int dim, const int mults[4], int max
         rc |= alloc_rows(u, &u->H1S[l], rows, 2 * (size_t)Cw) | alloc_rows(u, &u->Sa[l], rows, 2 * (size_t)Cw);
         rc |= alloc_rows(u, &u->Sb[l], rows, 2 * (size_t)Cw) | alloc_rows(u, &u->CAT[l], rows, 4 * (size_t)Cw);
     }
+    if (attention && !rc) {
+        if (Cw > 1024) { u->err = "LinearAttention sites: at most 1024 channels"; return u; }
+        auto site = [&](AttnSite& a, int l) {
+            a.level = l;
+            const size_t rows = ns * (size_t)(256 >> l);
+            int r = conv_alloc(u, a.qkv, Cw, 3 * LA_HID, 1) | conv_alloc(u, a.out, LA_HID, Cw, 1);
+            r |= ualloc_t(u, &a.norm.g, Cw) | ualloc_t(u, &a.norm.b, Cw);
+            r |= alloc_rows(u, &a.x, rows, Cw) | alloc_rows(u, &a.stats, rows, 2) | alloc_rows(u, &a.qkvf, rows, 3 * (size_t)LA_HID);
+            return r;
+        };
+        for (int l = 0; l < 4; ++l) rc |= site(u->at_down[l], l);
+        rc |= site(u->at_mid, 3);
+        for (int i = 0; i < 3; ++i) rc |= site(u->at_up[i], 3 - i);
+        for (int l = 0; l < 4 && !rc; ++l) {
+            const size_t rows = ns * (size_t)(256 >> l);
+            rc |= alloc_rows(u, &u->AYS[l], rows, 2 * (size_t)Cw) | alloc_rows(u, &u->AOS[l], rows, 2 * (size_t)LA_HID);
+            if (want_grad)
+                rc |= alloc_rows(u, &u->AGO[l], rows, (size_t)LA_HID) | alloc_rows(u, &u->AGS[l], rows, 6 * (size_t)LA_HID) |
+                      alloc_rows(u, &u->AGN[l], rows, Cw);
+        }
+    }
     rc |= alloc_rows(u, &u->in0S, ns * 256, 2 * (size_t)u->Cin0p);
     rc |= alloc_rows(u, &u->S0skip, ns * 256, 2 * (size_t)Cw);
     rc |= alloc_rows(u, &u->outF, ns * 256, (size_t)u->Np);
@@ -659,6 +706,9 @@ void unet_free(UnetModel* u) {
     for (int j = 0; j < 2; ++j) { drop(u->mid[j].c1); drop(u->mid[j].c2); drop(u->mid[j].res); }
     for (int l = 0; l < 3; ++l) { for (int j = 0; j < 2; ++j) { drop(u->up[l][j].c1); drop(u->up[l][j].c2); drop(u->up[l][j].res); } drop(u->downs[l]); drop(u->ups[l]); }
     drop(u->fin); drop(u->outc);
+    for (int l = 0; l < 4; ++l) { drop(u->at_down[l].qkv); drop(u->at_down[l].out); }
+    for (int i = 0; i < 3; ++i) { drop(u->at_up[i].qkv); drop(u->at_up[i].out); }
+    drop(u->at_mid.qkv); drop(u->at_mid.out);
     for (void* p : u->allocs) (void)hipFree(p);
     delete u;
 }
@@ -678,15 +728,19 @@ int unet_load_weight(UnetModel* u, const char* name, const float* d_src, int64_t
     else if (std::sscanf(name, "unet.downs.%d.%d.%127s", &a, &b, rest) == 3 && a >= 0 && a < 4) {
         const std::string r(rest);
         if (b < 2) ok = rb_slot(u->down[a][b], r, &sl);
+        else if (b == 2 && u->attention) ok = attn_slot(u->at_down[a], u->C[1], r, &sl);
         else if (b == 3 && a < 3 && r == "conv.weight" && u->downs[a].w) { sl = {u->downs[a].w, (int64_t)u->downs[a].cin * u->downs[a].cout * 3}; ok = true; }
         else if (b == 3 && a < 3 && r == "conv.bias") { sl = {u->downs[a].b, u->downs[a].cout}; ok = true; }
     } else if (std::sscanf(name, "unet.ups.%d.%d.%127s", &a, &b, rest) == 3 && a >= 0 && a < 3) {
         const std::string r(rest);
         if (b < 2) ok = rb_slot(u->up[a][b], r, &sl);
+        else if (b == 2 && u->attention) ok = attn_slot(u->at_up[a], u->C[1], r, &sl);
         else if (b == 3 && r == "conv.weight" && u->ups[a].w) { sl = {u->ups[a].w, (int64_t)u->ups[a].cin * u->ups[a].cout * 4}; ok = true; }
         else if (b == 3 && r == "conv.bias") { sl = {u->ups[a].b, u->ups[a].cout}; ok = true; }
     } else if (std::sscanf(name, "unet.mid_block%d.%127s", &a, rest) == 2 && (a == 1 || a == 2)) {
         ok = rb_slot(u->mid[a - 1], rest, &sl);
+    } else if (u->attention && n.rfind("unet.mid_attn.", 0) == 0) {
+        ok = attn_slot(u->at_mid, u->C[1], n.substr(14), &sl);
     } else if (n == "unet.final_conv.0.block.0.weight" && u->fin.w) { sl = {u->fin.w, (int64_t)u->fin.cin * u->fin.cout * 5}; ok = true; }
     else if (n == "unet.final_conv.0.block.0.bias") { sl = {u->fin.b, u->fin.cout}; ok = true; }
     else if (n == "unet.final_conv.0.block.2.weight") { sl = {u->fin_n.g, u->fin.cout}; ok = true; }
@@ -713,6 +767,11 @@ int unet_finalize(UnetModel* u, hipStream_t s) {
     rb(u->mid[0]); rb(u->mid[1]);
     for (int i = 0; i < 3; ++i) { rb(u->up[i][0]); rb(u->up[i][1]); convs.push_back(&u->ups[i]); }
     convs.push_back(&u->fin); convs.push_back(&u->outc);
+    if (u->attention) {
+        for (int l = 0; l < 4; ++l) { convs.push_back(&u->at_down[l].qkv); convs.push_back(&u->at_down[l].out); }
+        convs.push_back(&u->at_mid.qkv); convs.push_back(&u->at_mid.out);
+        for (int i = 0; i < 3; ++i) { convs.push_back(&u->at_up[i].qkv); convs.push_back(&u->at_up[i].out); }
+    }
     for (Conv* c : convs) {
         if (!c->w) { u->err = "UNET weights already packed"; return -1; }
         if (pack(u, *c, s) != hipSuccess) { u->err = "packing a convolution failed"; return -1; }
@@ -851,6 +910,20 @@ int res_block(UnetModel* u, const ResBlock& r, const _Float16* xs, int a_ld, con
     return conv_rows(u, r.res, r.res.ws, xs, a_ld, rows, level, 1, 0, 1, 0, 0, out_f, out_s, out_ld, u->F1[level], s);
 }
 
+// Residual(PreNorm(LinearAttention)) of the rows in a.x (written by the preceding block) -> out_f (fp32) and / or out_s
+int attn_forward(UnetModel* u, AttnSite& a, int nseq, float* out_f, _Float16* out_s, int out_ld, hipStream_t s) {
+    const Lvl L = lvl(a.level);
+    const int C = u->C[1], rows = nseq * L.Tp, l = a.level;
+    hipLaunchKernelGGL(chan_ln_kernel, dim3((L.Tv + 3) / 4, nseq), dim3(256), 0, s, a.x, a.norm.g, a.norm.b, u->AYS[l], a.stats,
+                       u->range_flag, C, L.Tp, L.h, L.Tv);
+    UCHK(hipGetLastError());
+    if (conv_rows(u, a.qkv, a.qkv.ws, u->AYS[l], 2 * C, rows, l, 1, 0, 1, 0, 0, a.qkvf, nullptr, 0, nullptr, s)) return -1;
+    hipLaunchKernelGGL(linattn_core_kernel, dim3(LA_HEADS, nseq), dim3(256), 0, s, a.qkvf, u->AOS[l], u->range_flag, L.Tp, L.h,
+                       L.Tv);
+    UCHK(hipGetLastError());
+    return conv_rows(u, a.out, a.out.ws, u->AOS[l], 2 * LA_HID, rows, l, 1, 0, 1, 0, 0, out_f, out_s, out_ld, a.x, s);
+}
+
 // ---- input-VJP ---------------------------------------------------------------------------------------------------------
 // one GEMM over gradient rows: C[M', N] (+)= A-rows (tap-shifted, strided) x W^T, frames only (halo rows stay zero)
 int grad_gemm(UnetModel* u, const _Float16* a, int a_ld, const _Float16* w, int M, int N, int K1, int taps, int pad,
@@ -897,6 +970,9 @@ int gn_bwd(UnetModel* u, const float* dy, int ld_dy, const float* f, int nsl, co
     return 0;
 }
 
+// LinearAttention site backward, in place: dy (fp32 rows, stride ld) = d (site output) -> d (site input) = dy + PreNorm^T(...)
+int attn_backward(UnetModel* u, const AttnSite& a, int nseq, float* dy, int ld, hipStream_t s);
+
 // ResidualTemporalBlock backward: dy = d out (fp32 rows, stride ld_dy; dys = the same as split rows, needed only when the
 // block has a 1x1 residual convolution) -> d x into out_f (fp32, cin_p wide, may be null) and / or out_s (split rows)
 int res_block_bwd(UnetModel* u, const ResBlock& r, const RBStash& st, const float* dy, int ld_dy, const _Float16* dys,
@@ -919,6 +995,29 @@ int res_block_bwd(UnetModel* u, const ResBlock& r, const RBStash& st, const floa
     if (grad_gemm(u, u->GS[level], 2 * C, r.c1.wb, rows, Ni, C, 5, 2, 1, 0, 0, level, out_f, Ni, nullptr, 0, nullptr, 0, s))
         return -1;
     return grad_gemm(u, dys, 2 * C, r.res.wb, rows, Ni, C, 1, 0, 1, 0, 0, level, out_f, Ni, out_s, 2 * Ni, out_f, Ni, s);
+}
+
+int attn_backward(UnetModel* u, const AttnSite& a, int nseq, float* dy, int ld, hipStream_t s) {
+    const Lvl L = lvl(a.level);
+    const int C = u->C[1], rows = nseq * L.Tp, l = a.level;
+    static bool attr_done = false;
+    if (!attr_done) {
+        UCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(linattn_core_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)LA_BWD_LDS));
+        attr_done = true;
+    }
+    UCHK(launch_split_f16(dy, u->AYS[l], rows, C, ld, nullptr, s));
+    if (grad_gemm(u, u->AYS[l], 2 * C, a.out.wb, rows, LA_HID, C, 1, 0, 1, 0, 0, l, u->AGO[l], LA_HID, nullptr, 0, nullptr, 0, s))
+        return -1;
+    hipLaunchKernelGGL(linattn_core_bwd_kernel, dim3(LA_HEADS, nseq), dim3(256), LA_BWD_LDS, s, a.qkvf, u->AGO[l], u->AGS[l], L.Tp,
+                       L.h, L.Tv);
+    UCHK(hipGetLastError());
+    if (grad_gemm(u, u->AGS[l], 6 * LA_HID, a.qkv.wb, rows, C, 3 * LA_HID, 1, 0, 1, 0, 0, l, u->AGN[l], C, nullptr, 0, nullptr, 0, s))
+        return -1;
+    hipLaunchKernelGGL(chan_ln_bwd_kernel, dim3((L.Tv + 3) / 4, nseq), dim3(256), 0, s, u->AGN[l], a.x, a.stats, a.norm.g, dy, ld, C,
+                       L.Tp, L.h, L.Tv);
+    UCHK(hipGetLastError());
+    return 0;
 }
 
 }  // namespace
@@ -967,6 +1066,12 @@ int unet_forward(UnetModel* u, const float* x, const float* obs, const uint8_t* 
         // skip of level l >= 1 goes straight into the right half of that level's concat buffer
         _Float16* skip = l == 0 ? u->S0skip : u->CAT[l] + 2 * Cw;
         const int skip_ld = l == 0 ? 2 * Cw : 4 * Cw;
+        if (u->attention) {   // x = attn(x) sits in front of h.append(x): the skip is the attention output
+            if (res_block(u, u->down[l][1], u->Sa[l], 2 * Cw, u->Xa[l], nseq, l, u->at_down[l].x, nullptr, 0, s,
+                          keep ? &u->st_down[l][1] : nullptr))
+                return -1;
+            if (attn_forward(u, u->at_down[l], nseq, l == 3 ? u->Xb[3] : nullptr, skip, skip_ld, s)) return -1;
+        } else
         if (res_block(u, u->down[l][1], u->Sa[l], 2 * Cw, u->Xa[l], nseq, l, l == 3 ? u->Xb[3] : nullptr, skip, skip_ld, s,
                       keep ? &u->st_down[l][1] : nullptr))
             return -1;
@@ -978,12 +1083,20 @@ int unet_forward(UnetModel* u, const float* x, const float* obs, const uint8_t* 
         }
     }
     // ---- middle -------------------------------------------------------------------------------------------
+    if (u->attention) {
+        if (res_block(u, u->mid[0], u->CAT[3] + 2 * Cw, 4 * Cw, u->Xb[3], nseq, 3, u->at_mid.x, nullptr, 0, s, keep ? &u->st_mid[0] : nullptr)) return -1;
+        if (attn_forward(u, u->at_mid, nseq, u->Xa[3], u->Sa[3], 2 * Cw, s)) return -1;
+    } else
     if (res_block(u, u->mid[0], u->CAT[3] + 2 * Cw, 4 * Cw, u->Xb[3], nseq, 3, u->Xa[3], u->Sa[3], 2 * Cw, s, keep ? &u->st_mid[0] : nullptr)) return -1;
     if (res_block(u, u->mid[1], u->Sa[3], 2 * Cw, u->Xa[3], nseq, 3, nullptr, u->CAT[3], 4 * Cw, s, keep ? &u->st_mid[1] : nullptr)) return -1;
     // ---- up path: cat(x, skip) is the [left | right] halves of CAT[l] --------------------------------------
     for (int i = 0; i < 3; ++i) {
         const int l = 3 - i;
         if (res_block(u, u->up[i][0], u->CAT[l], 4 * Cw, nullptr, nseq, l, u->Xa[l], u->Sa[l], 2 * Cw, s, keep ? &u->st_up[i][0] : nullptr)) return -1;
+        if (u->attention) {
+            if (res_block(u, u->up[i][1], u->Sa[l], 2 * Cw, u->Xa[l], nseq, l, u->at_up[i].x, nullptr, 0, s, keep ? &u->st_up[i][1] : nullptr)) return -1;
+            if (attn_forward(u, u->at_up[i], nseq, nullptr, u->Sb[l], 2 * Cw, s)) return -1;
+        } else
         if (res_block(u, u->up[i][1], u->Sa[l], 2 * Cw, u->Xa[l], nseq, l, nullptr, u->Sb[l], 2 * Cw, s, keep ? &u->st_up[i][1] : nullptr)) return -1;
         // Upsample1d: ConvTranspose1d(dim, dim, 4, 2, 1): even rows taps (x[j-1] W3, x[j] W1), odd (x[j] W2, x[j+1] W0)
         _Float16* dst = l - 1 >= 1 ? u->CAT[l - 1] : u->Sa[0];
@@ -1036,12 +1149,14 @@ int unet_backward(UnetModel* u, const float* gout, const uint8_t* mask, const un
         const int a_ld = i == 2 ? 2 * Cw : 4 * Cw;
         if (grad_gemm(u, a, a_ld, u->ups[i].wb, rows(l), Cw, Cw, 4, 1, 2, 0, 0, l, u->GA[l], Cw, nullptr, 0, nullptr, 0, s))
             return -1;
+        if (u->attention && attn_backward(u, u->at_up[i], nseq, u->GA[l], Cw, s)) return -1;
         if (res_block_bwd(u, u->up[i][1], u->st_up[i][1], u->GA[l], Cw, nullptr, nseq, l, u->GC[l], u->GU[l], s)) return -1;
         // d cat(x, skip): left half = d x (upsampled frames of the previous stage / the middle), right half = d skip
         if (res_block_bwd(u, u->up[i][0], u->st_up[i][0], u->GC[l], Cw, u->GU[l], nseq, l, u->GB[l], u->GBS[l], s)) return -1;
     }
     // ---- middle ----------------------------------------------------------------------------------------------------
     if (res_block_bwd(u, u->mid[1], u->st_mid[1], u->GB[3], 2 * Cw, nullptr, nseq, 3, u->GA[3], nullptr, s)) return -1;
+    if (u->attention && attn_backward(u, u->at_mid, nseq, u->GA[3], Cw, s)) return -1;
     if (res_block_bwd(u, u->mid[0], u->st_mid[0], u->GA[3], Cw, nullptr, nseq, 3, u->GC[3], nullptr, s)) return -1;
     {   // d skip_3 = d (middle input) + the concat's right half
         const int64_t n = (int64_t)rows(3) * (Cw / 4);
@@ -1051,8 +1166,9 @@ int unet_backward(UnetModel* u, const float* gout, const uint8_t* mask, const un
     }
     // ---- down path -------------------------------------------------------------------------------------------------
     for (int l = 3; l >= 0; --l) {
-        const float* sg = (l == 3 || l == 0) ? u->GC[l] : u->GB[l] + Cw;   // d skip_l
+        float* sg = (l == 3 || l == 0) ? u->GC[l] : u->GB[l] + Cw;   // d skip_l
         const int sg_ld = (l == 3 || l == 0) ? Cw : 2 * Cw;
+        if (u->attention && attn_backward(u, u->at_down[l], nseq, sg, sg_ld, s)) return -1;
         if (res_block_bwd(u, u->down[l][1], u->st_down[l][1], sg, sg_ld, nullptr, nseq, l, u->GA[l], l == 0 ? u->GU[0] : nullptr, s))
             return -1;
         if (l == 0) {

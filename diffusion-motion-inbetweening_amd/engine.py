@@ -33,7 +33,7 @@ class Engine:
     def __init__(self, *, n_layers: int, d_model: int, d_ff: int, n_heads: int, n_feats: int,
                  max_frames: int, max_batch: int, pe_rows: int = 5000, text_cond: bool = False,
                  want_grad: bool = False, precision: Optional[str] = None, arch: str = "trans_enc",
-                 unet_added: int = 0, unet_mults=(2, 2, 2, 2), device="cuda"):
+                 unet_added: int = 0, unet_mults=(2, 2, 2, 2), unet_attention: bool = False, device="cuda"):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise N.NativeError(
@@ -45,7 +45,7 @@ class Engine:
         self.desc = N.ModelDesc(n_layers, d_model, d_ff, n_heads, n_feats, max_frames, max_batch,
                                 pe_rows, int(text_cond), int(want_grad), N.PRECISIONS[precision],
                                 N.CMDI_ARCH_UNET if arch == "unet" else N.CMDI_ARCH_TRANS_ENC, int(unet_added),
-                                (C.c_int32 * 4)(*[int(m) for m in unet_mults]))
+                                (C.c_int32 * 4)(*[int(m) for m in unet_mults]), int(unet_attention))
         self.arch = arch
         self.n_feats, self.max_frames, self.max_batch = n_feats, max_frames, max_batch
         self.want_grad = bool(want_grad)

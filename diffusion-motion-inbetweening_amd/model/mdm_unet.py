@@ -7,8 +7,9 @@ The module holds parameters under the reference's state-dict names and shapes, s
 but ``forward`` does no torch arithmetic: the whole network (reference :766-849, TemporalUnet :214-358) runs as
 hand-written gfx950 kernels (csrc/unet.hip: every 1-D convolution is a split-f16 GEMM over tap-shifted rows).
 
-Not provided (reference-only): attention=True, adagn=False, 'unet_large', xz_only / traj models,
-train_keypoint_mask variants, action conditioning, reconstruction guidance through the U-Net (needs its VJP).
+``attention=True`` (Residual(PreNorm(LinearAttention)) sites, reference :102-156) is built as well, forward and input-VJP.
+Not provided (reference-only): adagn=False, 'unet_large', xz_only / traj models, train_keypoint_mask variants, action
+conditioning.
 """
 from __future__ import annotations
 
@@ -65,8 +66,40 @@ class _Up(nn.Module):
         self.conv = nn.ConvTranspose1d(dim, dim, 4, 2, 1)
 
 
+class _ChannelLayerNorm(nn.Module):   # reference :111-121
+    def __init__(self, dim):
+        super().__init__()
+        self.g = nn.Parameter(torch.ones(1, dim, 1))
+        self.b = nn.Parameter(torch.zeros(1, dim, 1))
+
+
+class _LinearAttention(nn.Module):    # reference :135-156
+    def __init__(self, dim, heads=4, dim_head=32):
+        super().__init__()
+        self.heads = heads
+        self.to_qkv = nn.Conv1d(dim, heads * dim_head * 3, 1, bias=False)
+        self.to_out = nn.Conv1d(heads * dim_head, dim, 1)
+
+
+class _PreNorm(nn.Module):            # reference :124-132
+    def __init__(self, dim, fn):
+        super().__init__()
+        self.fn = fn
+        self.norm = _ChannelLayerNorm(dim)
+
+
+class _Residual(nn.Module):           # reference :102-108
+    def __init__(self, fn):
+        super().__init__()
+        self.fn = fn
+
+
+def _attn_site(dim, attention):
+    return _Residual(_PreNorm(dim, _LinearAttention(dim))) if attention else nn.Identity()
+
+
 class TemporalUnet(nn.Module):   # reference :214-358 (parameter holder; the arithmetic lives in csrc/unet.hip)
-    def __init__(self, input_dim, cond_dim, dim, dim_mults, zero, added_input_channels):
+    def __init__(self, input_dim, cond_dim, dim, dim_mults, zero, added_input_channels, attention=False):
         super().__init__()
         dims = [input_dim, *[int(dim * m) for m in dim_mults]]
         in_out = list(zip(dims[:-1], dims[1:]))
@@ -77,16 +110,16 @@ class TemporalUnet(nn.Module):   # reference :214-358 (parameter holder; the ari
             last = ind >= n_res - 1
             self.downs.append(nn.ModuleList([
                 _ResidualTemporalBlock(din + added_input_channels * (ind == 0), dout, dim, zero),
-                _ResidualTemporalBlock(dout, dout, dim, zero), nn.Identity(),
+                _ResidualTemporalBlock(dout, dout, dim, zero), _attn_site(dout, attention),
                 _Down(dout) if not last else nn.Identity()]))
         mid = dims[-1]
         self.mid_block1 = _ResidualTemporalBlock(mid, mid, dim, zero)
-        self.mid_attn = nn.Identity()
+        self.mid_attn = _attn_site(mid, attention)
         self.mid_block2 = _ResidualTemporalBlock(mid, mid, dim, zero)
         for ind, (din, dout) in enumerate(reversed(in_out[1:])):
             self.ups.append(nn.ModuleList([
                 _ResidualTemporalBlock(dout * 2, din, dim, zero), _ResidualTemporalBlock(din, din, dim, zero),
-                nn.Identity(), _Up(din)]))
+                _attn_site(din, attention), _Up(din)]))
         self.final_conv = nn.Sequential(_Conv1dBlock(din, din, 5), nn.Conv1d(din, input_dim, 1))
         if zero:
             nn.init.zeros_(self.final_conv[1].weight)
@@ -101,9 +134,9 @@ class MDM_UNET(nn.Module):
                  train_keypoint_mask='none', keyframe_conditioned=False, keyframe_selection_scheme='in-between',
                  zero_keyframe_loss=False, **kwargs):
         super().__init__()
-        if arch != 'unet' or attention or not adagn or xz_only or train_keypoint_mask != 'none':
-            raise ValueError("the MI355X engine implements arch='unet' with adagn=True, attention=False, "
-                             "xz_only=False, train_keypoint_mask='none' (the CondMDI configuration)")
+        if arch != 'unet' or not adagn or xz_only or train_keypoint_mask != 'none':
+            raise ValueError("the MI355X engine implements arch='unet' with adagn=True, xz_only=False, "
+                             "train_keypoint_mask='none' (the CondMDI configuration; attention=False or True)")
         if latent_dim != 512 or len(dim_mults) != 4 or len(set(dim_mults)) != 1 or int(latent_dim * dim_mults[0]) % 256:
             raise ValueError("the MI355X engine needs latent_dim=512 and four equal dim_mults (e.g. (2, 2, 2, 2))")
         if dataset != 'humanml' or data_rep != 'hml_vec':
@@ -126,7 +159,7 @@ class MDM_UNET(nn.Module):
         added = self.input_feats if keyframe_conditioned else 0
         self.added_channels = added
         self.sequence_pos_encoder = PositionalEncoding(latent_dim, dropout=0)
-        self.unet = TemporalUnet(self.input_feats, latent_dim, latent_dim, self.dim_mults, zero, added)
+        self.unet = TemporalUnet(self.input_feats, latent_dim, latent_dim, self.dim_mults, zero, added, attention=attention)
         self.embed_timestep = TimestepEmbedder(latent_dim, self.sequence_pos_encoder)
         self.clip_version = clip_version
         self.clip_model = None
@@ -165,7 +198,8 @@ class MDM_UNET(nn.Module):
             eng = Engine(n_layers=0, d_model=self.latent_dim, d_ff=0, n_heads=0, n_feats=self.input_feats,
                          max_frames=max_frames, max_batch=max_batch, pe_rows=pe_rows,
                          text_cond='text' in self.cond_mode, want_grad=want_grad, arch="unet",
-                         unet_added=self.added_channels, unet_mults=self.dim_mults, device=device)
+                         unet_added=self.added_channels, unet_mults=self.dim_mults, unet_attention=self.attention,
+                         device=device)
             sd = {k: v for k, v in self.state_dict().items() if not k.startswith('clip_model.')}
             eng.load_state_dict(sd, n_time_rows=n_time_rows)
             self._engine = eng

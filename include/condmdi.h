@@ -73,6 +73,7 @@ typedef struct {
                             n_layers / d_ff / n_heads unused, d_model = latent_dim = 512)                        */
     int32_t unet_added;  /* UNET: extra input channels = n_feats if keyframe_conditioned (cat(x, obs_mask)) else 0 */
     int32_t unet_mults[4]; /* UNET: dim_mults (channels = d_model * mult; the built configuration has equal mults) */
+    int32_t unet_attention; /* UNET: 1 = attention=True, Residual(PreNorm(LinearAttention)) sites (model/mdm_unet.py:102-156,262,273,298) */
 } cmdi_model_desc;
 
 /* Model-output → x0 conventions (diffusion/gaussian_diffusion.py:74-95). */

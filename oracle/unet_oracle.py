@@ -11,8 +11,11 @@ TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Follows, piece by piece:
     Conv1dBlock / Conv1dAdaGNBlock :33-99 (Conv1d k=5 pad 2 -> GroupNorm(8) -> [x*(1+scale)+shift] -> Mish)
     Downsample1d / Upsample1d :15-30 (Conv1d(3, stride 2, pad 1) / ConvTranspose1d(4, stride 2, pad 1))
     CFG                  model/cfg_sampler.py:25-35
-The LinearAttention branch (attention=True) is not part of the released configurations and is not restated.
-Pinned by tests/golden/unet_fwd.npz (outputs of the real reference run on CPU, tests/golden/make_golden_unet.py).
+    LinearAttention      :102-156 (Residual(PreNorm(LayerNorm over channels, LinearAttention)): to_qkv 1x1 without
+                         bias, 4 heads x 32, q * 32^-0.5, softmax of k over the FRAMES, context = k v^T, to_out 1x1);
+                         present iff the state dict holds "unet.downs.0.2.fn.fn.to_qkv.weight" (attention=True)
+Pinned by tests/golden/unet_fwd.npz and unet_attn_fwd.npz (outputs of the real reference run on CPU,
+tests/golden/make_golden_unet.py).
 """
 from __future__ import annotations
 
@@ -104,6 +107,25 @@ class UnetOracle:
             x = conv1d(x, sd[f"{p}.residual_conv.weight"], sd[f"{p}.residual_conv.bias"])
         return (h + x).astype(F32)
 
+    def _attention(self, p, x):
+        """Residual(PreNorm(dim, LinearAttention(dim))) (reference :102-156); identity when the block is nn.Identity."""
+        sd = self.sd
+        if f"{p}.fn.fn.to_qkv.weight" not in sd:
+            return x
+        heads, dh = 4, 32
+        var = x.var(axis=1, keepdims=True, dtype=F32)                  # torch.var(unbiased=False) over the channels
+        mean = x.mean(axis=1, keepdims=True, dtype=F32)
+        xn = ((x - mean) / np.sqrt(var + GN_EPS) * sd[f"{p}.fn.norm.g"] + sd[f"{p}.fn.norm.b"]).astype(F32)
+        qkv = conv1d(xn, sd[f"{p}.fn.fn.to_qkv.weight"], np.zeros(3 * heads * dh, dtype=F32))
+        B, _, n = qkv.shape
+        q, k, v = [t.reshape(B, heads, dh, n) for t in np.split(qkv, 3, axis=1)]
+        q = q * F32(dh ** -0.5)
+        k = np.exp(k - k.max(axis=-1, keepdims=True))
+        k = (k / k.sum(axis=-1, keepdims=True, dtype=F32)).astype(F32)
+        context = np.einsum("bhdn,bhen->bhde", k, v).astype(F32)
+        out = np.einsum("bhde,bhdn->bhen", context, q).astype(F32).reshape(B, heads * dh, n)
+        return (conv1d(out, sd[f"{p}.fn.fn.to_out.weight"], sd[f"{p}.fn.fn.to_out.bias"]) + x).astype(F32)
+
     def temporal_unet(self, x, cond):
         """x [B, C, 224] ; cond [B, d] -> [B, C_out, 224]."""
         sd = self.sd
@@ -114,15 +136,18 @@ class UnetOracle:
         for l in range(n):
             x = self._res_block(f"unet.downs.{l}.0", x, c)
             x = self._res_block(f"unet.downs.{l}.1", x, c)
+            x = self._attention(f"unet.downs.{l}.2", x)
             skips.append(x)
             if l < n - 1:
                 x = conv1d(x, sd[f"unet.downs.{l}.3.conv.weight"], sd[f"unet.downs.{l}.3.conv.bias"], stride=2, pad=1)
         x = self._res_block("unet.mid_block1", x, c)
+        x = self._attention("unet.mid_attn", x)
         x = self._res_block("unet.mid_block2", x, c)
         for u in range(n - 1):
             x = np.concatenate([x, skips.pop()], axis=1)
             x = self._res_block(f"unet.ups.{u}.0", x, c)
             x = self._res_block(f"unet.ups.{u}.1", x, c)
+            x = self._attention(f"unet.ups.{u}.2", x)
             x = conv_transpose1d(x, sd[f"unet.ups.{u}.3.conv.weight"], sd[f"unet.ups.{u}.3.conv.bias"])
         x = self._conv_block("unet.final_conv.0", x)
         return conv1d(x, sd["unet.final_conv.1.weight"], sd["unet.final_conv.1.bias"])

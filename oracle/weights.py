@@ -76,7 +76,7 @@ def fill_like(shapes: dict, seed: int = 0) -> dict:
             fan_in = int(np.prod(shape[1:]))
             k = 1.0 / np.sqrt(fan_in)
             out[name] = rng.uniform(-k, k, size=shape).astype(np.float32)
-        elif name.endswith(".weight"):
+        elif name.endswith(".weight") or name.endswith(".norm.g"):   # (norm.g: the U-Net's channel LayerNorm gain [1, C, 1])
             out[name] = (1.0 + 0.1 * rng.standard_normal(shape)).astype(np.float32)
         else:
             out[name] = (0.1 * rng.standard_normal(shape)).astype(np.float32)

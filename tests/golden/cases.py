@@ -188,6 +188,10 @@ UNET_VJP_CASE = dict(UNET_CASE, seed=303, t=[333, 333], text_scale=[2.5, 1.0])
 UNET_RECON_CHAIN = dict(UNET_CHAIN, seed=304, recon_weight=20.0, stop_recguidance_at=0)
 
 
+# attention=True (Residual(PreNorm(LinearAttention)) sites; not reachable from the reference's CLI, built directly)
+UNET_ATTN_CASE = dict(UNET_CASE, seed=305, weight_seed=33, t=[700, 41], text_scale=[2.5, 1.0])
+
+
 def make_unet_vjp_inputs(case: dict = UNET_VJP_CASE) -> dict:
     inp = make_unet_inputs(case)
     rng = np.random.default_rng(case["seed"] + 1000)

@@ -99,3 +99,28 @@ with ref_shims.injected_noise(stream):
     final_r = diffusion.p_sample_loop(wrapped, ri["x_T"].shape, **kwr)
 np.savez_compressed(HERE / "unet_recon_chain.npz", final=final_r.detach().numpy(), fingerprint=cases.fingerprint(ri))
 print("recon chain", float(final_r.abs().mean()))
+
+
+# ---- attention=True: forward (cond / uncond / CFG) and the input-VJP of the guided output ----------------------
+ac = cases.UNET_ATTN_CASE
+ai = cases.make_unet_vjp_inputs(ac)
+model_a = ref_unet.MDM_UNET(**ref.model_util.get_model_args(args, SimpleNamespace(dataset=SimpleNamespace())), attention=True)
+shapes_a = {k: tuple(v.shape) for k, v in model_a.state_dict().items() if not k.startswith("clip_model.")}
+assert any(".fn.fn.to_qkv." in k for k in shapes_a)
+sd_a = weights.fill_like(shapes_a, ac["weight_seed"])
+missing, unexpected = model_a.load_state_dict({k: torch.from_numpy(v) for k, v in sd_a.items()}, strict=False)
+assert not unexpected and all(k.startswith("clip_model.") or k.endswith(".pe") for k in missing), (missing, unexpected)
+model_a.eval()
+wrapped_a = ref.cfg.ClassifierFreeSampleModel(model_a)
+ref_shims.set_text_embedding(t(ai["enc_text"]))
+ya = {"text": ["a"] * ac["B"], "mask": torch.ones(ac["B"], 1, 1, ac["T"], dtype=torch.bool)}
+with torch.no_grad():
+    oc_a = model_a(t(ai["x"]), t(ai["t"]), y=dict(ya), obs_x0=t(ai["obs_x0"]), obs_mask=t(ai["obs_mask"]))
+    ou_a = model_a(t(ai["x"]), t(ai["t"]), y=dict(ya, uncond=True), obs_x0=t(ai["obs_x0"]), obs_mask=t(ai["obs_mask"]))
+za = t(ai["x"]).clone().requires_grad_(True)
+with torch.enable_grad():
+    out_a = wrapped_a(za, t(ai["t"]), y=dict(ya, text_scale=t(ai["text_scale"])), obs_x0=t(ai["obs_x0"]), obs_mask=t(ai["obs_mask"]))
+    gx_a, = torch.autograd.grad((out_a * t(ai["gout"])).sum(), za)
+np.savez_compressed(HERE / "unet_attn.npz", out_cond=oc_a.numpy(), out_uncond=ou_a.numpy(), out_cfg=out_a.detach().numpy(),
+                    gx=gx_a.numpy(), fingerprint=cases.fingerprint(ai), names=np.asarray(sorted(shapes_a)))
+print("attention", float(oc_a.abs().mean()), float(gx_a.abs().mean()), float((oc_a - ou_a).abs().mean()))

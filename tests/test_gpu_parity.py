@@ -1011,6 +1011,69 @@ def test_unet_vjp_vs_reference_autograd(cases):
         assert rel_l2(gk, g["gx"]) <= 5e-5, (k, rel_l2(gk, g["gx"]))
 
 
+def make_unet_attention(cases):
+    mm = sub("model.mdm_unet")
+    mu = sub("utils.model_util")
+    case = cases.UNET_ATTN_CASE
+    model = mm.MDM_UNET(njoints=263, nfeats=1, latent_dim=512, dim_mults=case["dim_mults"], attention=True,
+                        keyframe_conditioned=True, cond_mode="text", cond_mask_prob=0.1)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items() if not k.startswith("clip_model.")}
+    g = load_golden("unet_attn")
+    assert sorted(shapes) == list(g["names"]), "state-dict names differ from the reference's MDM_UNET(attention=True)"
+    mu.load_model_wo_clip(model, weights.to_torch(weights.fill_like(shapes, case["weight_seed"])) |
+                          {k: v for k, v in model.state_dict().items() if k.endswith(".pe")})
+    return model.to(DEV).eval(), g
+
+
+def test_unet_attention_forward_and_vjp_vs_reference(cases):
+    """MDM_UNET(attention=True): the eight Residual(PreNorm(LinearAttention)) sites (reference model/mdm_unet.py:102-156)
+    forward (cond / uncond / CFG) and input-VJP vs the real reference's CPU outputs / torch autograd."""
+    inp = cases.make_unet_vjp_inputs(cases.UNET_ATTN_CASE)
+    model, g = make_unet_attention(cases)
+    assert np.array_equal(g["fingerprint"], cases.fingerprint(inp))
+    x, t = tt(inp["x"]), tt(inp["t"])
+    kw = dict(obs_x0=tt(inp["obs_x0"]), obs_mask=tt(inp["obs_mask"]))
+    y = {"text_embed": tt(inp["enc_text"])}
+    oc = model(x, t, y=y, **kw).cpu().numpy()
+    ou = model(x, t, y=dict(y, uncond=True), **kw).cpu().numpy()
+    wrapped = sub("model.cfg_sampler").ClassifierFreeSampleModel(model)
+    cfg = wrapped(x, t, y=dict(y, text_scale=tt(inp["text_scale"])), **kw).cpu().numpy()
+    for mine, key in ((oc, "out_cond"), (ou, "out_uncond"), (cfg, "out_cfg")):
+        assert np.isfinite(mine).all()
+        assert max_abs(mine, g[key]) <= 2e-4 and rel_l2(mine, g[key]) <= 2e-5, \
+            (key, max_abs(mine, g[key]), rel_l2(mine, g[key]))
+    z = tt(inp["x"]).requires_grad_(True)
+    with torch.enable_grad():
+        out = wrapped(z, t, y=dict(y, text_scale=tt(inp["text_scale"])), **kw)
+        gx, = torch.autograd.grad((out * tt(inp["gout"])).sum(), z)
+    gx = gx.cpu().numpy()
+    assert float(np.abs(gx[inp["obs_mask"]]).max()) == 0.0
+    assert rel_l2(gx, g["gx"]) <= 5e-5, rel_l2(gx, g["gx"])
+    eng = model._engine
+    for k in (1e-12, 1e9):   # linear in gout: the power-of-two gradient scale passes through the attention sites
+        gk = eng.mdm_vjp(tt(inp["gout"] * np.float32(k))).cpu().numpy().astype(np.float64) / k
+        assert rel_l2(gk, g["gx"]) <= 5e-5, (k, rel_l2(gk, g["gx"]))
+
+
+@pytest.mark.parametrize("B,T", [(3, 100), (1, 224)])
+def test_unet_attention_vs_oracle_other_shapes(cases, B, T):
+    from oracle.unet_oracle import UnetOracle
+    model, _ = make_unet_attention(cases)
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    rng = np.random.default_rng(2000 + 7 * B + T)
+    shape = (B, 263, 1, T)
+    x = rng.standard_normal(shape).astype(np.float32)
+    obs = rng.standard_normal(shape).astype(np.float32)
+    m = rng.random(shape) < 0.2
+    t = rng.integers(0, 1000, B)
+    enc = rng.standard_normal((B, 512)).astype(np.float32)
+    scale = np.full(B, 2.5, np.float32)
+    want, _, _ = UnetOracle(sd).forward_cfg(x, t, enc, scale, obs, m)
+    wrapped = sub("model.cfg_sampler").ClassifierFreeSampleModel(model)
+    got = wrapped(tt(x), tt(t), y={"text_embed": tt(enc), "text_scale": tt(scale)}, obs_x0=tt(obs), obs_mask=tt(m)).cpu().numpy()
+    assert max_abs(got, want) <= 2e-4 and rel_l2(got, want) <= 2e-5, (max_abs(got, want), rel_l2(got, want))
+
+
 @pytest.mark.parametrize("fuse", ["0", "3"])
 def test_unet_forward_groupnorm_fusion_modes(cases, monkeypatch, fuse):
     """CMDI_UNET_FUSE_GN = 0 (separate GroupNorm kernels everywhere) and 3 (fused epilogue at levels 0 AND 1; the default
