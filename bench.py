@@ -338,8 +338,8 @@ def roofline_from(eng, run_loop, split, is_unet, pmc):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 200, or what the config's chain leaves)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps before them (default 20, at most a tenth of the chain)")
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
@@ -381,13 +381,17 @@ def main():
     lo, hi = du.shard_bounds(global_batch, rank, world)
     B = hi - lo                      # this rank's samples [lo, hi) of the global batch
     K, W = args.steps, args.warmup
-    if args.pmc_child:
-        K, W = 3, 2
     is_unet = bool(cfg.get("unet"))
     model, sd = build_unet(dev) if is_unet else build_model(cfg["cfg"], dev)
     diffusion = rs.SpacedDiffusion(rs.space_timesteps(1000, cfg["respacing"]),
                                    gd.DiffusionConfig(betas=gd.get_named_beta_schedule("cosine", 1000)))
     n_chain = diffusion.num_timesteps
+    if args.warmup is None:
+        W = min(20, n_chain // 10)
+    if args.steps is None:
+        K = min(200, n_chain - W)
+    if args.pmc_child:
+        K, W = 3, 2
     assert K + W <= n_chain, f"steps + warmup must be <= {n_chain}"
     sampler = N.CMDI_SAMPLER_DDIM if cfg["sampler"] == "ddim" else N.CMDI_SAMPLER_DDPM
     seed = 20260925
