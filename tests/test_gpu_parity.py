@@ -754,6 +754,21 @@ def test_full_size_batch_independence_and_sharding(precision):
 
 
 # ---- bench.py ------------------------------------------------------------------------------------------
+def test_gelu_epilogue_accuracy():
+    """The GELU of the linear1 epilogue (common.hpp: branch-free erf) against float64 over [-8, 8]: fp32-class — within
+    2.5e-7 of the exact value (times |x| beyond 1), i.e. what a correctly rounded erf followed by two fp32 roundings gives
+    to within a factor of ~2; identity weights make the fp32-MFMA product exact, so the epilogue is what is measured."""
+    from scipy import special
+    E = sub("engine")
+    x = np.concatenate([np.linspace(-8.0, 8.0, 32 * 8192 - 32 * 1024), np.random.default_rng(5).standard_normal(32 * 1024) * 2])
+    x = x.astype(np.float32).reshape(-1, 32)
+    got = E.gemm_nt(tt(x), torch.eye(32, device=DEV), torch.zeros(32, device=DEV), epi=1).cpu().numpy().astype(np.float64)
+    x64 = x.astype(np.float64)
+    want = 0.5 * x64 * (1.0 + special.erf(x64 / np.sqrt(2.0)))
+    err = np.abs(got - want) / np.maximum(1.0, np.abs(x64))
+    assert err.max() <= 2.5e-7, (err.max(), x64.flat[err.argmax()])
+
+
 def test_bench_c5_runs_on_one_gpu():
     """BASELINE configs[4] (batch 1024 sharded over the node, strong scaling): the driver's 8-GPU run must not be the
     first execution of this path — one GPU takes the whole global batch (N = 1 point of the strong-scaling curve)."""
