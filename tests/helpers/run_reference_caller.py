@@ -1,11 +1,12 @@
-"""Run one of the REFERENCE's own sample scripts (sample/edit.py or sample/conditional_synthesis.py ``main()``), unchanged,
+"""Run one of the REFERENCE's own sample scripts (sample/edit.py, sample/conditional_synthesis.py or sample/synthesize.py
+``main()``), unchanged,
 on top of this package: ``compat.install_reference_aliases()`` first, exactly as INTEGRATION.md recipe A says, then the
 reference tree on sys.path.  Only what is NOT on the hot path is stubbed: the HumanML3D data loader (no dataset offline),
 the mp4 plotting and ffmpeg.  The build container has no GPU, so the one call into the hot path —
 ``diffusion.p_sample_loop`` — is recorded: its arguments go through the package's own host-side translation
 (GaussianDiffusion._condition_from_kwargs + _add_observations, i.e. everything up to the native call) and a tensor of the
 right shape comes back, so the script runs to its end and writes results.npy.   Usage:
-    python run_reference_caller.py <edit|conditional_synthesis> <workdir> [script args ...]
+    python run_reference_caller.py <edit|conditional_synthesis|synthesize> <workdir> [script args ...]
 Prints one JSON line describing the recorded call."""
 import importlib
 import json
@@ -38,7 +39,8 @@ def main():
     assert gd.__name__.startswith(PKG), "diffusion.gaussian_diffusion is not the aliased module"
     assert mod.create_model_and_diffusion.__module__.startswith(PKG)
     assert mod.ClassifierFreeSampleModel.__module__.startswith(PKG)
-    assert mod.get_keyframes_mask.__module__.startswith(PKG)
+    if hasattr(mod, "get_keyframes_mask"):
+        assert mod.get_keyframes_mask.__module__.startswith(PKG)
 
     # ---- stubs OUTSIDE the hot path -----------------------------------------------------------------------------
     rng = np.random.default_rng(0)

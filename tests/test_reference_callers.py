@@ -19,7 +19,7 @@ from oracle import ref_shims
 pytestmark = pytest.mark.skipif(not ref_shims.available(), reason="the reference checkout is not on this box")
 
 
-def run_caller(tmp_path, script, model_args, extra):
+def run_caller(tmp_path, script, model_args, extra, edit_args=True):
     mu = sub("utils.model_util")
     model, _ = mu.create_model_and_diffusion(SimpleNamespace(**model_args), None)
     ck = tmp_path / "save" / "ckpt"
@@ -29,7 +29,7 @@ def run_caller(tmp_path, script, model_args, extra):
     (ck / "args.json").write_text(json.dumps(dict(model_args, abs_3d=True, latent_dim=512)))
     cmd = [sys.executable, str(REPO / "tests" / "helpers" / "run_reference_caller.py"), script, str(tmp_path),
            "--model_path", "save/ckpt/model000000010.pt", "--num_samples", "3", "--num_repetitions", "1",
-           "--edit_mode", "benchmark_sparse", "--transition_length", "5", "--output_dir", "out"] + extra
+           "--output_dir", "out"] + (["--edit_mode", "benchmark_sparse", "--transition_length", "5"] if edit_args else []) + extra
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, CUDA_VISIBLE_DEVICES=""))
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     line = next(ln for ln in r.stdout.splitlines() if ln.startswith("CALLER_RESULT "))
@@ -61,4 +61,16 @@ def test_sample_conditional_synthesis_main_runs_unchanged(tmp_path):
     assert call["native_denoiser"] == "MDM_UNET" and call["extra_model_kwargs"] == ["obs_mask", "obs_x0"]
     c = call["condition"]
     assert c["obs_x0"] == [3, 263, 1, 196] and c["obs_mask"] == [3, 263, 1, 196] and c["imputate"] == 1
+    assert "out/results.npy" in res["results"]
+
+
+def test_sample_synthesize_main_runs_unchanged(tmp_path):
+    """reference sample/synthesize.py:39-200 (plain text-to-motion: BASELINE config 2's caller), test-set prompts."""
+    res = run_caller(tmp_path, "synthesize", dict(dataset="humanml", arch="trans_enc", cond_mask_prob=0.1,
+                                                  keyframe_conditioned=False, layers=8), [], edit_args=False)
+    (call,) = res["calls"]
+    assert call["shape"] == [3, 263, 1, 196] and call["native_denoiser"] == "MDM" and call["cfg"] is True
+    assert call["diffusion"].endswith("_amd.diffusion.respace.SpacedDiffusion") and call["n_steps"] == 1000
+    assert {"const_noise", "dump_steps", "init_image", "noise", "progress", "skip_timesteps", "clip_denoised"} <= set(call["kwargs"])
+    assert call["condition"]["text_scale"] == [3] and call["condition"].get("imputate", 0) == 0
     assert "out/results.npy" in res["results"]
