@@ -35,6 +35,7 @@ constexpr int ROWB = 512;                // bytes of one head of one token: 4 ch
 constexpr int TILE = KBLK * ROWB;        // 16 KiB per K or V tile
 constexpr int STAGE = 2 * TILE;
 constexpr int NSTG = 4;                  // LDS ring: 3 stages (96 KiB) in flight ahead of the one being used
+constexpr int kAttnStagDefault = 1;      // two wave groups half a stage apart (attention_h3_kernel); probes build: CMDI_ATTN_STAG
 constexpr int kAttnSplitDefault = 0;     // see launch_attention_h3 (measured: 36.7 vs 35.1 us per layer — no gain, so off)
 
 typedef short s4v __attribute__((ext_vector_type(4)));
@@ -75,7 +76,13 @@ __device__ __forceinline__ h8 tr_pair(const char* p0, const char* p1) {
 // CU, K / V staged once, three stages in flight.  (4, 2): the queries of a (sequence, head) are split over two blocks of
 // 4 waves with a 64-KiB ring each, so TWO blocks share a CU and one's load bursts / epilogue sit under the other's key
 // loop (the pair lands on one XCD: block ids differ by gridDim.x, a multiple of 8, so the second K / V read hits its L2).
-template <bool STASH, int NW = NWAVE, int NS = NSTG>
+// STAG != 0: the waves of a block run in two groups half a stage apart.  All waves of a block otherwise move in lockstep
+// (one barrier per 32-key stage), so the two waves that share a SIMD both issue MFMAs (Sᵀ = K·Qᵀ), then both do the
+// softmax on the VALU with the matrix pipe idle, then both issue MFMAs again (Oᵀ += Vᵀ·Pᵀ).  The lagging group runs
+// [Vᵀ·Pᵀ of the previous stage, K·Qᵀ, softmax] inside a barrier interval where the leading group runs [K·Qᵀ, softmax,
+// Vᵀ·Pᵀ]: one group's softmax falls under the other's products.  The ring then keeps the previous stage alive, so the
+// look-ahead is NS - 2 stages instead of NS - 1.  STAG = 1: waves NW/2.. lag; STAG = 2: odd waves lag.
+template <bool STASH, int NW = NWAVE, int NS = NSTG, int STAG = 0>
 __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const _Float16* __restrict__ qkv,
                                                               float* __restrict__ out,
                                                               _Float16* __restrict__ out_s,
@@ -143,114 +150,134 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const _Float16
     // K/V of a whole (sequence, head) is only 7 stages, each a fabric round trip: keep NSTG - 1 stages
     // in flight (counted vmcnt, raw barrier) so the loop is not one memory latency per 32 keys.
     constexpr int PCS = 32 / NW;   // LDS-DMA pieces per wave per stage
+    constexpr int AHEAD = STAG ? NS - 2 : NS - 1;   // stages requested ahead of the one being multiplied
+    const bool lag = STAG == 1 ? wave >= NW / 2 : (STAG == 2 ? (wave & 1) != 0 : false);
 #pragma unroll
-    for (int st = 0; st < NS - 1; ++st)
+    for (int st = 0; st < AHEAD; ++st)
         if (st < nkb) stage_kv<NW>(lds + st * STAGE, base, ld, koff, voff, st * KBLK, S, wave, lane);
     {
-        const int ahead = (nkb - 1 < NS - 2 ? nkb - 1 : NS - 2);   // stages allowed to stay in flight
+        const int ahead = (nkb - 1 < AHEAD - 1 ? nkb - 1 : AHEAD - 1);   // stages allowed to stay in flight
         if (ahead >= 2) wait_vmcnt<2 * PCS>(); else if (ahead == 1) wait_vmcnt<PCS>(); else wait_vmcnt<0>();
     }
     __builtin_amdgcn_s_barrier();
     if (dbg & 16) t1 = __builtin_readcyclecounter();
 
-    for (int kb = 0; kb < nkb; ++kb) {
-        const int cur = kb % NS;
-        if (kb + NS - 1 < nkb)
-            stage_kv<NW>(lds + ((kb + NS - 1) % NS) * STAGE, base, ld, koff, voff, (kb + NS - 1) * KBLK, S,
-                         wave, lane);
-        if (active) {
-            const char* kt = lds + cur * STAGE;
-            const char* vt = kt + TILE;
-            // ---- scores -------------------------------------------------------------------------
-            f32x16 a0, a1, a2;
+    f32x16 a0, a1, a2;
+    float s[16];
+    // ---- scores of stage kb: Sᵀ = K·Qᵀ ------------------------------------------------------------------
+    auto scores = [&](int kb) {
+        const char* kt = lds + (kb % NS) * STAGE;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; a2[r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; a2[r] = 0.f; }
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                if ((dbg & 1) && ks > 0) break;   // bench-only ablation: 1/8 of the QK^T MFMAs
-                const int t = (ks >> 1) * 8 + (ks & 1) * 2 + hi;
-                const h8 kh = *reinterpret_cast<const h8*>(kt + k_row + ((t ^ fk) << 4));
-                const h8 kl = *reinterpret_cast<const h8*>(kt + k_row + (((t + 4) ^ fk) << 4));
-                a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], a1, 0, 0, 0);
-                a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], a2, 0, 0, 0);
-            }
-            // scores in log2 units: p = 2^(s2 - m2) with s2 = s * log2(e) (v_exp_f32 is a base-2
-            // exponential; the absolute error of p stays below 2.2e-8 because |x| 2^-24 e^-|x| <= 2^-24 / e)
-            float s[16];
-            float mloc = -INFINITY;
+        for (int ks = 0; ks < 8; ++ks) {
+            if ((dbg & 1) && ks > 0) break;   // bench-only ablation: 1/8 of the QK^T MFMAs
+            const int t = (ks >> 1) * 8 + (ks & 1) * 2 + hi;
+            const h8 kh = *reinterpret_cast<const h8*>(kt + k_row + ((t ^ fk) << 4));
+            const h8 kl = *reinterpret_cast<const h8*>(kt + k_row + (((t + 4) ^ fk) << 4));
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], a2, 0, 0, 0);
+        }
+    };
+    // ---- online softmax of stage kb (per query = per lane column): a0..a2 -> p in s[], m_run / l_run / o rescaled ----
+    auto softmax = [&](int kb) {
+        // scores in log2 units: p = 2^(s2 - m2) with s2 = s * log2(e) (v_exp_f32 is a base-2
+        // exponential; the absolute error of p stays below 2.2e-8 because |x| 2^-24 e^-|x| <= 2^-24 / e)
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = (a0[r] + (a1[r] + a2[r]) * kLoInv) * scale2;
+            mloc = fmaxf(mloc, s[r]);
+        }
+        if (kb == nkb - 1) {   // only the last block can hold keys past S (wave-uniform branch)
+            mloc = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                s[r] = (a0[r] + (a1[r] + a2[r]) * kLoInv) * scale2;
+                const int key = kb * KBLK + mfma32_row(r, lane);
+                s[r] = key < S ? s[r] : -INFINITY;
                 mloc = fmaxf(mloc, s[r]);
             }
-            if (kb == nkb - 1) {   // only the last block can hold keys past S (wave-uniform branch)
-                mloc = -INFINITY;
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);   // finite: every block holds a valid key
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // 2^-inf = 0 on the first block
+        float psum = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kb * KBLK + mfma32_row(r, lane);
-                    s[r] = key < S ? s[r] : -INFINITY;
-                    mloc = fmaxf(mloc, s[r]);
-                }
-            }
-            // ---- online softmax (per query = per lane column) -----------------------------------
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-            const float m_new = fmaxf(m_run, mloc);   // finite: every block holds a valid key
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // 2^-inf = 0 on the first block
-            float psum = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                s[r] = (dbg & 2) ? (s[r] - m_new) * 1e-3f : __builtin_amdgcn_exp2f(s[r] - m_new);   // masked keys: 2^-inf = 0
-                psum += s[r];
-            }
-            l_run = l_run * alpha + psum;             // partial over this lane's keys
-            m_run = m_new;
+        for (int r = 0; r < 16; ++r) {
+            s[r] = (dbg & 2) ? (s[r] - m_new) * 1e-3f : __builtin_amdgcn_exp2f(s[r] - m_new);   // masked keys: 2^-inf = 0
+            psum += s[r];
+        }
+        l_run = l_run * alpha + psum;             // partial over this lane's keys
+        m_run = m_new;
+        // (no running maximum of the wave moved: alpha == 1 in every lane and the 64 multiplications are the identity)
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
             for (int db = 0; db < 4; ++db)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-            // ---- Oᵀ += Vᵀ · Pᵀ -------------------------------------------------------------------
+        }
+    };
+    // ---- Oᵀ += Vᵀ · Pᵀ of stage kb (p in s[]) -------------------------------------------------------------
+    auto pv = [&](int kb) {
+        const char* vt = lds + (kb % NS) * STAGE + TILE;
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                if ((dbg & 4) && kk > 0) break;   // bench-only ablation: half of the PV work
-                h8 ph, pl, ps;   // p_hi (round to nearest), p - p_hi (unscaled), p_hi * 2^-11
+        for (int kk = 0; kk < 2; ++kk) {
+            if ((dbg & 4) && kk > 0) break;   // bench-only ablation: half of the PV work
+            h8 ph, pl, ps;   // p_hi (round to nearest), p - p_hi (unscaled), p_hi * 2^-11
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float pv = s[8 * kk + e];
-                    const _Float16 a = (_Float16)pv;
-                    ph[e] = a;
-                    pl[e] = (_Float16)(pv - (float)a);
-                }
-                ps = ph * (_Float16)kLoInv;   // packed f16 multiply: exact (power of two) above 2^-14
-                h8 vh[4], vl[4];
+            for (int e = 0; e < 8; ++e) {
+                const float pvv = s[8 * kk + e];
+                const _Float16 a = (_Float16)pvv;
+                ph[e] = a;
+                pl[e] = (_Float16)(pvv - (float)a);
+            }
+            ps = ph * (_Float16)kLoInv;   // packed f16 multiply: exact (power of two) above 2^-14
+            h8 vh[4], vl[4];
 #pragma unroll
-                for (int db = 0; db < 4; ++db) {
-                    const int k0 = 16 * kk + v_kl, k1 = k0 + 8;
-                    const int t = db * 8 + v_slot;
-                    vh[db] = tr_pair(vt + k0 * ROWB + ((t ^ kswz(k0)) << 4) + v_half,
-                                     vt + k1 * ROWB + ((t ^ kswz(k1)) << 4) + v_half);
-                    vl[db] = tr_pair(vt + k0 * ROWB + (((t + 4) ^ kswz(k0)) << 4) + v_half,
-                                     vt + k1 * ROWB + (((t + 4) ^ kswz(k1)) << 4) + v_half);
-                }
+            for (int db = 0; db < 4; ++db) {
+                const int k0 = 16 * kk + v_kl, k1 = k0 + 8;
+                const int t = db * 8 + v_slot;
+                vh[db] = tr_pair(vt + k0 * ROWB + ((t ^ kswz(k0)) << 4) + v_half,
+                                 vt + k1 * ROWB + ((t ^ kswz(k1)) << 4) + v_half);
+                vl[db] = tr_pair(vt + k0 * ROWB + (((t + 4) ^ kswz(k0)) << 4) + v_half,
+                                 vt + k1 * ROWB + (((t + 4) ^ kswz(k1)) << 4) + v_half);
+            }
 #pragma unroll
-                for (int db = 0; db < 4; ++db)
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[db], ph, o[db], 0, 0, 0);
+            for (int db = 0; db < 4; ++db)
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[db], ph, o[db], 0, 0, 0);
 #pragma unroll
-                for (int db = 0; db < 4; ++db)
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[db], pl, o[db], 0, 0, 0);
+            for (int db = 0; db < 4; ++db)
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[db], pl, o[db], 0, 0, 0);
 #pragma unroll
-                for (int db = 0; db < 4; ++db)
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[db], ps, o[db], 0, 0, 0);
+            for (int db = 0; db < 4; ++db)
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[db], ps, o[db], 0, 0, 0);
+        }
+    };
+
+    for (int kb = 0; kb < nkb; ++kb) {
+        if (kb + AHEAD < nkb)
+            stage_kv<NW>(lds + ((kb + AHEAD) % NS) * STAGE, base, ld, koff, voff, (kb + AHEAD) * KBLK, S, wave, lane);
+        if (active) {
+            if (!lag) {
+                scores(kb);
+                softmax(kb);
+                pv(kb);
+            } else {
+                if (kb > 0) pv(kb - 1);
+                scores(kb);
+                softmax(kb);
             }
         }
         {   // stage kb+1 must have landed; later stages may stay in flight across the barrier
-            const int last = nkb - 1 < kb + NS - 1 ? nkb - 1 : kb + NS - 1;   // newest stage issued
+            const int last = nkb - 1 < kb + AHEAD ? nkb - 1 : kb + AHEAD;   // newest stage issued
             const int ahead = last - (kb + 1);
             if (ahead >= 2) wait_vmcnt<2 * PCS>(); else if (ahead == 1) wait_vmcnt<PCS>(); else wait_vmcnt<0>();
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
+    if (active && lag) pv(nkb - 1);
 
     if (dbg & 16) t2 = __builtin_readcyclecounter();
     if (active) {
@@ -728,7 +755,7 @@ hipError_t launch_attention_bwd_h3(const _Float16* qkv_split, const float* o_fwd
     return hipGetLastError();
 }
 
-template <int NW, int NS>
+template <int NW, int NS, int STAG = 0>
 static hipError_t launch_attention_h3_cfg(const _Float16* qkv_split, float* out, _Float16* out_split, int* range_flag,
                                           float* row_stats, int n_seq, int S, int H, int dbg, long head_rows,
                                           hipStream_t stream) {
@@ -737,19 +764,19 @@ static hipError_t launch_attention_h3_cfg(const _Float16* qkv_split, float* out,
     constexpr size_t lds = (size_t)NS * STAGE;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_h3_kernel<true, NW, NS>),
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_h3_kernel<true, NW, NS, STAG>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_h3_kernel<false, NW, NS>),
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_h3_kernel<false, NW, NS, STAG>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e1 != hipSuccess) return e1;
         if (e2 != hipSuccess) return e2;
         attr_done = true;
     }
     if (row_stats && !(dbg & 16))
-        hipLaunchKernelGGL((attention_h3_kernel<true, NW, NS>), grid, dim3(64 * NW), lds, stream, qkv_split,
+        hipLaunchKernelGGL((attention_h3_kernel<true, NW, NS, STAG>), grid, dim3(64 * NW), lds, stream, qkv_split,
                            out, out_split, range_flag, row_stats, S, H, scale, dbg, head_rows);
     else
-        hipLaunchKernelGGL((attention_h3_kernel<false, NW, NS>), grid, dim3(64 * NW), lds, stream, qkv_split,
+        hipLaunchKernelGGL((attention_h3_kernel<false, NW, NS, STAG>), grid, dim3(64 * NW), lds, stream, qkv_split,
                            out, out_split, range_flag, row_stats, S, H, scale, dbg, head_rows);
     return hipGetLastError();
 }
@@ -769,7 +796,14 @@ hipError_t launch_attention_h3(const _Float16* qkv_split, float* out, _Float16* 
     static const int split = std::getenv("CMDI_ATTN_SPLIT") ? std::atoi(std::getenv("CMDI_ATTN_SPLIT")) : kAttnSplitDefault;
     if (split && S > 128)
         return launch_attention_h3_cfg<4, 2>(qkv_split, out, out_split, range_flag, row_stats, n_seq, S, H, dbg, head_rows, stream);
-    return launch_attention_h3_cfg<NWAVE, NSTG>(qkv_split, out, out_split, range_flag, row_stats, n_seq, S, H, dbg, head_rows, stream);
+#ifdef CMDI_PROBES
+    static const int stag = std::getenv("CMDI_ATTN_STAG") ? std::atoi(std::getenv("CMDI_ATTN_STAG")) : kAttnStagDefault;
+    if (stag == 0)
+        return launch_attention_h3_cfg<NWAVE, NSTG, 0>(qkv_split, out, out_split, range_flag, row_stats, n_seq, S, H, dbg, head_rows, stream);
+    if (stag == 2)
+        return launch_attention_h3_cfg<NWAVE, NSTG, 2>(qkv_split, out, out_split, range_flag, row_stats, n_seq, S, H, dbg, head_rows, stream);
+#endif
+    return launch_attention_h3_cfg<NWAVE, NSTG, kAttnStagDefault>(qkv_split, out, out_split, range_flag, row_stats, n_seq, S, H, dbg, head_rows, stream);
 }
 
 }  // namespace cmdi
