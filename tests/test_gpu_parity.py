@@ -314,6 +314,37 @@ def test_forward_text_cfg_vs_reference(cases, precision):
             (key, max_abs(mine, g[key]), rel_l2(mine, g[key]))
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("B,T", [(1, 1), (1, 2), (2, 31), (3, 64), (5, 100), (1, 196), (2, 223), (9, 33)])
+def test_forward_other_shapes_vs_oracle(precision, B, T):
+    """Frame counts and batch sizes off the golden shapes — one frame, the largest sequence the attention kernels take
+    (T = 223: S = 224), row counts that leave ragged last tiles — CFG forward vs the numpy oracle, plus the input-VJP at
+    the same shapes (the stashing forward takes the un-folded LayerNorm schedule)."""
+    case = dict(text=True, weight_seed=17, cfg=True)
+    model, sd = make_model(case, layers=2, precision=precision)
+    oracle = MDMOracle(sd)
+    rng = np.random.default_rng(3000 + 17 * B + T)
+    shape = (B, 263, 1, T)
+    x = rng.standard_normal(shape).astype(np.float32)
+    t = rng.integers(0, 1000, B)
+    enc = rng.standard_normal((B, 512)).astype(np.float32)
+    scale = rng.uniform(0.0, 3.0, B).astype(np.float32)
+    y = {"text_embed": tt(enc), "text_scale": tt(scale)}
+    want, _, _ = oracle.forward_cfg(x, t, enc, scale)
+    got = model(tt(x), tt(t), y=y).cpu().numpy()
+    assert np.isfinite(got).all()
+    assert max_abs(got, want) <= 2e-4 and rel_l2(got, want) <= 2e-5, (max_abs(got, want), rel_l2(got, want))
+    gout = rng.standard_normal(shape).astype(np.float32)
+    z = tt(x).requires_grad_(True)
+    with torch.enable_grad():
+        out = model(z, tt(t), y=y)
+        gx, = torch.autograd.grad((out * tt(gout)).sum(), z)
+    assert rel_l2(out.detach().cpu().numpy(), want) <= 2e-5
+    want_gx = oracle.vjp_cfg(x, t, gout, enc, scale)
+    want_gx = want_gx[0] if isinstance(want_gx, tuple) else want_gx
+    assert rel_l2(gx.cpu().numpy(), want_gx) <= 5e-5, rel_l2(gx.cpu().numpy(), want_gx)
+
+
 @pytest.mark.parametrize("fold", ["0", "1"])
 def test_forward_layernorm_schedules(cases, monkeypatch, fold):
     """f16x3 forward with the LayerNorms folded into their consuming GEMMs (default: no LayerNorm pass, the residual stream
