@@ -200,23 +200,28 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const _Float16
             }
         }
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float m_new = fmaxf(m_run, mloc);   // finite: every block holds a valid key
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // 2^-inf = 0 on the first block
-        float psum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s[r] = (dbg & 2) ? (s[r] - m_new) * 1e-3f : __builtin_amdgcn_exp2f(s[r] - m_new);   // masked keys: 2^-inf = 0
-            psum += s[r];
-        }
-        l_run = l_run * alpha + psum;             // partial over this lane's keys
-        m_run = m_new;
-        // (no running maximum of the wave moved: alpha == 1 in every lane and the 64 multiplications are the identity)
-        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+        // Lazy reference maximum: m_run moves only when a block's maximum exceeds it by more than 2^LAZY (log2 units), so
+        // p = 2^(s - m_run) stays below 2^LAZY — the hi / lo split of p keeps its 22 bits relative to that — and the 64
+        // accumulator values are rescaled only then (wave-uniform branch; after the first block it is rarely taken).
+        constexpr float LAZY = 8.0f;
+        const bool moved = mloc > m_run + LAZY;          // first block: m_run = -inf
+        if (__builtin_amdgcn_ballot_w64(moved) != 0) {
+            const float m_new = moved ? mloc : m_run;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // 1 where nothing moved, 0 on the first block
+            l_run *= alpha;
+            m_run = m_new;
 #pragma unroll
             for (int db = 0; db < 4; ++db)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
         }
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = (dbg & 2) ? (s[r] - m_run) * 1e-3f : __builtin_amdgcn_exp2f(s[r] - m_run);   // masked keys: 2^-inf = 0
+            psum += s[r];
+        }
+        l_run += psum;                                   // partial over this lane's keys
     };
     // ---- Oᵀ += Vᵀ · Pᵀ of stage kb (p in s[]) -------------------------------------------------------------
     auto pv = [&](int kb) {
