@@ -221,6 +221,16 @@ BIG_CASES = {
     # (EPSILON chains start at respaced index 6 = t 666 from a noised init_image: from t = 999 an UNTRAINED eps-model gives
     # x0 = 2e4 (x - eps), which says nothing about parity)
     "fwd_b256": dict(kind="fwd", text=True, weight_seed=45, B=256, T=196, seed=507, keep=(0, 100, 127, 128, 200, 255)),
+    # (VERDICT r2 task 1a) CHAINS at C4's and C5's shapes.  c4_*: B=256 on the 'ddim100' respacing, CFG, ragged lengths,
+    # the LAST 10 respaced steps (skip_timesteps=90 from a noised init_image) — once through ddim_sample_loop (eta 0) and
+    # once through p_sample_loop on the respaced chain (what the sample scripts do).  c5_rank: one
+    # rank's share of C5 (B=128, C2 settings), 10 respaced steps.
+    "c4_ddim": dict(kind="chain", text=True, cfg=True, weight_seed=46, B=256, T=196, respacing="ddim100", sampler="ddim",
+                    eta=0.0, seed=508, ragged=True, skip=90, init_image=True, keep=(0, 63, 64, 127, 128, 255)),
+    "c4_ddpm": dict(kind="chain", text=True, cfg=True, weight_seed=46, B=256, T=196, respacing="ddim100", sampler="ddpm",
+                    seed=509, ragged=True, skip=90, init_image=True, keep=(0, 63, 64, 127, 128, 255)),
+    "c5_rank": dict(kind="chain", text=True, cfg=True, weight_seed=47, B=128, T=196, respacing=[10], sampler="ddpm",
+                    seed=510, ragged=True, keep=(0, 31, 32, 63, 64, 127)),
 }
 
 
@@ -269,3 +279,24 @@ def sample_stats(a: np.ndarray) -> np.ndarray:
     """Per-sample (sum, sum of squares) in float64 — a cheap check over samples whose tensors are not stored."""
     a = np.asarray(a, dtype=np.float64).reshape(a.shape[0], -1)
     return np.stack([a.sum(1), (a * a).sum(1)], axis=1)
+
+
+# ---- the reference's own callers (VERDICT r2 task 1b): sample/edit.py, sample/conditional_synthesis.py and
+# sample/synthesize.py main() build the p_sample_loop arguments; tests/helpers/run_reference_caller.py records them (and,
+# on the reference's own modules, the reference's output on the [10] respacing) -> tests/golden/caller_<name>.npz.
+# Checkpoint weights = oracle.weights.fill_like over the module's state-dict shapes (a pure function of names, shapes, seed).
+CALLER_CASES = {
+    "edit": dict(script="edit", weight_seed=61,
+                 model_args=dict(dataset="humanml", arch="trans_enc", cond_mask_prob=0.1, keyframe_conditioned=False, layers=8),
+                 cli=["--edit_mode", "benchmark_sparse", "--transition_length", "5", "--imputate", "--reconstruction_guidance",
+                      "--text_condition", "a person walks"]),
+    "conditional_synthesis": dict(script="conditional_synthesis", weight_seed=62,
+                                  model_args=dict(dataset="humanml", arch="unet", cond_mask_prob=0.1, keyframe_conditioned=True,
+                                                  dim_mults=[1, 1, 1, 1], unet_adagn=True, unet_zero=True),
+                                  cli=["--edit_mode", "benchmark_sparse", "--transition_length", "5", "--imputate"]),
+    "synthesize": dict(script="synthesize", weight_seed=63,
+                       model_args=dict(dataset="humanml", arch="trans_enc", cond_mask_prob=0.1, keyframe_conditioned=False,
+                                       layers=8),
+                       cli=[]),
+}
+CALLER_SAMPLES = 3

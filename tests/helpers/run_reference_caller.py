@@ -1,18 +1,33 @@
 """Run one of the REFERENCE's own sample scripts (sample/edit.py, sample/conditional_synthesis.py or sample/synthesize.py
-``main()``), unchanged,
-on top of this package: ``compat.install_reference_aliases()`` first, exactly as INTEGRATION.md recipe A says, then the
-reference tree on sys.path.  Only what is NOT on the hot path is stubbed: the HumanML3D data loader (no dataset offline),
-the mp4 plotting and ffmpeg.  The build container has no GPU, so the one call into the hot path —
-``diffusion.p_sample_loop`` — is recorded: its arguments go through the package's own host-side translation
-(GaussianDiffusion._condition_from_kwargs + _add_observations, i.e. everything up to the native call) and a tensor of the
-right shape comes back, so the script runs to its end and writes results.npy.   Usage:
-    python run_reference_caller.py <edit|conditional_synthesis|synthesize> <workdir> [script args ...]
+``main()``), unchanged, and capture the ONE call it makes into the hot path: ``diffusion.p_sample_loop(model, shape, ...)``.
+
+Two modes (env CALLER_MODE):
+
+``aliased`` (default; what tests/test_reference_callers.py runs)
+    ``compat.install_reference_aliases()`` first, exactly as INTEGRATION.md recipe A says, then the reference tree on
+    sys.path: the script imports THIS package under the reference's module names.  The build container has no GPU, so the
+    call is recorded after the package's own host-side argument translation (GaussianDiffusion._condition_from_kwargs +
+    _add_observations, i.e. everything up to the native call) and a tensor of the right shape comes back, so the script runs
+    to its end and writes results.npy.
+``reference`` (what tests/golden/make_golden_callers.py runs)
+    no aliases: the script runs on the reference's OWN modules (CPU).  The recorded call is then executed by the REAL
+    reference sampler — same model object, same kwargs — on the ``[10]`` respacing of the same DiffusionConfig with an
+    injected noise stream, and its output is stored next to the arguments.
+
+Either way the exact ``shape`` / ``model_kwargs`` / keyword arguments the script built are serialised to
+``<workdir>/recorded_call.npz`` (format: ``dump_call`` below).  The GPU test ``test_reference_callers_replayed_on_the_gpu``
+feeds the `reference`-mode file (committed as tests/golden/caller_<script>.npz) to the native ``p_sample_loop`` and compares
+with the stored reference output; the CPU test asserts that the `aliased` run builds the SAME arguments.
+
+Only what is NOT on the hot path is stubbed: the HumanML3D data loader (no dataset offline), the mp4 plotting, ffmpeg, and
+CLIP (absent offline: the text embedding is a seeded [n, 512] tensor handed to the stub tower / to ``y['text_embed']``).
+Usage:   python run_reference_caller.py <edit|conditional_synthesis|synthesize> <workdir> [script args ...]
 Prints one JSON line describing the recorded call."""
 import importlib
 import json
 import os
 import sys
-import types
+from copy import deepcopy
 from types import SimpleNamespace
 
 import numpy as np
@@ -21,30 +36,82 @@ import torch
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 REFERENCE = os.environ.get("CONDMDI_REFERENCE", "/root/reference")
 PKG = "diffusion-motion-inbetweening_amd"
+REPLAY_STEPS = 10              # the reference output is computed on the [10] respacing
+NOISE_SEED = 7001              # draw k of the replayed chain = default_rng([NOISE_SEED, k]) (k = 0: x_T)
+TEXT_SEED = 7002               # the stand-in CLIP embedding
+
+
+def replay_draw(shape, k):
+    return np.random.default_rng([NOISE_SEED, k]).standard_normal(tuple(shape)).astype(np.float32)
+
+
+def text_embedding(n):
+    return np.random.default_rng(TEXT_SEED).standard_normal((n, 512)).astype(np.float32)
+
+
+def dump_call(path, shape, kw, extra=None):
+    """np.savez: tensors of model_kwargs['y'] as ``y.<key>``, other model_kwargs tensors as ``mk.<key>``, tensor keyword
+    arguments as ``kw.<key>``; everything else (ints, bools, strings, None, lists of strings) in the JSON string ``meta``."""
+    arrays, meta = {}, {"shape": [int(v) for v in shape], "kw": {}, "y": {}, "mk": {}}
+
+    def put(prefix, bucket, k, v):
+        if torch.is_tensor(v):
+            arrays[f"{prefix}.{k}"] = v.detach().cpu().numpy()
+        elif isinstance(v, np.ndarray):
+            arrays[f"{prefix}.{k}"] = v
+        else:
+            json.dumps(v)                                   # must be plain data
+            meta[bucket][k] = v
+
+    for k, v in kw.items():
+        if k != "model_kwargs":
+            put("kw", "kw", k, v)
+    for k, v in kw["model_kwargs"].items():
+        if k == "y":
+            for yk, yv in v.items():
+                put("y", "y", yk, yv)
+        else:
+            put("mk", "mk", k, v)
+    arrays.update(extra or {})
+    np.savez_compressed(path, meta=np.asarray(json.dumps(meta, sort_keys=True)), **arrays)
 
 
 def main():
     script, workdir = sys.argv[1], sys.argv[2]
+    mode = os.environ.get("CALLER_MODE", "aliased")
+    assert mode in ("aliased", "reference"), mode
     sys.path.insert(0, REPO)
-    compat = importlib.import_module(f"{PKG}.compat")
-    compat.install_reference_aliases()                      # INTEGRATION.md, recipe A, line 1
+    if mode == "aliased":
+        compat = importlib.import_module(f"{PKG}.compat")
+        compat.install_reference_aliases()                  # INTEGRATION.md, recipe A, line 1
     sys.path.insert(0, REFERENCE)
     from oracle import ref_shims                            # numpy aliases + clip / spacy / smplx stubs of SURVEY 8c
-    ref_shims._install_stubs()
+    if mode == "reference":
+        ref_shims.import_reference()                        # + identity Rotation2xyz (SMPL files absent)
+        import model.mdm as ref_mdm
+        import model.mdm_unet as ref_unet
+        ref_unet.Rotation2xyz = ref_mdm.Rotation2xyz
+        # SURVEY App. B #1: ClassifierFreeSampleModel reads model.keyframe_conditioned (cfg_sampler.py:20), which the
+        # reference's MDM never sets — edit.py / synthesize.py on a trans_enc checkpoint die with AttributeError without it
+        ref_mdm.MDM.keyframe_conditioned = False
+    else:
+        ref_shims._install_stubs()
     os.chdir(workdir)
 
     # ---- the caller's module, imported UNCHANGED from the reference tree ---------------------------------------
     mod = importlib.import_module(f"sample.{script}")
     gd = importlib.import_module("diffusion.gaussian_diffusion")
-    assert gd.__name__.startswith(PKG), "diffusion.gaussian_diffusion is not the aliased module"
-    assert mod.create_model_and_diffusion.__module__.startswith(PKG)
-    assert mod.ClassifierFreeSampleModel.__module__.startswith(PKG)
+    ours = lambda obj: obj.__module__.startswith(PKG)
+    want = mode == "aliased"
+    assert gd.__name__.startswith(PKG) == want, "diffusion.gaussian_diffusion resolves to the wrong tree"
+    assert ours(mod.create_model_and_diffusion) == want and ours(mod.ClassifierFreeSampleModel) == want
     if hasattr(mod, "get_keyframes_mask"):
-        assert mod.get_keyframes_mask.__module__.startswith(PKG)
+        assert ours(mod.get_keyframes_mask) == want
 
     # ---- stubs OUTSIDE the hot path -----------------------------------------------------------------------------
     rng = np.random.default_rng(0)
     n, T = int(os.environ.get("CALLER_SAMPLES", "3")), 196
+    ref_shims.set_text_embedding(torch.from_numpy(text_embedding(n)))
 
     class FakeT2M:
         mean, std = np.zeros(263, np.float32), np.ones(263, np.float32)
@@ -72,11 +139,12 @@ def main():
     calls = []
     real = gd.GaussianDiffusion.p_sample_loop
 
-    def recorded(self, model, shape, **kw):
+    def recorded_aliased(self, model, shape, **kw):
         mdm, cfg = gd._unwrap_model(model)
+        dump_call(os.path.join(workdir, "recorded_call.npz"), shape, kw)
         y = kw["model_kwargs"]["y"]
         if mdm is not None and "text" in mdm.cond_mode and "text_embed" not in y:
-            y = dict(y, text_embed=torch.zeros(shape[0], 512))          # CLIP is stubbed away on this box
+            y = dict(y, text_embed=torch.from_numpy(text_embedding(shape[0])))   # CLIP is stubbed away on this box
         B, J, F, Tn = shape
         cond = self._condition_from_kwargs(y, mdm, cfg, B, J * F, Tn, torch.device("cpu"))
         gd._add_observations(cond, mdm, kw["model_kwargs"], B, J * F, Tn)
@@ -87,7 +155,29 @@ def main():
                       "diffusion": type(self).__module__ + "." + type(self).__name__, "n_steps": self.num_timesteps})
         return torch.from_numpy(rng.standard_normal(tuple(shape)).astype(np.float32))
 
-    gd.GaussianDiffusion.p_sample_loop = recorded
+    def recorded_reference(self, model, shape, **kw):
+        respace = importlib.import_module("diffusion.respace")
+        conf = deepcopy(self.conf)
+        conf.betas = gd.get_named_beta_schedule("cosine", self.original_num_steps, 1.)   # utils/model_util.py:131
+        short = respace.SpacedDiffusion(use_timesteps=respace.space_timesteps(self.original_num_steps, [REPLAY_STEPS]),
+                                        conf=conf)
+        stream = (torch.from_numpy(replay_draw(shape, k)) for k in range(REPLAY_STEPS + 1))
+        kw_saved = {k: (deepcopy(v) if k == "model_kwargs" else v) for k, v in kw.items()}
+        with ref_shims.injected_noise(stream):
+            out = real(short, model, shape, **kw)
+        inner = getattr(model, "model", model)
+        dump_call(os.path.join(workdir, "recorded_call.npz"), shape, kw_saved,
+                  extra={"ref_sample": out.detach().cpu().numpy(),
+                         "text_embed": text_embedding(shape[0])})
+        calls.append({"shape": list(shape), "native_denoiser": type(inner).__name__,
+                      "cfg": type(model).__name__ == "ClassifierFreeSampleModel",
+                      "kwargs": sorted(k for k in kw if k != "model_kwargs"), "y_keys": sorted(kw["model_kwargs"]["y"]),
+                      "extra_model_kwargs": sorted(set(kw["model_kwargs"]) - {"y"}),
+                      "diffusion": type(self).__module__ + "." + type(self).__name__, "n_steps": self.num_timesteps,
+                      "mean_type": self.model_mean_type.name, "var_type": self.model_var_type.name})
+        return out
+
+    gd.GaussianDiffusion.p_sample_loop = recorded_aliased if mode == "aliased" else recorded_reference
     sys.argv = [f"sample/{script}.py"] + sys.argv[3:]
     try:
         mod.main()

@@ -543,6 +543,79 @@ def test_baseline_shape_chain_vs_reference(cases, name, precision):
     assert stats_close(cases.sample_stats(final), g["stats"], 2e-4)
 
 
+@pytest.mark.parametrize("name", ["c4_ddim", "c4_ddpm", "c5_rank"])
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_c4_c5_shape_chains_vs_reference(cases, name, precision):
+    """CHAINS (not single evaluations) at BASELINE config 4's and 5's shapes vs the real reference: B=256 on the 'ddim100'
+    respacing — its last 10 steps from a noised init_image, through ddim_sample_loop (eta 0) and through p_sample_loop (what
+    the sample scripts call on that respacing) — and one rank's share of config 5 (B=128, 10 respaced steps).  CFG, ragged
+    lengths.  Tile counts, split decisions, workspace offsets and the number of pipelines differ from B=32; the schedule
+    that was actually taken is asserted as observed."""
+    case, inp, g, model, diffusion, kw = big_setup(cases, name, precision)
+    loop = diffusion.ddim_sample_loop if case["sampler"] == "ddim" else diffusion.p_sample_loop
+    final = loop(model, inp["draw0"].shape, **kw)
+    eng = model.model._engine
+    assert eng.pipeline_parts() == C4C5_PARTS[case["B"]], eng.pipeline_parts()
+    final = final.cpu().numpy()
+    keep = list(case["keep"])
+    err = rel_l2(final[keep], g["final"])
+    per = [rel_l2(final[k], g["final"][i]) for i, k in enumerate(keep)]
+    assert err <= 1e-4 and max(per) <= 2e-4, (err, per)
+    assert stats_close(cases.sample_stats(final), g["stats"], 2e-4)
+
+
+C4C5_PARTS = {256: 2, 128: 2}     # engine pipelines at these batch sizes (api_sampler.hip n_parts), as observed
+
+
+@pytest.mark.parametrize("name", ["synthesize", "edit", "conditional_synthesis"])
+@pytest.mark.parametrize("progress", [True, False])
+def test_reference_callers_replayed_on_the_gpu(cases, name, progress):
+    """tests/golden/caller_<name>.npz holds the EXACT shape / model_kwargs / keyword arguments the reference's own
+    sample/<name>.py main() passes to diffusion.p_sample_loop (recorded while the script ran unchanged on the reference's
+    modules; tests/test_reference_callers.py asserts that the script builds the same arguments on THIS package) and the real
+    reference sampler's output for that call on the [10] respacing with injected noise.  Here the recorded call goes through
+    the native p_sample_loop — nothing mocked.  Deviations, both forced by the offline box: CLIP is absent, so y['text']
+    comes with its stand-in embedding as y['text_embed']; the noise stream is injected (torch CPU randn != device Philox).
+    progress=True is what the scripts pass (per-step cmdi_step path); False takes the one-call cmdi_sample_loop path."""
+    import json
+    case = cases.CALLER_CASES[name]
+    g = load_golden(f"caller_{name}")
+    meta = json.loads(str(g["meta"]))
+    mu, rs, gd = sub("utils.model_util"), sub("diffusion.respace"), sub("diffusion.gaussian_diffusion")
+    # what the script does: create_model_and_diffusion(args from the checkpoint's args.json) + load_saved_model
+    args = SimpleNamespace(**dict(case["model_args"], abs_3d=True, latent_dim=512))
+    model, diffusion = mu.create_model_and_diffusion(args, None)
+    own = {k: v for k, v in model.state_dict().items() if not k.startswith("clip_model.")}
+    sd = weights.fill_like({k: tuple(v.shape) for k, v in own.items()}, case["weight_seed"])
+    mu.load_model_wo_clip(model, weights.to_torch(sd) | {k: v for k, v in own.items() if k.endswith(".pe")})
+    model = sub("model.cfg_sampler").ClassifierFreeSampleModel(model)       # guidance_param != 1 in all three scripts
+    model.to(DEV).eval()
+    assert diffusion.num_timesteps == 1000
+    conf = diffusion.conf
+    conf.betas = gd.get_named_beta_schedule("cosine", 1000)
+    short = rs.SpacedDiffusion(rs.space_timesteps(1000, [10]), conf)
+    shape = tuple(meta["shape"])
+    sys_path_helper = str(__import__("pathlib").Path(__file__).resolve().parent / "helpers")
+    import sys
+    if sys_path_helper not in sys.path:
+        sys.path.insert(0, sys_path_helper)
+    from run_reference_caller import replay_draw
+    short.injected_noise = torch.from_numpy(np.stack([replay_draw(shape, k) for k in range(11)])).to(DEV)
+    y = dict(meta["y"])
+    y.update({k[2:]: tt(g[k]) for k in g.files if k.startswith("y.")})
+    y["text_embed"] = tt(g["text_embed"])
+    model_kwargs = {"y": y}
+    model_kwargs.update(meta["mk"])
+    model_kwargs.update({k[3:]: tt(g[k]) for k in g.files if k.startswith("mk.")})
+    kw = dict(meta["kw"])
+    kw.update({k[3:]: tt(g[k]) for k in g.files if k.startswith("kw.")})
+    assert kw["progress"] is True and kw["noise"] is None and kw["clip_denoised"] is False
+    kw["progress"] = progress
+    out = short.p_sample_loop(model, shape, model_kwargs=model_kwargs, **kw).cpu().numpy()
+    err = rel_l2(out, g["ref_sample"])
+    assert np.isfinite(out).all() and err <= (2e-4 if name == "conditional_synthesis" else 1e-4), err
+
+
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_forced_two_pipelines_on_small_golden(cases, precision, monkeypatch):
     """CMDI_GROUPS=2 forces the part_forward / part_backward schedule on a small reference chain (B=2: one sample per

@@ -1,46 +1,51 @@
 """north_star: 'sample.conditional_synthesis and sample.edit call the new path unchanged'.  These tests EXECUTE the
-reference's own ``main()`` of both scripts (from /root/reference, untouched) on top of compat.install_reference_aliases(),
-with only the data loader / plotting stubbed (tests/helpers/run_reference_caller.py).  The build container has no GPU, so
-the p_sample_loop call itself is recorded after the package's host-side argument translation; the kernels behind it are
-covered by the -m gpu tests, which feed p_sample_loop the same model_kwargs these scripts build.
+reference's own ``main()`` of the three scripts (from /root/reference, untouched) on top of
+compat.install_reference_aliases(), with only the data loader / plotting / CLIP stubbed
+(tests/helpers/run_reference_caller.py, mode `aliased`).  The build container has no GPU, so the p_sample_loop call itself is
+recorded after the package's host-side argument translation — AND its exact arguments (shape, model_kwargs, keyword
+arguments) are compared, tensor by tensor, with tests/golden/caller_<script>.npz: the arguments the SAME script builds on the
+reference's OWN modules, stored together with the real reference sampler's output for them
+(tests/golden/make_golden_callers.py).  On the GPU box tests/test_gpu_parity.py::test_reference_callers_replayed_on_the_gpu
+feeds those arguments to the native p_sample_loop and compares with that output — the two halves together take the mock out
+of the argument: same call (here), same result for that call (there).
 Needs /root/reference: skipped on the GPU box."""
 import json
-import os
-import subprocess
 import sys
-from types import SimpleNamespace
 
+import numpy as np
 import pytest
-import torch
 
-from conftest import REPO, sub
+from conftest import GOLDEN, REPO
 from oracle import ref_shims
+
+sys.path.insert(0, str(REPO / "tests" / "helpers"))
+import caller_setup  # noqa: E402
 
 pytestmark = pytest.mark.skipif(not ref_shims.available(), reason="the reference checkout is not on this box")
 
 
-def run_caller(tmp_path, script, model_args, extra, edit_args=True):
-    mu = sub("utils.model_util")
-    model, _ = mu.create_model_and_diffusion(SimpleNamespace(**model_args), None)
-    ck = tmp_path / "save" / "ckpt"
-    ck.mkdir(parents=True)
-    torch.save({"model": {k: v for k, v in model.state_dict().items() if not k.startswith("clip_model.")}},
-               ck / "model000000010.pt")
-    (ck / "args.json").write_text(json.dumps(dict(model_args, abs_3d=True, latent_dim=512)))
-    cmd = [sys.executable, str(REPO / "tests" / "helpers" / "run_reference_caller.py"), script, str(tmp_path),
-           "--model_path", "save/ckpt/model000000010.pt", "--num_samples", "3", "--num_repetitions", "1",
-           "--output_dir", "out"] + (["--edit_mode", "benchmark_sparse", "--transition_length", "5"] if edit_args else []) + extra
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, CUDA_VISIBLE_DEVICES=""))
-    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
-    line = next(ln for ln in r.stdout.splitlines() if ln.startswith("CALLER_RESULT "))
-    return json.loads(line[len("CALLER_RESULT "):])
+def run_caller(tmp_path, cases, name):
+    case = cases.CALLER_CASES[name]
+    caller_setup.write_checkpoint(tmp_path, case["model_args"], case["weight_seed"])
+    res = caller_setup.run_script(tmp_path, case, "aliased", cases.CALLER_SAMPLES)
+    same_call_as_the_reference_run(tmp_path / "recorded_call.npz", GOLDEN / f"caller_{name}.npz")
+    return res
 
 
-def test_sample_edit_main_runs_unchanged(tmp_path):
+def same_call_as_the_reference_run(ours_path, golden_path):
+    """Every argument of the recorded p_sample_loop call — the script running on THIS package — equals what the script
+    passes when it runs on the reference's own modules (get_keyframes_mask output included: bit-exact)."""
+    ours, gold = np.load(ours_path), np.load(golden_path)
+    assert json.loads(str(ours["meta"])) == json.loads(str(gold["meta"]))
+    arg_keys = lambda z: sorted(k for k in z.files if k.split(".")[0] in ("y", "mk", "kw"))
+    assert arg_keys(ours) == arg_keys(gold)
+    for k in arg_keys(gold):
+        assert ours[k].dtype == gold[k].dtype and np.array_equal(ours[k], gold[k]), k
+
+
+def test_sample_edit_main_runs_unchanged(tmp_path, cases):
     """reference sample/edit.py:26-264: imputation + reconstruction guidance (BASELINE config 3's caller)."""
-    res = run_caller(tmp_path, "edit", dict(dataset="humanml", arch="trans_enc", cond_mask_prob=0.1,
-                                            keyframe_conditioned=False, layers=8),
-                     ["--imputate", "--reconstruction_guidance"])
+    res = run_caller(tmp_path, cases, "edit")
     (call,) = res["calls"]
     assert call["shape"] == [3, 263, 1, 196] and call["native_denoiser"] == "MDM" and call["cfg"] is True
     assert call["diffusion"].endswith("_amd.diffusion.respace.SpacedDiffusion") and call["n_steps"] == 1000
@@ -52,11 +57,9 @@ def test_sample_edit_main_runs_unchanged(tmp_path):
     assert "out/results.npy" in res["results"]
 
 
-def test_sample_conditional_synthesis_main_runs_unchanged(tmp_path):
+def test_sample_conditional_synthesis_main_runs_unchanged(tmp_path, cases):
     """reference sample/conditional_synthesis.py:26-330 with a keyframe-conditioned MDM_UNET (obs_x0 / obs_mask)."""
-    res = run_caller(tmp_path, "conditional_synthesis",
-                     dict(dataset="humanml", arch="unet", cond_mask_prob=0.1, keyframe_conditioned=True,
-                          dim_mults=[1, 1, 1, 1], unet_adagn=True, unet_zero=True), ["--imputate"])
+    res = run_caller(tmp_path, cases, "conditional_synthesis")
     (call,) = res["calls"]
     assert call["native_denoiser"] == "MDM_UNET" and call["extra_model_kwargs"] == ["obs_mask", "obs_x0"]
     c = call["condition"]
@@ -64,10 +67,9 @@ def test_sample_conditional_synthesis_main_runs_unchanged(tmp_path):
     assert "out/results.npy" in res["results"]
 
 
-def test_sample_synthesize_main_runs_unchanged(tmp_path):
+def test_sample_synthesize_main_runs_unchanged(tmp_path, cases):
     """reference sample/synthesize.py:39-200 (plain text-to-motion: BASELINE config 2's caller), test-set prompts."""
-    res = run_caller(tmp_path, "synthesize", dict(dataset="humanml", arch="trans_enc", cond_mask_prob=0.1,
-                                                  keyframe_conditioned=False, layers=8), [], edit_args=False)
+    res = run_caller(tmp_path, cases, "synthesize")
     (call,) = res["calls"]
     assert call["shape"] == [3, 263, 1, 196] and call["native_denoiser"] == "MDM" and call["cfg"] is True
     assert call["diffusion"].endswith("_amd.diffusion.respace.SpacedDiffusion") and call["n_steps"] == 1000
