@@ -25,6 +25,12 @@ def caller_state_dict(model_args: dict, weight_seed: int) -> dict:
     mu = importlib.import_module(f"{PKG}.utils.model_util")
     model, _ = mu.create_model_and_diffusion(SimpleNamespace(**model_args), None)
     own = {k: v for k, v in model.state_dict().items() if not k.startswith("clip_model.")}
+    if model_args.get("arch", "trans_enc") == "trans_enc":
+        # (fill_like would draw self_attn.in_proj_weight — a name that does not end in '.weight' — like a bias, std 0.1:
+        # 16x the attention logits of a default-initialised layer, and the sampling chain turns chaotic)
+        sd = weights.make_state_dict(weight_seed, n_layers=model_args.get("layers", 8), text=True)
+        assert sorted(sd) == sorted(own), sorted(set(sd) ^ set(own))
+        return sd
     sd = weights.fill_like({k: tuple(v.shape) for k, v in own.items()}, weight_seed)
     # positional tables are persistent buffers of the reference modules, i.e. part of every real checkpoint
     sd.update({k: v.numpy().copy() for k, v in own.items() if k.endswith(".pe")})

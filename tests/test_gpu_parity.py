@@ -578,6 +578,12 @@ def test_reference_callers_replayed_on_the_gpu(cases, name, progress):
     comes with its stand-in embedding as y['text_embed']; the noise stream is injected (torch CPU randn != device Philox).
     progress=True is what the scripts pass (per-step cmdi_step path); False takes the one-call cmdi_sample_loop path."""
     import json
+    import sys
+    helpers = str(__import__("pathlib").Path(__file__).resolve().parent / "helpers")
+    if helpers not in sys.path:
+        sys.path.insert(0, helpers)
+    import caller_setup
+    from run_reference_caller import replay_draw
     case = cases.CALLER_CASES[name]
     g = load_golden(f"caller_{name}")
     meta = json.loads(str(g["meta"]))
@@ -585,9 +591,7 @@ def test_reference_callers_replayed_on_the_gpu(cases, name, progress):
     # what the script does: create_model_and_diffusion(args from the checkpoint's args.json) + load_saved_model
     args = SimpleNamespace(**dict(case["model_args"], abs_3d=True, latent_dim=512))
     model, diffusion = mu.create_model_and_diffusion(args, None)
-    own = {k: v for k, v in model.state_dict().items() if not k.startswith("clip_model.")}
-    sd = weights.fill_like({k: tuple(v.shape) for k, v in own.items()}, case["weight_seed"])
-    mu.load_model_wo_clip(model, weights.to_torch(sd) | {k: v for k, v in own.items() if k.endswith(".pe")})
+    mu.load_model_wo_clip(model, weights.to_torch(caller_setup.caller_state_dict(case["model_args"], case["weight_seed"])))
     model = sub("model.cfg_sampler").ClassifierFreeSampleModel(model)       # guidance_param != 1 in all three scripts
     model.to(DEV).eval()
     assert diffusion.num_timesteps == 1000
@@ -595,11 +599,6 @@ def test_reference_callers_replayed_on_the_gpu(cases, name, progress):
     conf.betas = gd.get_named_beta_schedule("cosine", 1000)
     short = rs.SpacedDiffusion(rs.space_timesteps(1000, [10]), conf)
     shape = tuple(meta["shape"])
-    sys_path_helper = str(__import__("pathlib").Path(__file__).resolve().parent / "helpers")
-    import sys
-    if sys_path_helper not in sys.path:
-        sys.path.insert(0, sys_path_helper)
-    from run_reference_caller import replay_draw
     short.injected_noise = torch.from_numpy(np.stack([replay_draw(shape, k) for k in range(11)])).to(DEV)
     y = dict(meta["y"])
     y.update({k[2:]: tt(g[k]) for k in g.files if k.startswith("y.")})
