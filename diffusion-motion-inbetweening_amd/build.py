@@ -29,6 +29,7 @@ UNITS = {
     "api_hooks.hip": [],
     "gemm_f32.hip": [],
     "gemm_h3.hip": [],
+    "gemm_h3p.hip": [],
     "gemm_x6.hip": [],
     "attention_f32.hip": [],
     "attention_h3.hip": [],

@@ -1,5 +1,7 @@
 // Instantiations + host dispatcher of the split-f16 (fp32-equivalent) NT GEMM family (gemm_h3.hpp)
 // and the fp32 -> split-rows conversion kernel.
+#include <cstdlib>
+
 #include "gemm_h3.hpp"
 #include "kernels.hpp"
 
@@ -131,6 +133,19 @@ int gemm_h3_auto_tile(int M, int N) {
     return tiles < 384 ? 21 : 8;
 }
 
+// The persistent kernel (gemm_h3p.hpp) computes the same bits as the tiles above; which one runs is a pure speed choice.
+// Measured on MI355X (tools/h3p_check.py): it wins from M ~ 50,000 rows up (in_proj at B=256: 536 vs 568 us) and loses below
+// (M = 12,608: 84-88 vs 77-80 us — 2.3 tiles per CU, one epilogue per tile with the matrix pipe idle).  CMDI_H3_PERSIST=0 / 1
+// forces never / whenever supported.
+bool gemm_h3_persistent_for(int M) {
+    static int mode = -2;
+    if (mode == -2) {
+        const char* v = std::getenv("CMDI_H3_PERSIST");
+        mode = v ? std::atoi(v) : -1;
+    }
+    return mode == 1 || (mode == -1 && M >= 32768);
+}
+
 hipError_t launch_gemm_h3(int epi, const H3Params& p, int tile, hipStream_t s) {
     if (p.K % 32 != 0 || (p.N % 8 != 0 && epi != H3_MOTION) || p.M <= 0 || p.N <= 0) return hipErrorInvalidValue;
     if (epi == H3_RESID_LN) {
@@ -144,6 +159,9 @@ hipError_t launch_gemm_h3(int epi, const H3Params& p, int tile, hipStream_t s) {
     if ((p.out_part && (epi != H3_RESID || p.N != 512)) || (p.ln_rg && (epi != H3_RESID || !p.Rs || !p.ln_part || p.N != 512)) ||
         (p.ln_c1 && (!p.ln_part || p.K != 512)))
         return hipErrorInvalidValue;
+    if (tile == 50) return launch_gemm_h3p(epi, p, s, 0);
+    if (tile == 0 && gemm_h3_persistent_for(p.M) && gemm_h3p_supports(epi, p)) return launch_gemm_h3p(epi, p, s, 0);
+    if (tile >= 1000) return launch_gemm_h3p(epi, p, s, tile - 1000);   // structure variants / ablations (probes library only)
     if (tile == 0) tile = gemm_h3_auto_tile(p.M, p.N);
     if (epi == H3_CONV_GN) {   // tile rows = one framed sequence: 256 (level 0) or 128 (level 1)
         if (!p.ln_g || !p.ln_b || (!p.C && !p.Cs) || p.N % 128 != 0 || (p.gn_cg != 128 && p.gn_cg != 64) || p.M % p.tp != 0 ||

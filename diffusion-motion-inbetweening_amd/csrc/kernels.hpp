@@ -36,6 +36,10 @@ hipError_t launch_pack_x6(const float* src, void* dst, int64_t rows, int cols, i
 // 21 = 64x128 8 waves (2)
 hipError_t launch_gemm_h3(int epi, const H3Params& p, int tile, hipStream_t stream);
 int gemm_h3_auto_tile(int M, int N);
+// gemm_h3p.hip: the persistent, phase-alternating kernel (tile id 50 of launch_gemm_h3); same bits as the tiles above
+bool gemm_h3p_supports(int epi, const H3Params& p);
+bool gemm_h3_persistent_for(int M);   // policy (CMDI_H3_PERSIST), gemm_h3.hip
+hipError_t launch_gemm_h3p(int epi, const H3Params& p, hipStream_t stream, int ablation = 0);   // ablation: probes library only
 // fp32 [rows][cols] (row stride ld_src) -> split rows [rows][2*cols] halves (format: gemm_h3.hpp)
 hipError_t launch_split_f16(const float* src, _Float16* dst, int64_t rows, int cols, int64_t ld_src,
                             int* range_flag, hipStream_t stream);

@@ -135,6 +135,31 @@ def test_gemm_h3(tile, shape):
     assert rel_l2(out.numpy(), ref.numpy()) <= 2e-6
 
 
+@pytest.mark.parametrize("shape", [(333, 512, 512), (128, 256, 64), (129, 256, 96), (197 * 4, 1536, 512), (1000, 512, 1024),
+                                   (12608, 1536, 64), (12608, 1536, 512), (6304, 1024, 512), (40000, 256, 512), (33000, 768, 128)])
+def test_gemm_h3_persistent_is_bitwise_the_tiled_kernel(shape):
+    """gemm_h3p.hpp (tile id 50: persistent grid of 128 x 256 tiles + 128 x 128 half tiles in the last partial round, two wave
+    groups alternating between fragment reads and products, LDS-DMA ring of three stages running ahead across tile
+    boundaries, epilogue with 8 columns per lane) must produce the SAME BITS as the one-tile-per-block kernel (tile 8) for
+    every epilogue: which of the two runs is a speed decision taken from M (gemm_h3_persistent_for), and a sample must not
+    depend on the size of the batch it is sampled in.  Shapes: ragged last row tile, K of 2 / 3 / 16 / 32 steps, fewer tiles
+    than CUs, rounds with and without half tiles."""
+    eng = sub("engine")
+    m, n, k = shape
+    g = torch.Generator().manual_seed(m * 7 + n + k)
+    a = torch.randn(m, k, generator=g).to(DEV)
+    w = (torch.randn(n, k, generator=g) * (torch.arange(n).float()[:, None] % 7 + 1) * 0.05).to(DEV)
+    b = torch.randn(n, generator=g).to(DEV)
+    r = torch.randn(m, n, generator=g).to(DEV)
+    a_s, w_s, r_s = eng.split_f16(a), eng.split_f16(w), eng.split_f16(r)
+    ref64 = a.double() @ w.double().T + b.double()
+    for epi, kw in ((0, dict(split_out=True)), (0, {}), (1, {}), (3, dict(resid=r)), (4, dict(resid=r_s))):
+        ref = eng.gemm_h3(a_s, w_s, b, tile=8, epi=epi, **kw)
+        out = eng.gemm_h3(a_s, w_s, b, tile=50, epi=epi, **kw)
+        assert torch.equal(out, ref), (shape, epi, kw.keys())
+    assert rel_l2(eng.gemm_h3(a_s, w_s, b, tile=50).cpu().numpy(), ref64.cpu().numpy()) <= 2e-6
+
+
 # ---- bf16x6: exact three-plane bf16 operands, six MFMA products (fp32-class, no operand truncation) -----------------
 def test_pack_x6_is_exact():
     """W = p0 + p1 + p2 EXACTLY for every finite binary32 (24 significant bits = three bf16 mantissas), over the whole
