@@ -259,7 +259,7 @@ __global__ __launch_bounds__(H3PTile::NT, 2) void gemm_h3p_kernel(const H3Params
     constexpr bool NO_WAIT = (ABL & 128) != 0;       // ablation: requests are never waited for (wrong results, timing only)
     constexpr bool HALF_DMA = (ABL & 256) != 0;      // ablation: only half of the pieces are requested
     constexpr bool NO_STORE = (ABL & 512) != 0;      // ablation: the epilogue computes but does not store
-    constexpr bool TWO_INT = (ABL & 32) != 0;        // structure variants under test: K step = two barrier intervals instead of four
+    constexpr bool TWO_INT = (ABL & 32) == 0;        // K step = TWO barrier intervals (ABL & 32: the first version's four, for A/B)        // structure variants under test: K step = two barrier intervals instead of four
     constexpr int TAILN = (ABL & 64) ? 4 : 2;        // MFMAs behind an interval's closing barrier
     constexpr int STAGE = TC::STAGE;
     extern __shared__ __attribute__((aligned(16))) char lds[];
