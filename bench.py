@@ -335,6 +335,24 @@ def roofline_from(eng, run_loop, split, is_unet, pmc):
     return rl
 
 
+def job_layout(cfg: dict, world: int, rank: int, shard_bounds) -> dict:
+    """The rank arithmetic of a run, a pure function (tests/test_host_logic.py checks it for N = 1, 2, 4, 8 without a GPU).
+    Weak scaling (c2 / c3 / c4): every rank steps its own batch of cfg['B'], the job's batch is N * B.  Strong scaling (c5):
+    ONE global batch of cfg['B'] cut into contiguous shards [lo, hi) by utils.dist_util.shard_bounds."""
+    strong = bool(cfg.get("strong"))
+    global_batch = cfg["B"] if strong else world * cfg["B"]
+    lo, hi = shard_bounds(global_batch, rank, world)
+    return {"strong": strong, "global_batch": global_batch, "lo": lo, "hi": hi, "batch": hi - lo}
+
+
+def job_rates(layout: dict, world: int, K: int, elapsed_s: float, n_chain: int) -> dict:
+    """Whole-job numbers from the max-over-ranks time of K steps.  Weak scaling: the job advances N batch-steps per step
+    time; strong scaling: ONE global batch, so steps/s is 1 / step time and motions/s carries the scaling."""
+    steps_per_s = (1 if layout["strong"] else world) * K / elapsed_s
+    return {"steps_per_s": steps_per_s, "ms_per_step": elapsed_s / K * 1e3,
+            "motions_per_sec": layout["global_batch"] / (n_chain * elapsed_s / K)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -372,14 +390,13 @@ def main():
 
     gd, rs, du = sub("diffusion.gaussian_diffusion"), sub("diffusion.respace"), sub("utils.dist_util")
     N = sub("_native")
-    strong = bool(cfg.get("strong"))
     if args.batch > 0:
         cfg["B"] = args.batch
         if not args.pmc_child:
             cfg["desc"] += f" [batch overridden to {args.batch}]"
-    global_batch = cfg["B"] if strong else world * cfg["B"]
-    lo, hi = du.shard_bounds(global_batch, rank, world)
-    B = hi - lo                      # this rank's samples [lo, hi) of the global batch
+    layout = job_layout(cfg, world, rank, du.shard_bounds)
+    strong, global_batch, lo, hi = layout["strong"], layout["global_batch"], layout["lo"], layout["hi"]
+    B = layout["batch"]              # this rank's samples [lo, hi) of the global batch
     K, W = args.steps, args.warmup
     is_unet = bool(cfg.get("unet"))
     model, sd = build_unet(dev) if is_unet else build_model(cfg["cfg"], dev)
@@ -461,14 +478,15 @@ def main():
 
     # whole-job throughput.  Weak scaling: every rank steps its own batch, so the job advances N batch-steps per
     # step time; strong scaling (c5): ONE global batch, so steps/s is 1 / step time and motions/s carries the scaling
-    steps_per_s = (1 if strong else world) * K / elapsed
+    rates = job_rates(layout, world, K, elapsed, n_chain)
+    steps_per_s = rates["steps_per_s"]
     passes = 2 if cfg["cfg"] else 1
     flop_step = B * passes * flops_per_sample_eval() * (30.68 / 14.706 if cfg["edit"] else 1.0)
     if is_unet:   # the input-VJP repeats every convolution GEMM once (dX only, no weight gradients)
         flop_step = B * passes * unet_flops_per_sample_eval() * (2.0 if cfg["edit"] else 1.0)
     out = {
         "metric": "diffusion denoising steps/sec", "value": steps_per_s, "unit": "steps/s",
-        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": rates["ms_per_step"],
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": {"f16x3": "f32 (products as 3 split-f16 MFMAs on 22-bit operand pairs, fp32 accumulate)",
                   "bf16x6": "f32 (operands carried exactly as three bf16 planes, 6 bf16 MFMA partial products per fp32 "
@@ -479,7 +497,7 @@ def main():
         "config": {"workload": cfg["desc"], "batch_per_gpu": B, "global_batch": global_batch,
                    "n_frames": T_FRAMES, "n_feats": N_FEATS, "chain_steps": n_chain,
                    "parallelism": f"batch-sharded x{world}"},
-        "motions_per_sec": global_batch / (n_chain * elapsed / K),
+        "motions_per_sec": rates["motions_per_sec"],
         "step_tflops": flop_step / (elapsed / K) / 1e12,
         "step_frac_of_fp32_mfma_peak": flop_step / (elapsed / K) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
         "allgather_ms": gather_ms, "n_ranks_seen": n_ranks_seen,

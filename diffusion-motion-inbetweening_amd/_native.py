@@ -96,6 +96,7 @@ SIGNATURES = {
     "cmdi_attention_fwd_h3": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _VP]),
     "cmdi_precision": (C.c_int, [_VP]),
     "cmdi_range_status": (C.c_int, [_VP, C.POINTER(_I32), _VP]),
+    "cmdi_range_clear": (C.c_int, [_VP, _VP]),
     "cmdi_split_f16": (C.c_int, [_VP, _VP, _I64, _I32, _VP]),
     "cmdi_gemm_h3": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _VP]),
     "cmdi_clip_create": (C.c_int, [C.POINTER(ClipDesc), C.POINTER(_VP)]),

@@ -31,7 +31,14 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
         // the temporal U-Net of unet.hip; the sampler / condition machinery is shared
         if (desc->d_model != 512 || desc->max_frames > 224 || desc->pe_rows < 1)
             return fail(CMDI_E_INVALID, "UNET engine: latent_dim must be 512, max_frames <= 224");
-        if (desc->precision == CMDI_PREC_F32) return fail(CMDI_E_INVALID, "UNET engine: only the f16x3 precision is built");
+        if (desc->precision == CMDI_PREC_F32 || desc->precision == CMDI_PREC_BF16X6)
+            return fail(CMDI_E_INVALID, "UNET engine: only the f16x3 precision is built (CMDI_PREC_F16X3 or CMDI_PREC_DEFAULT)");
+        if (desc->precision == CMDI_PREC_DEFAULT) {   // (an environment override naming a mode this arch does not have)
+            const char* v = std::getenv("CMDI_PRECISION");
+            const std::string name = v ? v : "";
+            if (name == "f32" || name == "bf16x6")
+                return fail(CMDI_E_INVALID, "UNET engine: CMDI_PRECISION names a precision that is not built for this arch (f16x3 only)");
+        }
         cmdi_engine* e = new cmdi_engine();
         e->desc = *desc;
         e->d = desc->d_model; e->C = desc->n_feats; e->Tmax = desc->max_frames; e->Bmax = desc->max_batch;

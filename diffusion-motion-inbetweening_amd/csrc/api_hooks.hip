@@ -119,6 +119,17 @@ int cmdi_range_status(cmdi_handle e, int32_t* out_flag, cmdi_stream stream) {
     return CMDI_OK;
 }
 
+int cmdi_range_clear(cmdi_handle e, cmdi_stream stream) {
+    if (!e) return fail(CMDI_E_INVALID, "null handle");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (e->range_flag) HIPCHK(hipMemsetAsync(e->range_flag, 0, sizeof(int), s));
+    if (e->unet) {
+        int uf = 0;   // (the U-Net's flag is read-and-cleared in one call)
+        if (unet_range_flag(e->unet, &uf, s) != 0) return fail(CMDI_E_HIP, "UNET: range flag read-back failed");
+    }
+    return CMDI_OK;
+}
+
 int cmdi_split_f16(const float* d_src, void* d_dst, int64_t rows, int32_t cols, cmdi_stream stream) {
     if (!d_src || !d_dst || rows < 1 || cols < 32 || cols % 32 != 0)
         return fail(CMDI_E_INVALID, "bad argument (cols must be a positive multiple of 32)");

@@ -189,6 +189,14 @@ class GaussianDiffusion:
     def _original_num_steps(self):
         return self.num_timesteps
 
+    def _model_variance(self):
+        """Reference :466-480: FIXED_SMALL -> posterior_variance, FIXED_LARGE -> append(posterior_variance[1], betas[1:])."""
+        if self.model_var_type == ModelVarType.FIXED_SMALL:
+            return self.posterior_variance
+        if self.model_var_type == ModelVarType.FIXED_LARGE:
+            return np.append(self.posterior_variance[1], self.betas[1:])
+        raise NotImplementedError(f"learned variances are not supported by the sampling engine ({self.model_var_type})")
+
     def _model_log_variance(self):
         if self.model_var_type == ModelVarType.FIXED_SMALL:
             return self.posterior_log_variance_clipped
@@ -310,6 +318,7 @@ class GaussianDiffusion:
         cond = self._condition_from_kwargs(y, mdm, cfg, B, J * F, T, device)
         _add_observations(cond, mdm, model_kwargs, B, J * F, T)
         eng.set_condition(**cond)
+        eng.clear_range()      # a chain reports its own range / timestep events only
 
         first = int(y.get('first_sample', self.first_sample))
         seed = _fresh_seed()
@@ -377,6 +386,9 @@ class GaussianDiffusion:
         y = model_kwargs['y']
         if editing_util.uses_imputation(y) or editing_util.uses_reconstruction_guidance(y):
             raise NotImplementedError("cond_fn together with imputation / reconstruction guidance is not supported")
+        if 'cond_until_second_stage' in y:
+            # the reference switches cond_until AND the inpainting targets of its GMD post-imputation here (:771-781)
+            raise NotImplementedError("cond_until_second_stage (two-stage GMD guidance) is reference-only")
         if 'inpainting_mask' in y and 'inpainted_motion' in y:
             # the reference would run the GMD post-sampling imputation here (:800-1105), which needs data_transform_fn
             raise NotImplementedError("GMD post-sampling imputation (inpainting_mask with cond_fn) is reference-only")
@@ -396,8 +408,8 @@ class GaussianDiffusion:
                 model_output = model_output[0]
             pred_xstart = model_output                                   # START_X, clip_denoised is a no-op (:489-492)
             mean = f32(self.posterior_mean_coef1) * pred_xstart + f32(self.posterior_mean_coef2) * x
-            variance = f32(np.exp(self._model_log_variance()))
-            log_variance = f32(self._model_log_variance())
+            variance = f32(self._model_variance())          # the TABLE (reference :466-480), not exp(log table): FIXED_SMALL's
+            log_variance = f32(self._model_log_variance())  # variance is 0 at i = 0 while its clipped log is that of i = 1
             p_mean_var = {"mean": mean, "variance": variance.expand_as(x), "log_variance": log_variance.expand_as(x),
                           "pred_xstart": pred_xstart, "model_output": model_output}
             if sampler == "ddpm":
@@ -533,24 +545,27 @@ class GaussianDiffusion:
             "ddim", model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device,
             progress, eta, skip_timesteps, init_image, randomize_class, fast=False)
 
-    def _loop(self, sampler, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs,
-              device, progress, eta, skip_timesteps, init_image, randomize_class, dump_steps,
-              cond_fn_with_grad=False):
-        # The default precision (f16x3) is range-limited; if an activation leaves the f16 range the chain is re-run —
-        # same torch RNG state, hence same engine seed and noise — on a bf16x6 engine (exact operands, fp32 range).
+    @staticmethod
+    def _with_range_fallback(model, run):
+        """The default precision (f16x3) is range-limited; if an activation leaves the f16 range, `run` is repeated — same
+        torch RNG state, hence same engine seed and noise — on a bf16x6 engine (exact operands, fp32 range).  Used by the
+        sampling loops AND by the single-step entry points (p_sample, ddim_sample, *_with_grad)."""
         mdm, _ = _unwrap_model(model)
         rng_state = torch.random.get_rng_state()
         try:
-            return self._loop_once(sampler, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs,
-                                   device, progress, eta, skip_timesteps, init_image, randomize_class, dump_steps,
-                                   cond_fn_with_grad)
+            return run()
         except N.RangeError:
             if mdm is None or not hasattr(mdm, "range_fallback") or not mdm.range_fallback():
                 raise
             torch.random.set_rng_state(rng_state)
-            return self._loop_once(sampler, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs,
-                                   device, progress, eta, skip_timesteps, init_image, randomize_class, dump_steps,
-                                   cond_fn_with_grad)
+            return run()
+
+    def _loop(self, sampler, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs,
+              device, progress, eta, skip_timesteps, init_image, randomize_class, dump_steps,
+              cond_fn_with_grad=False):
+        return self._with_range_fallback(model, lambda: self._loop_once(
+            sampler, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device, progress, eta,
+            skip_timesteps, init_image, randomize_class, dump_steps, cond_fn_with_grad))
 
     def _loop_once(self, sampler, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs,
                    device, progress, eta, skip_timesteps, init_image, randomize_class, dump_steps,
@@ -571,22 +586,24 @@ class GaussianDiffusion:
     def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None,
                  model_kwargs=None, const_noise=False, previous_xstart=None):
         """One ancestral step (reference :656-713) on a fresh copy of x."""
-        return self._single_step("ddpm", model, x, t, cond_fn, model_kwargs, const_noise, 0.0, clip_denoised)
+        return self._with_range_fallback(model, lambda: self._single_step(
+            "ddpm", model, x, t, cond_fn, model_kwargs, const_noise, 0.0, clip_denoised))
 
     def ddim_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None,
                     model_kwargs=None, eta=0.0, previous_xstart=None):
         """One DDIM step (reference :1300-1356)."""
-        return self._single_step("ddim", model, x, t, cond_fn, model_kwargs, False, eta, clip_denoised)
+        return self._with_range_fallback(model, lambda: self._single_step(
+            "ddim", model, x, t, cond_fn, model_kwargs, False, eta, clip_denoised))
 
     def p_sample_with_grad(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None,
                            model_kwargs=None, const_noise=False, previous_xstart=None):
         """Reference :715-800 (cond_fn(x, t, p_mean_var, **model_kwargs) -> gradient, added as variance * gradient)."""
-        return self._single_guided("ddpm", model, x, t, cond_fn, model_kwargs, 0.0)
+        return self._with_range_fallback(model, lambda: self._single_guided("ddpm", model, x, t, cond_fn, model_kwargs, 0.0))
 
     def ddim_sample_with_grad(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None,
                               model_kwargs=None, eta=0.0, previous_xstart=None):
         """Reference :1358-1416 (condition_score_with_grad)."""
-        return self._single_guided("ddim", model, x, t, cond_fn, model_kwargs, eta)
+        return self._with_range_fallback(model, lambda: self._single_guided("ddim", model, x, t, cond_fn, model_kwargs, eta))
 
     def _single_guided(self, sampler, model, x, t, cond_fn, model_kwargs, eta):
         i = int(t.reshape(-1)[0].item())
@@ -600,7 +617,13 @@ class GaussianDiffusion:
             eng = self._engine_for(None, x.device, x.shape[0], x.shape[1] * x.shape[2], x.shape[-1], False)
             nz = eng.randn(x.shape, seed=_fresh_seed(), step=i,
                            first_sample=int(model_kwargs['y'].get('first_sample', self.first_sample)))
-        return self._guided_step(sampler, model, x.detach().float(), i, cond_fn, model_kwargs, eta, nz)
+        mdm, _ = _unwrap_model(model)
+        if mdm is not None and mdm._engine is not None:
+            mdm._engine.clear_range()
+        out = self._guided_step(sampler, model, x.detach().float(), i, cond_fn, model_kwargs, eta, nz)
+        if mdm is not None and mdm._engine is not None:
+            mdm._engine.check_range()     # (the step synchronised already: t.item() above)
+        return out
 
     def _single_step(self, sampler, model, x, t, cond_fn, model_kwargs, const_noise, eta, clip_denoised=False):
         assert cond_fn is None, "only support the case where cond_fn is None"
@@ -617,6 +640,7 @@ class GaussianDiffusion:
         cond = self._condition_from_kwargs(y, mdm, cfg, B, J * F, T, x.device)
         _add_observations(cond, mdm, model_kwargs, B, J * F, T)
         eng.set_condition(**cond)
+        eng.clear_range()
         first = int(y.get('first_sample', self.first_sample))
         out = x.detach().float().contiguous().clone()
         pred = torch.empty_like(out)
@@ -627,6 +651,8 @@ class GaussianDiffusion:
             eng.step(out, i, sampler=sid, eta=eta, noise=nz, pred_xstart=pred, seed=_fresh_seed(), first_sample=first)
         else:
             self._generic_step(eng, model, out, i, sid, eta, nz, pred, _fresh_seed(), model_kwargs, first)
+        if mdm is not None:
+            eng.check_range()      # one 4-byte read-back; a public single step must not hand back clamped / overflowed values
         return {"sample": out, "pred_xstart": pred}
 
 

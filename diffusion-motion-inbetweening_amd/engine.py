@@ -102,9 +102,16 @@ class Engine:
             raise IndexError("a timestep outside the time-embedding table reached the denoiser "
                              "(the reference raises at pe[timesteps], model/mdm.py:352)")
         if flag.value & 1 and self.precision == "f16x3":
-            raise N.RangeError(
-                "an activation left the f16 range (|x| >= 65504 or non-finite) in the split-f16 GEMM "
-                "path: results are invalid; re-run with precision='bf16x6' (CMDI_PRECISION=bf16x6)")
+            what = "an activation left the f16 range (|x| >= 65504 or non-finite) in the split-f16 GEMM path: results are invalid; "
+            if self.arch == "unet":
+                raise N.RangeError(what + "the MDM_UNET engine is built for f16x3 only (no bf16x6 / f32 mode to fall back to): "
+                                          "check the checkpoint and the normalisation of the inputs")
+            raise N.RangeError(what + "re-run with precision='bf16x6' (CMDI_PRECISION=bf16x6)")
+
+    def clear_range(self):
+        """Drop a pending status flag without reading it (start of a sampling chain: report this chain's events only)."""
+        with torch.cuda.device(self.device):
+            N.check(self.lib.cmdi_range_clear(self._h, self.stream))
 
     def set_graph(self, on: bool):
         """hipGraph replay of whole denoising steps in sample_loop (bitwise identical results)."""

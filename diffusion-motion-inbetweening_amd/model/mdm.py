@@ -264,6 +264,15 @@ class MDM(nn.Module):
             self._engine.close()
         self._engine, self._engine_key = None, None
 
+    def check_range(self):
+        """forward() launches asynchronously and never reads the device status flag.  Call this after one or more forward calls
+        to learn whether any of them left the f16 range of the default precision (RangeError: results invalid — re-run after
+        ``range_fallback()`` or with ``native_precision = 'bf16x6'``) or fed an out-of-range device timestep (IndexError, as the
+        reference's pe[timesteps] raises).  One 4-byte read-back: synchronises the stream.  The sampling loops and the
+        single-step samplers of GaussianDiffusion do this themselves."""
+        if self._engine is not None:
+            self._engine.check_range()
+
     def range_fallback(self) -> bool:
         """After a RangeError of the default (f16x3) engine: switch this module to bf16x6 for good and report whether a
         retry makes sense (False if the caller pinned a precision or the fallback is already active)."""

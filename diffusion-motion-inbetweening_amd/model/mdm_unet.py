@@ -178,6 +178,7 @@ class MDM_UNET(nn.Module):
     text_embedding = MDM.text_embedding
     _weights_key = MDM._weights_key
     invalidate_engine = MDM.invalidate_engine
+    check_range = MDM.check_range
 
     def engine(self, device, max_batch, max_frames, want_grad=False, n_time_rows=1000):
         """The native engine holding this module's weights on `device` (built / grown lazily)."""

@@ -252,15 +252,20 @@ int cmdi_clip_encode_text(cmdi_clip_handle h, const int32_t* d_tokens, int32_t b
 int cmdi_gemm_nt(const float* d_a, const float* d_w, const float* d_bias, const float* d_resid,
                  float* d_c, int32_t m, int32_t n, int32_t k, int32_t epi, int32_t tile,
                  cmdi_stream stream);
-/* The precision the handle runs at (CMDI_PREC_F32 or CMDI_PREC_F16X3). */
+/* The precision the handle runs at (CMDI_PREC_F32, CMDI_PREC_F16X3 or CMDI_PREC_BF16X6; a CMDI_ARCH_UNET handle is always
+ * CMDI_PREC_F16X3 — creating one with another precision fails). */
 int cmdi_precision(cmdi_handle h);
 /* Status bits raised on the device since the last call (cleared by it):
  *   bit 0 (F16X3 only): an activation left the f16 range (|x| >= 65504 or non-finite) while being split; the results
- *         of that run are invalid and the caller should re-run on an engine created with CMDI_PREC_F32;
+ *         of that run are invalid and the caller should re-run on an engine created with CMDI_PREC_BF16X6 (exact operands,
+ *         fp32's exponent range; or CMDI_PREC_F32).  CMDI_ARCH_UNET has no such mode: there the inputs must be rescaled;
  *   bit 1: a timestep outside [0, n_time_rows) reached the time-embedding lookup (the reference raises IndexError
  *         at pe[timesteps], model/mdm.py:352); the row was clamped.
  * SYNCHRONISES `stream` (one 4-byte read-back); call it once per sampling chain, not per step. */
 int cmdi_range_status(cmdi_handle h, int32_t* out_flag, cmdi_stream stream);
+/* Forget whatever the status flag holds (events of earlier, unrelated calls), ordered on `stream`, without a read-back:
+ * the sampling loops call it before their first step so that a chain reports its own events only. */
+int cmdi_range_clear(cmdi_handle h, cmdi_stream stream);
 /* Split-f16 GEMM family alone (test / bench hooks).  cmdi_split_f16: fp32 [rows, cols] -> split rows
  * [rows, 2*cols] f16; per 32-column chunk: 32 hi values f16(x), then 32 lo values
  * f16((x - hi) * 2^11); cols % 32 == 0.

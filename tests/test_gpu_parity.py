@@ -811,6 +811,49 @@ def test_out_of_range_timestep_is_reported():
         model._engine.check_range()
     with pytest.raises(IndexError):
         model(x, torch.tensor([5, 5000]), y={})      # host tensor: checked before the launch
+    model(x, torch.tensor([5, 5000], device=DEV), y={})
+    with pytest.raises(IndexError):
+        model.check_range()                          # the public form of the same check
+
+
+def test_status_flag_is_per_call(cases):
+    """(1) a stale flag left by an unchecked forward call must not fire at the end of the next, unrelated chain —
+    the loops clear it before their first step; (2) the public single-step samplers check it themselves (a 10-step schedule
+    keeps timesteps in range, so the stale flag is the only event: p_sample / ddim_sample must NOT raise)."""
+    case = cases.CASES["chain_uncond_ddpm"]
+    inp = cases.make_inputs(case)
+    model, _ = make_model(case, layers=1)
+    diffusion = make_diffusion(case["respacing"])
+    x = tt(inp["x_T"])
+    y = {"mask": tt(inp["len_mask"]), "lengths": tt(inp["lengths"])}
+    model(x, torch.tensor([5, 5000], device=DEV), y={})          # raises the timestep bit, nobody checks
+    out = diffusion.p_sample_loop(model, x.shape, noise=x, clip_denoised=False, model_kwargs={"y": y})
+    assert torch.isfinite(out).all()
+    model(x, torch.tensor([5, 5000], device=DEV), y={})
+    step = diffusion.p_sample(model, x, torch.full((2,), 3, device=DEV), clip_denoised=False, model_kwargs={"y": y})
+    assert torch.isfinite(step["sample"]).all()
+    model(x, torch.tensor([5, 5000], device=DEV), y={})
+    step = diffusion.ddim_sample(model, x, torch.full((2,), 3, device=DEV), clip_denoised=False, model_kwargs={"y": y})
+    assert torch.isfinite(step["sample"]).all()
+    model._engine.check_range()                                   # nothing pending after the checked calls
+
+
+def test_single_step_range_fallback(cases):
+    """p_sample on a model whose activations leave the f16 range falls back to bf16x6 like the loops do (instead of
+    returning overflowed values); with a pinned f16x3 precision it raises."""
+    N_ = sub("_native")
+    case = cases.CASES["chain_uncond_ddpm"]
+    inp = cases.make_inputs(case)
+    diffusion = make_diffusion(case["respacing"])
+    y = {"mask": tt(inp["len_mask"]), "lengths": tt(inp["lengths"])}
+    x = tt(inp["x_T"]) * 3.0e4            # token values of 1e5 .. 1e6 after the input projection: beyond f16
+    t3 = torch.full((2,), 3, device=DEV)
+    model, _ = make_model(case, layers=1, precision="f16x3")
+    with pytest.raises(N_.RangeError):
+        diffusion.p_sample(model, x, t3, clip_denoised=False, model_kwargs={"y": y})
+    model, _ = make_model(case, layers=1)            # default precision: automatic fallback
+    out = diffusion.p_sample(model, x, t3, clip_denoised=False, model_kwargs={"y": y})
+    assert model._engine.precision == "bf16x6" and torch.isfinite(out["sample"]).all()
 
 
 # ---- cond_fn guidance (SURVEY 8f rank 4: p_sample_with_grad / ddim_sample_with_grad) -------------------------------

@@ -272,3 +272,35 @@ def test_bench_work_counts_match_the_scope_table():
     conv5 = 2.0 * 224 * 5 * 1024 * 1024                          # one level-0 k=5 convolution: 2.35 GF
     assert 34.3e9 < u < 34.5e9 and 14 < u / conv5 < 15            # 34.37 GF = 14.6 level-0 convolutions' worth
     assert set(b.CONFIGS) >= {"c2", "c3", "c4", "unet", "unet_recon"} and b.CONFIGS["c2"]["B"] == 32
+
+
+def test_bench_rank_arithmetic_for_2_4_8_gpus():
+    """VERDICT r2 task 10: bench.py's shard bounds and whole-job rates for N in {1, 2, 4, 8} (no scaling curve can be measured
+    in the build container; the arithmetic the driver's SCALE run depends on is checked here)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_bench_for_test", REPO / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    du = sub("utils.dist_util")
+    t_step = 2.0e-3                        # every rank needs 2 ms per step of its own shard (weak) ...
+    for N in (1, 2, 4, 8):
+        # weak scaling (c2): per-rank batch fixed, job batch grows, steps/s = N / step time
+        lay = [bench.job_layout(bench.CONFIGS["c2"], N, r, du.shard_bounds) for r in range(N)]
+        assert all(l["batch"] == 32 and not l["strong"] and l["global_batch"] == 32 * N for l in lay)
+        assert [l["lo"] for l in lay] == [32 * r for r in range(N)] and lay[-1]["hi"] == 32 * N
+        r = bench.job_rates(lay[0], N, K=20, elapsed_s=20 * t_step, n_chain=1000)
+        assert abs(r["steps_per_s"] - N / t_step) < 1e-6 and abs(r["ms_per_step"] - 2.0) < 1e-9
+        assert abs(r["motions_per_sec"] - 32 * N / (1000 * t_step)) < 1e-9
+        # strong scaling (c5): ONE batch of 1024 in contiguous shards that tile it exactly; steps/s = 1 / step time
+        lay = [bench.job_layout(bench.CONFIGS["c5"], N, r, du.shard_bounds) for r in range(N)]
+        assert all(l["strong"] and l["global_batch"] == 1024 for l in lay)
+        assert lay[0]["lo"] == 0 and lay[-1]["hi"] == 1024
+        assert all(a["hi"] == b["lo"] for a, b in zip(lay, lay[1:])) and sum(l["batch"] for l in lay) == 1024
+        assert max(l["batch"] for l in lay) - min(l["batch"] for l in lay) <= 1
+        t_strong = t_step * 32 / N         # ... and a shard of 1024 / N samples takes 1024 / N / 32 of that (linear in B)
+        r = bench.job_rates(lay[0], N, K=20, elapsed_s=20 * t_strong, n_chain=1000)
+        assert abs(r["steps_per_s"] - 1 / t_strong) < 1e-6
+        assert abs(r["motions_per_sec"] - 1024 / (1000 * t_strong)) < 1e-6
+    # a batch that does not divide: shards differ by at most one sample and still tile the batch
+    b = [du.shard_bounds(1001, r, 8) for r in range(8)]
+    assert b[0][0] == 0 and b[-1][1] == 1001 and all(x[1] == y[0] for x, y in zip(b, b[1:]))
