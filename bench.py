@@ -276,6 +276,16 @@ def pmc_counters(config: str, precision: str, batch: int, timeout_s: float = 150
                             if int(r_["Dispatch_Id"]) in dominant and r_["Kernel_Name"] == first["Kernel_Name"]}
                 res["pmc_kernel"], res["pmc_grid"] = first["Kernel_Name"][:160], int(first["Grid_Size"])
                 res["pmc_launches"] = len(dominant)
+            if i == 0 and rows and "Start_Timestamp" in rows[0] and "End_Timestamp" in rows[0]:
+                # wall time of the same launches IN THIS counter pass (ns): effective clock = GRBM_GUI_ACTIVE / 8 / that
+                seen, dur = set(), []
+                for r_ in rows:
+                    d = int(r_["Dispatch_Id"])
+                    if d in dominant and d not in seen:
+                        seen.add(d)
+                        dur.append(float(r_["End_Timestamp"]) - float(r_["Start_Timestamp"]))
+                if dur and min(dur) > 0:
+                    res["pmc_pass_kernel_ns"] = sum(dur) / len(dur)
             for c in ctrs:
                 vals = [float(r_["Counter_Value"]) for r_ in rows if int(r_["Dispatch_Id"]) in dominant and r_["Counter_Name"] == c]
                 if len(vals) != len(dominant):
@@ -307,10 +317,14 @@ def roofline_from(eng, run_loop, split, is_unet, pmc):
     if "SQ_VALU_MFMA_BUSY_CYCLES" in pmc and "GRBM_GUI_ACTIVE" in pmc and pmc["GRBM_GUI_ACTIVE"] > 0:
         cyc = pmc["GRBM_GUI_ACTIVE"] / N_XCD              # the counter is summed over the 8 XCDs
         mfma_busy = pmc["SQ_VALU_MFMA_BUSY_CYCLES"] / (N_SIMD * cyc)
+        if pmc.get("pmc_pass_kernel_ns"):
+            # shader clock the kernel actually ran at (in the counter pass): busy cycles / wall time.  The power cap holds it
+            # well below the 2.4 GHz the peaks are quoted at (MI355X_MICROARCH.md "DVFS give-back")
+            clock = cyc / pmc["pmc_pass_kernel_ns"]
     rl = {"bound": "mfma", "achieved": ach, "unit": "TFLOP/s", "traffic": traffic, "launches": launches,
           "avg_launch_us": avg_s * 1e6, "flops_per_launch": flop_launch,
           "algorithmic_bytes": 4.0 * (m * k + n * k + m * n),
-          "mfma_busy": mfma_busy, "hbm_gbps": (traffic / avg_s / 1e9) if traffic else None,
+          "mfma_busy": mfma_busy, "effective_clock_ghz": clock, "hbm_gbps": (traffic / avg_s / 1e9) if traffic else None,
           "pmc": {k_: v for k_, v in pmc.items() if k_.startswith("pmc_") or k_ in ("FETCH_SIZE", "WRITE_SIZE",
                   "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE")}}
     if split:
@@ -333,6 +347,33 @@ def roofline_from(eng, run_loop, split, is_unet, pmc):
         rl.update(kernel=f"gemm_nt_kernel (self_attn.in_proj, M={m} N={n} K={k}, fp32 MFMA 32x32x2)",
                   peak=FP32_MFMA_PEAK_TFLOPS, frac=ach / FP32_MFMA_PEAK_TFLOPS)
     return rl
+
+
+def roofline_attention(eng, run_loop):
+    """The next kernel on the list: the self-attention core, timed like the in_proj GEMM — HIP events around every
+    launch in an instrumented pass over the same K steps.  Algorithmic work 4 S^2 d per sequence and layer (QK^T and PV)."""
+    eng.profile_select(1)
+    eng.profile_enable(True)
+    run_loop()
+    torch.cuda.synchronize()
+    ms, launches, (nseq, S, H) = eng.profile_read()
+    eng.profile_enable(False)
+    eng.profile_select(0)
+    if launches == 0:
+        return None
+    avg_s = ms / launches * 1e-3
+    d_head = 128
+    flop = 4.0 * nseq * H * S * S * d_head
+    ach = flop / avg_s / 1e12
+    split = eng.precision == "f16x3"
+    peak = F16_MFMA_PEAK_TFLOPS / 3.0 if split else FP32_MFMA_PEAK_TFLOPS
+    return {"kernel": ("attention_h3_kernel (softmax(QK^T / sqrt(128)) V on split-f16 products: 3 MFMAs per fp32-equivalent "
+                       "product)" if split else "attention_fwd_kernel (fp32 MFMA 16x16x4)") + f", {nseq} sequences x {H} heads x {S} tokens",
+            "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "launches": launches,
+            "avg_launch_us": avg_s * 1e6, "flops_per_launch": flop,
+            "algorithmic_bytes": 4.0 * nseq * S * 4 * H * d_head,       # q, k, v in + o out, 4 bytes per value
+            "note": "per key stage a wave pays MFMA issue + LDS fragment reads + softmax VALU nearly in series (DESIGN.md 3): "
+                    "the kernel is bound by its own instruction stream, not by the pipe's peak and not by HBM"}
 
 
 def job_layout(cfg: dict, world: int, rank: int, shard_bounds) -> dict:
@@ -505,14 +546,14 @@ def main():
         "pipeline_parts": eng.pipeline_parts(),
     }
 
-    want_pmc = rank == 0 and world == 1 and not args.no_pmc and not args.no_roofline and not is_unet
+    want_pmc = rank == 0 and world == 1 and not args.no_pmc and not args.no_roofline
     if rank == 0 and not args.no_roofline:
-        pmc = pmc_counters(args.config, eng.precision, B) if want_pmc else {}
+        # (U-Net: the dominant launches are the level-0 k=5 convolution GEMMs — the largest MFMA count of the step — found by
+        # the same rule as the transformer's in_proj; counters measured IN this run since round 3)
+        pmc = pmc_counters(args.config, eng.precision, B, timeout_s=240.0 if is_unet else 150.0) if want_pmc else {}
         out["roofline"] = roofline_from(eng, loop, split, is_unet, pmc)
-        if is_unet:   # PMC passes of the level-0 convolution GEMM were taken by tools/conv_pmc.py (round 1)
-            pmc_u = REPO / "profiles" / "pmc_unet_conv_gemm.json"
-            out["roofline"]["traffic"] = json.loads(pmc_u.read_text()).get("hbm_bytes_per_launch") if pmc_u.exists() else None
-            out["roofline"]["traffic_source"] = "profiles/pmc_unet_conv_gemm.json (round 1, not re-measured in this run)"
+        if not is_unet:
+            out["roofline_attention"] = roofline_attention(eng, loop)
     if use_dist:
         dist.barrier()
 

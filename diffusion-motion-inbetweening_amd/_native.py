@@ -109,6 +109,7 @@ SIGNATURES = {
     "cmdi_workspace_bytes": (_I64, [_VP]),
     "cmdi_pipeline_parts": (C.c_int, [_VP]),
     "cmdi_profile_enable": (C.c_int, [_VP, _I32]),
+    "cmdi_profile_select": (C.c_int, [_VP, _I32]),
     "cmdi_profile_read": (C.c_int, [_VP, C.POINTER(C.c_double), C.POINTER(_I64), C.POINTER(_I32),
                                     C.POINTER(_I32), C.POINTER(_I32)]),
 }

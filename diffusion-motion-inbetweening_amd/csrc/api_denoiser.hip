@@ -29,6 +29,28 @@ int run_layers(cmdi_engine* e, int seq0, int nseq, bool keep, bool prof, hipStre
         p.M = M; p.N = N; p.K = K; p.ldc = N;
         return p;
     };
+    // live timing (cmdi_profile_enable): HIP events around ONE kernel kind per pass — the in_proj GEMM (prof_which 0) or the
+    // attention kernel (1)
+    auto prof_begin = [&](int which) -> int {
+        if (!prof || e->prof_which != which) return CMDI_OK;
+        if (e->ev_used + 2 > e->ev_pool.size()) {
+            hipEvent_t a, b;
+            HIPCHK(hipEventCreate(&a));
+            HIPCHK(hipEventCreate(&b));
+            e->ev_pool.push_back(a);
+            e->ev_pool.push_back(b);
+        }
+        HIPCHK(hipEventRecord(e->ev_pool[e->ev_used], s));
+        return CMDI_OK;
+    };
+    auto prof_end = [&](int which) -> int {
+        if (!prof || e->prof_which != which) return CMDI_OK;
+        HIPCHK(hipEventRecord(e->ev_pool[e->ev_used + 1], s));
+        e->ev_used += 2;
+        if (which == 0) { e->prof_m = M; e->prof_n = 3 * d; e->prof_k = d; }
+        else { e->prof_m = nseq; e->prof_n = S; e->prof_k = e->H; }      // (sequences, tokens, heads)
+        return CMDI_OK;
+    };
     if (h3 && !e->io_h3)  // layer 0 reads the tokens assembled by token0 + the input projection (fp32)
         HIPCHK(launch_split_f16(tokA, tokS, M, d, d, e->range_flag, s));
     if (h3 && e->ln_fold && !keep && e->io_h3) {
@@ -38,29 +60,18 @@ int run_layers(cmdi_engine* e, int seq0, int nseq, bool keep, bool prof, hipStre
         for (int l = 0; l < e->L; ++l) {
             const LayerW& w = e->layers[l];
             const LayerW* prev = l > 0 ? &e->layers[l - 1] : nullptr;
-            if (prof) {
-                if (e->ev_used + 2 > e->ev_pool.size()) {
-                    hipEvent_t a, b;
-                    HIPCHK(hipEventCreate(&a));
-                    HIPCHK(hipEventCreate(&b));
-                    e->ev_pool.push_back(a);
-                    e->ev_pool.push_back(b);
-                }
-                HIPCHK(hipEventRecord(e->ev_pool[e->ev_used], s));
-            }
+            { int prc = prof_begin(0); if (prc != CMDI_OK) return prc; }
             {   // qkv = in_proj(LN2_prev(P))
                 H3Params p = hp(tokS, prev ? w.in_wsf : w.in_ws, prev ? w.in_c2 : w.in_b, nullptr, qkvS, 3 * d, d);
                 if (prev) { p.ln_part = partB; p.ln_c1 = w.in_c1; }
                 p.cs_head_major = e->qkv_head_major;
                 HIPCHK(launch_gemm_h3(H3_PLAIN_SPLIT, p, e->h3_tile_qkv, s));
             }
-            if (prof) {
-                HIPCHK(hipEventRecord(e->ev_pool[e->ev_used + 1], s));
-                e->ev_used += 2;
-                e->prof_m = M; e->prof_n = 3 * d; e->prof_k = d;
-            }
+            { int prc = prof_end(0); if (prc != CMDI_OK) return prc; }
+            { int prc = prof_begin(1); if (prc != CMDI_OK) return prc; }
             HIPCHK(launch_attention_h3(qkvS, nullptr, attnS, e->range_flag, nullptr, nseq, S, e->H, s,
                                        e->qkv_head_major != 0));
+            { int prc = prof_end(1); if (prc != CMDI_OK) return prc; }
             {   // pre1 = LN2_prev(P) + out_proj(attn)   -> bufHS (+ partial statistics A)
                 H3Params p = hp(attnS, w.out_ws, w.out_b, nullptr, bufHS, d, d);
                 p.Rs = tokS;
@@ -96,27 +107,16 @@ int run_layers(cmdi_engine* e, int seq0, int nseq, bool keep, bool prof, hipStre
         if (h3) {
             // same layer on the f16 matrix pipe; every A operand arrives as split rows written by
             // its producer (LayerNorm, attention, the GELU epilogue)
-            if (prof) {
-                if (e->ev_used + 2 > e->ev_pool.size()) {
-                    hipEvent_t a, b;
-                    HIPCHK(hipEventCreate(&a));
-                    HIPCHK(hipEventCreate(&b));
-                    e->ev_pool.push_back(a);
-                    e->ev_pool.push_back(b);
-                }
-                HIPCHK(hipEventRecord(e->ev_pool[e->ev_used], s));
-            }
+            { int prc = prof_begin(0); if (prc != CMDI_OK) return prc; }
             // qkv leaves as split rows for the f16-pipe attention (stashed per layer for the backward)
             _Float16* qkvL = keep ? st->qkvS + r0 * 6 * d : qkvS;
             HIPCHK(launch_gemm_h3(H3_PLAIN_SPLIT, hp(tokS, w.in_ws, w.in_b, nullptr, qkvL, 3 * d, d),
                                   e->h3_tile_qkv, s));
-            if (prof) {
-                HIPCHK(hipEventRecord(e->ev_pool[e->ev_used + 1], s));
-                e->ev_used += 2;
-                e->prof_m = M; e->prof_n = 3 * d; e->prof_k = d;
-            }
+            { int prc = prof_end(0); if (prc != CMDI_OK) return prc; }
+            { int prc = prof_begin(1); if (prc != CMDI_OK) return prc; }
             HIPCHK(launch_attention_h3(qkvL, keep ? attn : nullptr, attnS, e->range_flag, row_stats,
                                        nseq, S, e->H, s));
+            { int prc = prof_end(1); if (prc != CMDI_OK) return prc; }
             if (e->ln_fuse) {   // x = norm1(x + out_proj(attn)) in one kernel
                 H3Params p = hp(attnS, w.out_ws, w.out_b, bufH, bufHS, d, d);
                 p.R = tokA; p.ln_g = w.n1_g; p.ln_b = w.n1_b;
@@ -155,24 +155,13 @@ int run_layers(cmdi_engine* e, int seq0, int nseq, bool keep, bool prof, hipStre
             continue;
         }
         // self-attention block: x = norm1(x + out_proj(MHA(x)))
-        if (prof) {
-            if (e->ev_used + 2 > e->ev_pool.size()) {
-                hipEvent_t a, b;
-                HIPCHK(hipEventCreate(&a));
-                HIPCHK(hipEventCreate(&b));
-                e->ev_pool.push_back(a);
-                e->ev_pool.push_back(b);
-            }
-            HIPCHK(hipEventRecord(e->ev_pool[e->ev_used], s));
-        }
+        { int prc = prof_begin(0); if (prc != CMDI_OK) return prc; }
         HIPCHK(gemm_any(e, GK_PLAIN, gp(tokA, w.in_w, w.in_b, qkv, M, 3 * d, d, d, d, 3 * d), w.in_wx,
                         e->tile_inproj, s));
-        if (prof) {
-            HIPCHK(hipEventRecord(e->ev_pool[e->ev_used + 1], s));
-            e->ev_used += 2;
-            e->prof_m = M; e->prof_n = 3 * d; e->prof_k = d;
-        }
+        { int prc = prof_end(0); if (prc != CMDI_OK) return prc; }
+        { int prc = prof_begin(1); if (prc != CMDI_OK) return prc; }
         HIPCHK(launch_attention_fwd(qkv, attn, nullptr, nullptr, row_stats, nseq, S, e->H, s));
+        { int prc = prof_end(1); if (prc != CMDI_OK) return prc; }
         {
             GemmParams p = gp(attn, w.out_w, w.out_b, pre1, M, d, d, d, d, d);
             p.R = tokA;

@@ -237,6 +237,13 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
     return CMDI_OK;
 }
 
+int cmdi_profile_select(cmdi_handle e, int32_t which) {
+    if (!e || which < 0 || which > 1) return fail(CMDI_E_INVALID, "cmdi_profile_select: 0 = in_proj GEMM, 1 = attention kernel");
+    e->prof_which = which;
+    e->ev_used = 0;
+    return CMDI_OK;
+}
+
 int cmdi_profile_enable(cmdi_handle e, int32_t on) {
     if (!e) return fail(CMDI_E_INVALID, "null handle");
     e->profile = on != 0;

@@ -120,6 +120,10 @@ class Engine:
     def profile_enable(self, on: bool):
         N.check(self.lib.cmdi_profile_enable(self._h, int(on)))
 
+    def profile_select(self, which: int):
+        """0 = time the in_proj GEMM launches (default), 1 = the attention kernel launches."""
+        N.check(self.lib.cmdi_profile_select(self._h, int(which)))
+
     def profile_read(self):
         """(total_ms, launches, (M, N, K)) of the in_proj GEMM launches recorded since enable."""
         ms, cnt = C.c_double(), C.c_int64()

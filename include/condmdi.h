@@ -311,6 +311,9 @@ void cmdi_philox4x32_10(const uint32_t counter[4], const uint32_t key[2], uint32
  * cmdi_profile_read waits for the recorded events and returns their summed duration and count,
  * then clears them.  Used by bench.py's roofline leg; off by default (no events, no overhead). */
 int cmdi_profile_enable(cmdi_handle h, int32_t on);
+/* Which kernel the events bracket: 0 = the in_proj GEMM (default; cmdi_profile_read's m, n, k = its shape), 1 = the
+ * self-attention kernel (m, n, k = sequences, tokens per sequence, heads).  One kind per instrumented pass. */
+int cmdi_profile_select(cmdi_handle h, int32_t which);
 int cmdi_profile_read(cmdi_handle h, double* total_ms, int64_t* launches, int32_t* m, int32_t* n,
                       int32_t* k);
 /* Number of independent batch pipelines cmdi_sample_loop cuts the CURRENT condition's batch into (1 = none; 2 from
