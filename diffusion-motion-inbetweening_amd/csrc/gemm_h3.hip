@@ -148,6 +148,11 @@ bool gemm_h3_persistent_for(int M) {
 
 hipError_t launch_gemm_h3(int epi, const H3Params& p, int tile, hipStream_t s) {
     if (p.K % 32 != 0 || (p.N % 8 != 0 && epi != H3_MOTION) || p.M <= 0 || p.N <= 0) return hipErrorInvalidValue;
+    {   // the LDS-DMA requests address both operands with 32-bit byte offsets from their base (buffer descriptors)
+        const size_t a_row = 2 * (p.a_ld ? (size_t)p.a_ld : 2 * (size_t)p.K) * (size_t)(p.a_row_mul ? p.a_row_mul : 1);
+        const size_t a_bytes = (size_t)p.M * a_row + (size_t)(p.taps > 0 ? p.taps : 1) * a_row;
+        if (a_bytes >= (1ull << 32) || (size_t)p.N * 4 * (size_t)p.K >= (1ull << 32)) return hipErrorInvalidValue;
+    }
     if (epi == H3_RESID_LN) {
         if (p.N != 512 || !p.R || !p.ln_g || !p.ln_b || !p.C) return hipErrorInvalidValue;
         return launch_h3_one<H64x512ln, H3_RESID_LN>(p, s);

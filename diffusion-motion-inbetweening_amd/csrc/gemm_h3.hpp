@@ -603,25 +603,33 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
     // swizzle sits on the SOURCE address: the 16-B slot c of tile row r is stored at slot position
     // c ^ ((r >> 1) & 7), so the 16 rows of a ds_read_b128 lane group cover all 16 slots of a 256-B
     // bank row.  Slots 0-3 of a row are the hi plane, 4-7 the lo plane.
+    // Requests are `buffer_load_dwordx4 ... offen lds` (round 3): operand base in a buffer descriptor, the lane's byte offset
+    // in ONE 32-bit register per piece that never changes, the K step (and the convolution tap) in the scalar offset — one M0
+    // write + one request per piece.  (Rounds 1-2 used flat global_load_lds with a 64-bit address per lane and piece: two
+    // 64-bit vector adds per request, and twice the address registers in a kernel capped at 128.)  The operands are required
+    // to span < 2 GiB (launch_gemm_h3 checks): offsets are 32-bit.
     const int prow = lane >> 3, pslot = lane & 7;
     const size_t ldk = 2 * (size_t)p.K;
     const size_t lda = p.a_ld ? (size_t)p.a_ld : ldk;
     const int a_rmul = p.a_row_mul ? p.a_row_mul : 1;
-    const _Float16* a_src[BM / 8 / NW];
-    const _Float16* w_src[BN / 8 / NW];
+    // (a convolution caller has moved p.A back by the padding rows; base + offset is the address the pointer arithmetic of the
+    // flat form produced)
+    const auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.A), 0, 0xffffffff, 0x00020000);
+    const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.W), 0, 0xffffffff, 0x00020000);
+    unsigned a_voff[BM / 8 / NW], w_voff[BN / 8 / NW];
 #pragma unroll
     for (int q = 0; q < BM / 8 / NW; ++q) {
         const int row = (q * NW + wave) * 8 + prow;
         int grow = m0 + row;
         grow = grow < M ? grow : M - 1;
-        a_src[q] = p.A + (size_t)grow * a_rmul * lda + ((pslot ^ ((row >> 1) & 7)) << 3);
+        a_voff[q] = (unsigned)(((size_t)grow * a_rmul * lda + ((pslot ^ ((row >> 1) & 7)) << 3)) * 2);
     }
 #pragma unroll
     for (int q = 0; q < BN / 8 / NW; ++q) {
         const int row = (q * NW + wave) * 8 + prow;
         int grow = n0 + row;
         grow = grow < p.N ? grow : p.N - 1;
-        w_src[q] = p.W + (size_t)grow * ldk + ((pslot ^ ((row >> 1) & 7)) << 3);
+        w_voff[q] = (unsigned)(((size_t)grow * ldk + ((pslot ^ ((row >> 1) & 7)) << 3)) * 2);
     }
     // plain GEMM: chunk kt of the row; convolution: tap kt / cpt = one row further, chunk kt % cpt.  (cpt = "never" for
     // the plain case keeps the address arithmetic branch-free: the requests then sit in the same scheduling region as
@@ -630,17 +638,15 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
     auto issue = [&](int kt, int buf) {
         char* stage = lds + buf * STAGE;
         const int tap = kt / cpt;
-        const size_t a_off = (size_t)tap * lda + (size_t)(kt - tap * cpt) * 64;
+        const int a_soff = (int)(((size_t)tap * lda + (size_t)(kt - tap * cpt) * 64) * 2);
 #pragma unroll
         for (int q = 0; q < BM / 8 / NW; ++q)
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(a_src[q] + a_off),
-                (__attribute__((address_space(3))) void*)(stage + (q * NW + wave) * 1024), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(stage + (q * NW + wave) * 1024),
+                                                     16, (int)a_voff[q], a_soff, 0, 0);
 #pragma unroll
         for (int q = 0; q < BN / 8 / NW; ++q)
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(w_src[q] + kt * 64),
-                (__attribute__((address_space(3))) void*)(stage + BM * 128 + (q * NW + wave) * 1024), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(stage + BM * 128 + (q * NW + wave) * 1024),
+                                                     16, (int)w_voff[q], kt * 128, 0, 0);
     };
 
     const int swz = (l31 >> 1) & 7;

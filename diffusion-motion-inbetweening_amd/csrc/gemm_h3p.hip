@@ -8,6 +8,7 @@ bool gemm_h3p_supports(int epi, const H3Params& p) {
     if (epi != H3_PLAIN && epi != H3_PLAIN_SPLIT && epi != H3_GELU_SPLIT && epi != H3_GELUGRAD_SPLIT && epi != H3_RESID) return false;
     if (p.cpt || p.a_ld || p.a_row_mul || p.c_row_mul || p.tp || p.ksplit > 1 || p.cs_head_major || p.m_fast) return false;
     if (p.M <= 0 || p.N % H3PTile::BN != 0 || p.K % 32 != 0 || p.K < 64) return false;
+    if ((size_t)p.M * 4 * (size_t)p.K >= (1ull << 31) || (size_t)p.N * 4 * (size_t)p.K >= (1ull << 31)) return false;   // 32-bit request offsets
     if (epi == H3_RESID && p.ln_c1) return false;        // (a folded-LayerNorm A operand together with a residual: not used, not built)
     return true;
 }
