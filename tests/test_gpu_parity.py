@@ -838,6 +838,29 @@ def test_status_flag_is_per_call(cases):
     model._engine.check_range()                                   # nothing pending after the checked calls
 
 
+def test_range_probe_switches_before_a_long_chain(cases, monkeypatch):
+    """VERDICT r2 task 7: weights whose activations leave the f16 range are detected by the two-evaluation probe at the START
+    of a long chain — the chain itself then runs once, on bf16x6 — instead of at the end of 100 wasted f16x3 steps."""
+    gd = sub("diffusion.gaussian_diffusion")
+    case = dict(text=False, weight_seed=6)
+    model, sd = make_model(case, layers=2)
+    key = "seqTransEncoder.layers.0.linear1.weight"      # FFN pre-activations of ~1e5: beyond f16 (the scale of
+    sd = dict(sd)                                         # test_real_scale_activations_and_range_fallback's second case)
+    sd[key] = sd[key] * np.float32(4.0e4)
+    sub("utils.model_util").load_model_wo_clip(model, weights.to_torch(sd))
+    model.to(DEV).eval()
+    diffusion = make_diffusion("ddim100")
+    x = torch.randn(2, 263, 1, 40, device=DEV)
+    y = {"mask": torch.ones(2, 1, 1, 40, dtype=torch.bool, device=DEV), "lengths": torch.full((2,), 40, device=DEV)}
+    calls = []
+    real = sub("engine").Engine.sample_loop
+    monkeypatch.setattr(sub("engine").Engine, "sample_loop",
+                        lambda self, *a, **k: (calls.append(self.precision), real(self, *a, **k))[1])
+    out = diffusion.p_sample_loop(model, x.shape, noise=x, clip_denoised=False, model_kwargs={"y": y})
+    assert calls == ["bf16x6"], calls                  # the f16x3 engine never ran the chain
+    assert model._engine.precision == "bf16x6" and torch.isfinite(out).all()
+
+
 def test_single_step_range_fallback(cases):
     """p_sample on a model whose activations leave the f16 range falls back to bf16x6 like the loops do (instead of
     returning overflowed values); with a pinned f16x3 precision it raises."""
