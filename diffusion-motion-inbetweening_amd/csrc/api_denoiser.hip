@@ -53,27 +53,36 @@ int run_layers(cmdi_engine* e, int seq0, int nseq, bool keep, bool prof, hipStre
     };
     if (h3 && !e->io_h3)  // layer 0 reads the tokens assembled by token0 + the input projection (fp32)
         HIPCHK(launch_split_f16(tokA, tokS, M, d, d, e->range_flag, s));
-    if (h3 && e->ln_fold && !keep && e->io_h3) {
+    if (h3 && e->ln_fold && e->io_h3 && (!keep || e->ln_fold_keep)) {
         // ---- no LayerNorm pass: P (tokS) is the layer input BEFORE its LayerNorm (layer 0: the tokens themselves) ----
         float* partA = e->partA + r0 * 32;
         float* partB = e->partB + r0 * 32;
         for (int l = 0; l < e->L; ++l) {
             const LayerW& w = e->layers[l];
             const LayerW* prev = l > 0 ? &e->layers[l - 1] : nullptr;
+            // keep (round 3): the folded schedule also serves the forward pass that stashes activations for the input-VJP
+            // (reconstruction guidance, torch.autograd through the module): the GEMM epilogues write what the backward reads —
+            // split qkv per layer, the fp32 pre-LayerNorm sums, the FFN pre-activation — and the GEMM that CONSUMES a
+            // LayerNorm's partial statistics writes its (mean, rstd) out (p.ln_stats).  16 LayerNorm launches per evaluation
+            // less than the schedule below, which it replaces unless CMDI_LN_FOLD_KEEP=0.
+            const LayerStash* st = keep ? &e->stash[l] : nullptr;
+            _Float16* qkvL = keep ? st->qkvS + r0 * 6 * d : qkvS;
+            const bool head_major = e->qkv_head_major != 0 && !keep;   // (the attention backward reads token-major rows)
             { int prc = prof_begin(0); if (prc != CMDI_OK) return prc; }
             {   // qkv = in_proj(LN2_prev(P))
-                H3Params p = hp(tokS, prev ? w.in_wsf : w.in_ws, prev ? w.in_c2 : w.in_b, nullptr, qkvS, 3 * d, d);
+                H3Params p = hp(tokS, prev ? w.in_wsf : w.in_ws, prev ? w.in_c2 : w.in_b, nullptr, qkvL, 3 * d, d);
                 if (prev) { p.ln_part = partB; p.ln_c1 = w.in_c1; }
-                p.cs_head_major = e->qkv_head_major;
+                if (prev && keep) p.ln_stats = e->stash[l - 1].stats2 + r0 * 2;
+                p.cs_head_major = head_major;
                 HIPCHK(launch_gemm_h3(H3_PLAIN_SPLIT, p, e->h3_tile_qkv, s));
             }
             { int prc = prof_end(0); if (prc != CMDI_OK) return prc; }
             { int prc = prof_begin(1); if (prc != CMDI_OK) return prc; }
-            HIPCHK(launch_attention_h3(qkvS, nullptr, attnS, e->range_flag, nullptr, nseq, S, e->H, s,
-                                       e->qkv_head_major != 0));
+            HIPCHK(launch_attention_h3(qkvL, keep ? st->attn + r0 * d : nullptr, attnS, e->range_flag,
+                                       keep ? st->row_stats + (size_t)seq0 * e->H * S * 2 : nullptr, nseq, S, e->H, s, head_major));
             { int prc = prof_end(1); if (prc != CMDI_OK) return prc; }
             {   // pre1 = LN2_prev(P) + out_proj(attn)   -> bufHS (+ partial statistics A)
-                H3Params p = hp(attnS, w.out_ws, w.out_b, nullptr, bufHS, d, d);
+                H3Params p = hp(attnS, w.out_ws, w.out_b, keep ? st->pre1 + r0 * d : nullptr, bufHS, d, d);
                 p.Rs = tokS;
                 if (prev) { p.ln_part = partB; p.ln_rg = prev->n2_g; p.ln_rb = prev->n2_b; }
                 p.out_part = partA;
@@ -82,10 +91,11 @@ int run_layers(cmdi_engine* e, int seq0, int nseq, bool keep, bool prof, hipStre
             {   // ffn = gelu(linear1(LN1(pre1)))
                 H3Params p = hp(bufHS, w.l1_wsf, w.l1_c2, nullptr, ffnS, f, d);
                 p.ln_part = partA; p.ln_c1 = w.l1_c1;
+                if (keep) { p.aux = st->aux + r0 * f; p.ln_stats = st->stats1 + r0 * 2; }
                 HIPCHK(launch_gemm_h3(H3_GELU_SPLIT, p, e->h3_tile_ffn1, s));
             }
             {   // pre2 = LN1(pre1) + linear2(ffn)   -> tokS (+ partial statistics B): the next layer's P
-                H3Params p = hp(ffnS, w.l2_ws, w.l2_b, nullptr, tokS, d, f);
+                H3Params p = hp(ffnS, w.l2_ws, w.l2_b, keep ? st->pre2 + r0 * d : nullptr, tokS, d, f);
                 p.Rs = bufHS; p.ln_part = partA; p.ln_rg = w.n1_g; p.ln_rb = w.n1_b;
                 p.out_part = partB;
                 HIPCHK(launch_gemm_h3(H3_RESID, p, e->h3_tile_ffn2, s));
@@ -93,7 +103,8 @@ int run_layers(cmdi_engine* e, int seq0, int nseq, bool keep, bool prof, hipStre
         }
         // the encoder output is LN2 of the last layer: the one LayerNorm launch that remains (split rows in, in place)
         const LayerW& last = e->layers[e->L - 1];
-        HIPCHK(launch_layernorm(nullptr, last.n2_g, last.n2_b, nullptr, tokS, e->range_flag, nullptr, M, d, s, tokS));
+        HIPCHK(launch_layernorm(nullptr, last.n2_g, last.n2_b, nullptr, tokS, e->range_flag,
+                                keep ? e->stash[e->L - 1].stats2 + r0 * 2 : nullptr, M, d, s, tokS));
         return CMDI_OK;
     }
     for (int l = 0; l < e->L; ++l) {

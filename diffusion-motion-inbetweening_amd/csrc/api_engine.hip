@@ -143,6 +143,7 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
     e->ln_fuse = env_probe("CMDI_LN_FUSE", 0) && desc->d_model == 512;
     e->io_h3 = e->precision == CMDI_PREC_F16X3 && !e->ln_fuse && env_probe("CMDI_IO_H3", 1);
     e->ln_fold = e->io_h3 && desc->d_model == 512 && env_int("CMDI_LN_FOLD", 1);
+    e->ln_fold_keep = env_int("CMDI_LN_FOLD_KEEP", 1);
     e->qkv_head_major = env_int("CMDI_QKV_HEAD_MAJOR", 0);
     const int d = e->d, f = e->f, C = e->C;
     const size_t nseq = 2 * (size_t)e->Bmax, Smax = e->Tmax + 1, Mmax = nseq * Smax;

@@ -130,6 +130,7 @@ struct cmdi_engine {
     // per-row partial statistics and every LayerNorm is folded into the GEMM that consumes it (gemm_params.hpp);
     // CMDI_LN_FOLD=0 keeps the separate LayerNorm kernels
     int ln_fold = 0;
+    int ln_fold_keep = 1;     // the folded schedule also for forward passes that stash activations (CMDI_LN_FOLD_KEEP)
     int qkv_head_major = 0;   // folded path: in_proj writes q | k | v head-major for the attention kernel (CMDI_QKV_HEAD_MAJOR=1;
                               // measured: no gain — attention 36.0 vs 35.1 us, step 2.14 vs 2.07 ms — so off)
     float *partA = nullptr, *partB = nullptr;   // [M][16][2] partial statistics of pre1 / pre2

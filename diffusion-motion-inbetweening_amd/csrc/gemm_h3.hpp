@@ -678,7 +678,11 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
         mean *= (1.0f / 512.0f);
 #pragma unroll
         for (int q = 0; q < 16; ++q) { const float dq = mean_b[q] - mean; m2 = __builtin_fmaf(32.0f * dq, dq, m2); }
-        row_stats[tid] = make_float2(mean, 1.0f / sqrtf(__builtin_fmaf(m2, 1.0f / 512.0f, 1e-5f)));
+        const float2 ms = make_float2(mean, 1.0f / sqrtf(__builtin_fmaf(m2, 1.0f / 512.0f, 1e-5f)));
+        row_stats[tid] = ms;
+        // a stashing forward pass (reconstruction guidance) keeps (mean, rstd) of every LayerNorm for the backward: the blocks
+        // of the first column panel write them out
+        if (p.ln_stats && n0 == 0 && m0 + tid < M) *reinterpret_cast<float2*>(p.ln_stats + 2 * (size_t)(m0 + tid)) = ms;
     }
 
     const int nk_all = p.K / 32;

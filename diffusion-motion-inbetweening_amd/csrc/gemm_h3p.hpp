@@ -351,7 +351,7 @@ __global__ __launch_bounds__(H3PTile::NT, 2) void gemm_h3p_kernel(const H3Params
 
     // ---- folded LayerNorm: (mean, rstd) of a tile's rows, 16 rows per wave (same arithmetic, same bits as gemm_h3_body) --
     float2* stats0 = reinterpret_cast<float2*>(lds + TC::NSTAGE * STAGE);
-    auto row_stats = [&](int m0, int parity) {
+    auto row_stats = [&](int m0, int n0, int parity) {
         if (p.ln_part && lane < 16) {
             const int row = wave * 16 + lane;
             int grow = m0 + row;
@@ -368,7 +368,9 @@ __global__ __launch_bounds__(H3PTile::NT, 2) void gemm_h3p_kernel(const H3Params
             mean *= (1.0f / 512.0f);
 #pragma unroll
             for (int q = 0; q < 16; ++q) { const float dq = mean_b[q] - mean; m2 = __builtin_fmaf(32.0f * dq, dq, m2); }
-            stats0[parity * TC::BM + row] = make_float2(mean, 1.0f / sqrtf(__builtin_fmaf(m2, 1.0f / 512.0f, 1e-5f)));
+            const float2 ms = make_float2(mean, 1.0f / sqrtf(__builtin_fmaf(m2, 1.0f / 512.0f, 1e-5f)));
+            stats0[parity * TC::BM + row] = ms;
+            if (p.ln_stats && n0 == 0 && m0 + row < M) *reinterpret_cast<float2*>(p.ln_stats + 2 * (size_t)(m0 + row)) = ms;   // (as gemm_h3)
         }
     };
 
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(H3PTile::NT, 2) void gemm_h3p_kernel(const H3Params
     };
 
     // ---- prologue: statistics of the first tile, K steps 0 and 1 requested, K step 0 landed --------------------------------
-    row_stats(m0, 0);
+    row_stats(m0, n0, 0);
     issue_range(Q0{}, Q6{}, iss_kt, 0);
     advance_issue();
     issue_range(Q0{}, Q6{}, iss_kt, 1);       // (nk >= 2: the same item)
@@ -653,7 +655,7 @@ __global__ __launch_bounds__(H3PTile::NT, 2) void gemm_h3p_kernel(const H3Params
                 kstep_any(std::integral_constant<int, 2>{}, kt == 0);
             }
             if constexpr (STAMPS) { probe_kt = -1; if (probing) ts[11] = __builtin_readcyclecounter(); }
-            if (next < n_items) row_stats(nm0, parity ^ 1);
+            if (next < n_items) row_stats(nm0, nn0, parity ^ 1);
             if constexpr (STAMPS) { if (probing) ts[12] = __builtin_readcyclecounter(); }
             epi_enter();
             if (NO_EPI && acc0[0][0][0] != 12345.678f) { /* ablation: no epilogue */ }
@@ -663,7 +665,7 @@ __global__ __launch_bounds__(H3PTile::NT, 2) void gemm_h3p_kernel(const H3Params
             epi_leave();
         } else {
             for (int kt = 0; kt < nk; ++kt) kstep_any(std::integral_constant<int, 1>{}, kt == 0);
-            if (next < n_items) row_stats(nm0, parity ^ 1);
+            if (next < n_items) row_stats(nm0, nn0, parity ^ 1);
             epi_enter();
             if (edge) epilogue(std::integral_constant<int, 1>{}, std::true_type{});
             else epilogue(std::integral_constant<int, 1>{}, std::false_type{});

@@ -79,7 +79,8 @@ struct H3Params {
     float* aux;         // optional pre-activation stash [M][ldc]
     const float* ln_g;  // H3_RESID_LN: LayerNorm weight / bias [N], optional (mean, rstd) [M][2]
     const float* ln_b;
-    float* ln_stats;
+    float* ln_stats;    // H3_RESID_LN: (mean, rstd) of the rows normalised; with ln_part: (mean, rstd) derived from the partials,
+                        // written by the blocks of the first column panel (stash of a forward pass that keeps activations)
     int* range_flag;    // set to 1 if a split output leaves the f16 range
     int M, N, K, ldc;
     int n_big, m_split; // mixed-granularity launch (set by launch_gemm_h3)
