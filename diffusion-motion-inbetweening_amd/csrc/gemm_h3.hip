@@ -15,6 +15,7 @@ using H128x64s3 = H3Tile<128, 64, 2, 2, 3, 2>;      // 72 KiB, 2 blocks/CU
 using H64x128s2 = H3Tile<64, 128, 2, 2, 2, 2>;      // 32x64 per wave
 using H128x128w8s3 = H3Tile<128, 128, 4, 2, 3, 2>;  // 8 waves, 32x64 per wave, 96 KiB
 using H128x128w8s2 = H3Tile<128, 128, 4, 2, 2, 4>;  // 8 waves, 64 KiB, 2 blocks/CU (16 waves = 4 per SIMD: at most 128 VGPRs)
+using H128x128w8s2E = H3Tile<128, 128, 4, 2, 2, 4, 0, 1>;  // the same, 8-column-per-lane epilogue (dwordx4 split stores) on interior tiles
 using H128x128w8s2L = H3Tile<128, 128, 4, 2, 2, 2, 1>;  // the same, LDS-DMA requests issued among the trailing MFMAs
 using H128x128w8s2P = H3Tile<128, 128, 4, 2, 2, 2, 2>;  // the same, wait + barrier pinned behind the last MFMA of the K step
 using H128x128w8s2R = H3Tile<128, 128, 4, 2, 2, 2, 3>;  // the same, K step rotated around its barrier
@@ -104,6 +105,9 @@ static hipError_t launch_h3_tiles(const H3Params& p, int tile, hipStream_t s) {
         case 6: return launch_h3_one<H64x128s2, EPI>(p, s);
         case 7: return launch_h3_one<H128x128w8s3, EPI>(p, s);
         case 8: return launch_h3_one<H128x128w8s2, EPI>(p, s);
+        case 88:
+            if constexpr (EPI == H3_PLAIN_SPLIT || EPI == H3_GELU_SPLIT) return launch_h3_one<H128x128w8s2E, EPI>(p, s);
+            else return launch_h3_one<H128x128w8s2, EPI>(p, s);
         case 9: return launch_h3_one<H128x256s2, EPI>(p, s);
         case 10: return launch_h3_one<H256x128w16, EPI>(p, s);
         case 11: return launch_h3_one<H128x256w16, EPI>(p, s);
@@ -167,7 +171,12 @@ hipError_t launch_gemm_h3(int epi, const H3Params& p, int tile, hipStream_t s) {
     if (tile == 50) return launch_gemm_h3p(epi, p, s, 0);
     if (tile == 0 && gemm_h3_persistent_for(p.M) && gemm_h3p_supports(epi, p)) return launch_gemm_h3p(epi, p, s, 0);
     if (tile >= 1000) return launch_gemm_h3p(epi, p, s, tile - 1000);   // structure variants / ablations (probes library only)
-    if (tile == 0) tile = gemm_h3_auto_tile(p.M, p.N);
+    if (tile == 0) {
+        tile = gemm_h3_auto_tile(p.M, p.N);
+        static int epi8 = -1;
+        if (epi8 < 0) { const char* v = std::getenv("CMDI_H3_EPI8"); epi8 = v ? std::atoi(v) : 0; }
+        if (tile == 8 && epi8) tile = 88;
+    }
     if (epi == H3_CONV_GN) {   // tile rows = one framed sequence: 256 (level 0) or 128 (level 1)
         if (!p.ln_g || !p.ln_b || (!p.C && !p.Cs) || p.N % 128 != 0 || (p.gn_cg != 128 && p.gn_cg != 64) || p.M % p.tp != 0 ||
             p.c_row_mul || p.ksplit > 1)

@@ -56,12 +56,17 @@ __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
     lo = (_Float16)((x - (float)hi) * kLoScale);
 }
 
+}  // namespace cmdi
+#include "gemm_h3_epi.hpp"
+namespace cmdi {
+
 // LATE_ = 1: the LDS-DMA requests of the next K step are issued BETWEEN the trailing MFMAs of this one (one piece per
 // MFMA) instead of in front of the fragment reads — an LDS-DMA piece costs 60 cycles of issue among bare MFMAs but
 // 100-185 inside a phase that also carries the fragment reads (MI355X_MICROARCH.md, per-instruction constants).
-template <int BM_, int BN_, int WM_, int WN_, int NSTAGE_, int MINW_, int LATE_ = 0>
+template <int BM_, int BN_, int WM_, int WN_, int NSTAGE_, int MINW_, int LATE_ = 0, int EPI8_ = 0>
 struct H3Tile {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, NSTAGE = NSTAGE_, MINW = MINW_, LATE = LATE_;
+    static constexpr int EPI8 = EPI8_;             // interior tiles of the split epilogues without residual: 8 columns per lane
     static constexpr int BK = 32;                  // columns per K step = one 128-B line per row
     static constexpr int NW = WM * WN, NT = 64 * NW;
     static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -279,6 +284,30 @@ __device__ __forceinline__ void h3_epilogue(const H3Params& p, f32x16 (&acc0)[TC
         }
         const bool fast = !p.c_row_mul && !p.tp && m0 + BM <= M && n0 + BN <= p.N;
         (void)fast;
+        if constexpr (EPI == H3_PLAIN_SPLIT || EPI == H3_GELU_SPLIT) {
+            // interior tiles, round 3: 32 x 32 blocks with EIGHT columns per lane (gemm_h3_epi.hpp) — the hi and the lo half of a
+            // split row leave as one dwordx4 store each instead of two dwordx2 (half the store instructions through the
+            // address path this block's neighbour on the CU is feeding its LDS-DMA requests through).  Same arithmetic per
+            // element, same bits.
+            if (TC::EPI8 && fast && !p.cs_head_major) {
+                float* wb = reinterpret_cast<float*>(lds) + wave * (32 * ROWLEN);
+                const int cl8 = (lane & 3) * 8;
+                bool ovf = false;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int nb = n0 + wn * ROWLEN + j * 32;
+                        const H3PCols cols = h3p_load_cols<EPI>(p, nb + cl8);
+                        H3PRows rows;
+                        h3p_epi_block<EPI, false, false, true>(p, acc0[i][j], acc1[i][j], m0 + (wm * TM + i) * 32, nb,
+                                                               p.ln_part ? row_stats + (wm * TM + i) * 32 : nullptr, wb, lane, cols,
+                                                               rows, ovf);
+                    }
+                if (ovf && p.range_flag) atomicOr(p.range_flag, 1);
+                return;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -891,7 +920,8 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
 template <int BM_, int NSTAGE_, int PIN_ = 0>
 struct H3ATile {
     static constexpr int BM = BM_, BN = 128, WM = BM_ / 32, WN = 1, NSTAGE = NSTAGE_, MINW = 2, LATE = 0;
-    static constexpr int PIN = PIN_;   // 1: the step's wait + barrier are pinned behind its last MFMA; 0: the compiler places them
+    static constexpr int PIN = PIN_;
+    static constexpr int EPI8 = 0;   // 1: the step's wait + barrier are pinned behind its last MFMA; 0: the compiler places them
                                        // (it moves them up between the MFMAs, which rotates the step around its barrier)
     static constexpr int BK = 32;
     static constexpr int NW = WM, NT = 64 * NW;
