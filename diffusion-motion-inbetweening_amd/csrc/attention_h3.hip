@@ -47,24 +47,20 @@ typedef short s8v __attribute__((ext_vector_type(8)));
 // 4 different 64-B quarters).
 __device__ __forceinline__ int kswz(int k) { return ((k & 3) << 2) | ((k >> 2) & 3); }
 
+// One 32-key stage of K and V by LDS-DMA: 32 pieces of 1 KiB (2 keys each), 32 / NW per wave.  Round 3: `buffer_load ... offen
+// lds` through a descriptor that starts at the sequence's first row and ENDS WITH THE LAUNCH'S LAST ROW — the lane's byte
+// offset inside a stage is a constant of the kernel (computed once, kv_lane_offset), the stage position is the scalar offset,
+// and keys past the sequence need no clamp: inside the tensor they are the next sequence's (finite) rows, past its end the
+// hardware returns zeros; their scores are masked by a select and their P is exactly 0.  (Rounds 1-2: flat global_load_lds,
+// ~15 vector instructions of address arithmetic and clamping per piece, inside the key loop.)
 template <int NW = NWAVE>
-__device__ __forceinline__ void stage_kv(char* stage, const _Float16* __restrict__ base, size_t ld,
-                                         long koff, long voff, int key0, int S, int wave, int lane) {
-#pragma unroll
-    for (int it = 0; it < 32 / NW; ++it) {
-        const int pc = it * NW + wave;           // 0..15 K pieces, 16..31 V pieces (2 keys each)
-        const int mat = pc >> 4, g = pc & 15;
-        const int kl = 2 * g + (lane >> 5);
-        const int t = (lane & 31) ^ kswz(kl);
-        int key = key0 + kl;
-        key = key < S ? key : S - 1;             // rows past S: masked scores, P == 0, finite values
-        const _Float16* src = base + (size_t)key * ld + (mat ? voff : koff) + t * 8;
-        char* dst = stage + mat * TILE + g * 1024;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-    }
+__device__ __forceinline__ unsigned kv_lane_offset(int it, size_t ld, long koff, long voff, int wave, int lane) {
+    const int pc = it * NW + wave;               // 0..15 K pieces, 16..31 V pieces (2 keys each)
+    const int mat = pc >> 4, g = pc & 15;
+    const int kl = 2 * g + (lane >> 5);
+    const int t = (lane & 31) ^ kswz(kl);
+    return (unsigned)(((size_t)kl * ld + (size_t)(mat ? voff : koff) + t * 8) * 2);
 }
-
 __device__ __forceinline__ h8 tr_pair(const char* p0, const char* p1) {
     const s4v a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)p0);
     const s4v b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)p1);
@@ -152,9 +148,30 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const _Float16
     constexpr int PCS = 32 / NW;   // LDS-DMA pieces per wave per stage
     constexpr int AHEAD = STAG ? NS - 2 : NS - 1;   // stages requested ahead of the one being multiplied
     const bool lag = STAG == 1 ? wave >= NW / 2 : (STAG == 2 ? (wave & 1) != 0 : false);
+    const int uwave = __builtin_amdgcn_readfirstlane(wave);
+    unsigned kv_off[PCS];
+#pragma unroll
+    for (int it = 0; it < PCS; ++it) kv_off[it] = kv_lane_offset<NW>(it, ld, koff, voff, uwave, lane);
+    const unsigned row_bytes = (unsigned)(ld * 2);
+    // token-major: the descriptor ends with the last row of the launch's last sequence; head-major: with the V matrix of the
+    // last head (operand matrices of head_rows rows each)
+    const size_t n_seq = gridDim.x / H;
+    const size_t span = head_rows ? (size_t)3 * H * hm * 2 - (size_t)b * S * row_bytes
+                                  : (n_seq - b) * (size_t)S * row_bytes;
+    const auto kv_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(base), 0,
+                                                           (int)(span < 0xffffffffull ? span : 0xffffffffull), 0x00020000);
+    auto stage_kv = [&](char* stage, int key0) {
+#pragma unroll
+        for (int it = 0; it < PCS; ++it) {
+            const int pc = it * NW + uwave;
+            char* dst = stage + (pc >> 4) * TILE + (pc & 15) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(kv_rsrc, (__attribute__((address_space(3))) void*)dst, 16, (int)kv_off[it],
+                                                     (int)(key0 * row_bytes), 0, 0);
+        }
+    };
 #pragma unroll
     for (int st = 0; st < AHEAD; ++st)
-        if (st < nkb) stage_kv<NW>(lds + st * STAGE, base, ld, koff, voff, st * KBLK, S, wave, lane);
+        if (st < nkb) stage_kv(lds + st * STAGE, st * KBLK);
     {
         const int ahead = (nkb - 1 < AHEAD - 1 ? nkb - 1 : AHEAD - 1);   // stages allowed to stay in flight
         if (ahead >= 2) wait_vmcnt<2 * PCS>(); else if (ahead == 1) wait_vmcnt<PCS>(); else wait_vmcnt<0>();
@@ -262,7 +279,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const _Float16
 
     for (int kb = 0; kb < nkb; ++kb) {
         if (kb + AHEAD < nkb)
-            stage_kv<NW>(lds + ((kb + AHEAD) % NS) * STAGE, base, ld, koff, voff, (kb + AHEAD) * KBLK, S, wave, lane);
+            stage_kv(lds + ((kb + AHEAD) % NS) * STAGE, (kb + AHEAD) * KBLK);
         if (active) {
             if (!lag) {
                 scores(kb);
@@ -285,9 +302,50 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const _Float16
     if (active && lag) pv(nkb - 1);
 
     if (dbg & 16) t2 = __builtin_readcyclecounter();
+    // the ring is free from here on (round 3: the split output leaves through it as whole rows): every wave — the lagging
+    // group reads its last V tile after the loop's last barrier — must be past its last LDS read first
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     if (active) {
         const float lsum = l_run + __shfl_xor(l_run, 32, 64);
         const float inv = 1.0f / lsum;
+        if (out_s) {
+            // Split rows for the out_proj GEMM.  A lane holds ONE query's values at dims 32 db + 8 g4 + 4 hi + e: stored from
+            // registers that is 32 dwordx2 stores per lane, each instruction touching 32 rows with 16 bytes (rounds 1-2; the
+            // store tail was ~9 % of a block's life).  Now: the wave's 32 queries x 512 B (the head's 4 chunks of 64 B hi |
+            // 64 B lo) are assembled in a private LDS slice (rows padded to 528 B: conflict-free ds_write_b64 per 16-lane
+            // group) and leave as 16 dwordx4 stores per lane, every instruction two whole 512-byte rows.
+            constexpr int RSTR = 528;
+            char* ws = lds + wave * (32 * RSTR);
+            bool overflow = false;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    h4 oh, ol;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = o[db][4 * g4 + e] * inv;
+                        _Float16 a, c;
+                        split_f16(v, a, c);
+                        oh[e] = a; ol[e] = c;
+                        overflow |= qok && !(fabsf(v) < 65504.0f);
+                    }
+                    char* wp = ws + l31 * RSTR + db * 128 + (g4 * 8 + 4 * hi) * 2;
+                    *reinterpret_cast<h4*>(wp) = oh;
+                    *reinterpret_cast<h4*>(wp + 64) = ol;
+                }
+            if (overflow && range_flag) atomicOr(range_flag, 1);
+            // (wave-private slice: LDS operations of one wave execute in order, no barrier needed)
+            _Float16* ob = out_s + ((size_t)b * S + q0) * (2 * d_model) + split_pos(h * DH);
+#pragma unroll
+            for (int pc = 0; pc < 16; ++pc) {
+                const int row = 2 * pc + hi;
+                const uint4 v = *reinterpret_cast<const uint4*>(ws + row * RSTR + l31 * 16);
+                if (q0 + row < S)
+                    *reinterpret_cast<uint4*>(reinterpret_cast<char*>(ob + (size_t)row * (2 * d_model)) + l31 * 16) = v;
+            }
+        }
         if (qok) {
             if constexpr (STASH) {
                 if (hi == 0) {
@@ -304,28 +362,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const _Float16
                         *reinterpret_cast<float4*>(ob + db * 32 + g4 * 8) =
                             make_float4(o[db][4 * g4] * inv, o[db][4 * g4 + 1] * inv,
                                         o[db][4 * g4 + 2] * inv, o[db][4 * g4 + 3] * inv);
-            }
-            if (out_s) {
-                // split rows for the out_proj GEMM: chunk (h*4 + db), columns 8 g4 + 4 hi .. + 3
-                _Float16* ob = out_s + ((size_t)b * S + q) * (2 * d_model) + split_pos(h * DH) + 4 * hi;
-                bool overflow = false;
-#pragma unroll
-                for (int db = 0; db < 4; ++db)
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        h4 oh, ol;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float v = o[db][4 * g4 + e] * inv;
-                            _Float16 a, c;
-                            split_f16(v, a, c);
-                            oh[e] = a; ol[e] = c;
-                            overflow |= !(fabsf(v) < 65504.0f);
-                        }
-                        *reinterpret_cast<h4*>(ob + db * 64 + g4 * 8) = oh;
-                        *reinterpret_cast<h4*>(ob + db * 64 + g4 * 8 + 32) = ol;
-                    }
-                if (overflow && range_flag) atomicOr(range_flag, 1);
             }
         }
     }
@@ -766,7 +802,8 @@ static hipError_t launch_attention_h3_cfg(const _Float16* qkv_split, float* out,
                                           hipStream_t stream) {
     dim3 grid(n_seq * H, (S + 32 * NW - 1) / (32 * NW));
     const float scale = 1.0f / sqrtf((float)DH);
-    constexpr size_t lds = (size_t)NS * STAGE;
+    constexpr size_t lds_ring = (size_t)NS * STAGE, lds_epi = (size_t)NW * 32 * 528;   // K/V ring | output rows (epilogue)
+    constexpr size_t lds = lds_ring > lds_epi ? lds_ring : lds_epi;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_h3_kernel<true, NW, NS, STAG>),
