@@ -257,10 +257,13 @@ def pmc_counters(config: str, precision: str, batch: int, timeout_s: float = 150
                 res["pmc_error"] = f"rocprofv3 rc={r.returncode}: {r.stderr[-300:]}"
                 break
             files = [os.path.join(dp, f) for dp, _, fs in os.walk(out_dir) for f in fs if f.endswith("counter_collection.csv")]
+            # the GEMM family of this precision only: with reconstruction guidance the step also launches two fp32-MFMA boundary
+            # GEMMs whose busy-cycle count (1/16 of the f16 rate per flop) would otherwise win the "largest count" rule below
+            family = {"f16x3": "gemm_h3", "bf16x6": "gemm_x6", "f32": "gemm_nt"}.get(precision, "gemm")
             rows = []
             for fcsv in files:
                 with open(fcsv, newline="") as fh:
-                    rows += [r_ for r_ in csv.DictReader(fh) if "gemm" in r_["Kernel_Name"]]
+                    rows += [r_ for r_ in csv.DictReader(fh) if family in r_["Kernel_Name"]]
             if not rows:
                 res["pmc_error"] = "no gemm dispatches in the counter file"
                 break
