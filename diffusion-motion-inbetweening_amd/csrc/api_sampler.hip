@@ -305,21 +305,29 @@ static int sample_loop_pipelines(cmdi_engine* e, int32_t sampler, int32_t first_
         for (const Part& pt : parts) HIPCHK(hipStreamWaitEvent(pt.s, e->gevents[0], 0));
     }
     const size_t n = (size_t)e->B * e->C * e->T;
-    for (int step = first_step, i = 0; step >= last_step; --step, ++i) {
+    int rc = CMDI_OK;
+    for (int step = first_step, i = 0; step >= last_step && rc == CMDI_OK; --step, ++i) {
         const float* nz = d_noise_stream ? d_noise_stream + (size_t)i * n : nullptr;
         for (const Part& pt : parts) {
-            int rc = part_step(e, pt, sampler, step, eta, d_x, nz, seed, first_sample);
-            if (rc != CMDI_OK) return rc;
+            rc = part_step(e, pt, sampler, step, eta, d_x, nz, seed, first_sample);
+            if (rc != CMDI_OK) break;
         }
     }
+    // join — ALSO on the error path: the part streams may still be writing d_x, out_raw and the stash; the caller's
+    // stream (and whatever the caller does next on it, engine teardown by the Python retry path included) must be ordered
+    // after them before the error is returned
     if (G > 1) {
         for (const Part& pt : parts) {
-            HIPCHK(hipEventRecord(e->gevents[1 + pt.idx], pt.s));
-            HIPCHK(hipStreamWaitEvent(s, e->gevents[1 + pt.idx], 0));
+            const hipError_t e1 = hipEventRecord(e->gevents[1 + pt.idx], pt.s);
+            const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(s, e->gevents[1 + pt.idx], 0) : e1;
+            if (e2 != hipSuccess) {
+                (void)hipStreamSynchronize(pt.s);      // last resort: order by blocking
+                if (rc == CMDI_OK) rc = fail(CMDI_E_HIP, std::string("pipeline join: ") + hipGetErrorString(e2));
+            }
         }
     }
     e->stash_valid = false;   // the stash holds slot-ordered rows of the last step: not a cmdi_mdm_forward stash
-    return CMDI_OK;
+    return rc;
 }
 
 static int step_impl(cmdi_engine* e, int32_t sampler, int32_t step, float eta, float* d_x,

@@ -164,8 +164,16 @@ class SimpleTokenizer:
         self.decoder = {v: k for k, v in self.encoder.items()}
         self.bpe_ranks = dict(zip(merges, range(len(merges))))
         self.cache = {"<|startoftext|>": "<|startoftext|>", "<|endoftext|>": "<|endoftext|>"}
-        self.pat = re.compile(r"<\|startoftext\|>|<\|endoftext\|>|'s|'t|'re|'ve|'m|'ll|'d|[a-zA-Z]+|[0-9]|[^\s a-zA-Z0-9]+",
-                              re.IGNORECASE)
+        # openai/CLIP's pattern is r"<\|startoftext\|>|<\|endoftext\|>|'s|'t|'re|'ve|'m|'ll|'d|[\p{L}]+|[\p{N}]|[^\s\p{L}\p{N}]+"
+        # (third-party `regex` module, IGNORECASE): Unicode letters / numbers, not ASCII classes.  `regex` is used when it is
+        # importable; otherwise _split_unicode below scans with unicodedata categories — the same token boundaries (ADVICE r2:
+        # an ASCII pattern split "café", "größe" or "３" differently from the reference's tokenizer, silently)
+        try:
+            import regex
+            self.pat = regex.compile(r"<\|startoftext\|>|<\|endoftext\|>|'s|'t|'re|'ve|'m|'ll|'d|[\p{L}]+|[\p{N}]|[^\s\p{L}\p{N}]+",
+                                     regex.IGNORECASE)
+        except ImportError:
+            self.pat = None
 
     def bpe(self, token):
         if token in self.cache:
@@ -205,7 +213,7 @@ class SimpleTokenizer:
     def encode(self, text):
         text = re.sub(r"\s+", " ", html.unescape(html.unescape(text)).strip()).strip().lower()
         ids = []
-        for token in re.findall(self.pat, text):
+        for token in (self.pat.findall(text) if self.pat is not None else _split_unicode(text)):
             token = "".join(self.byte_encoder[b] for b in token.encode("utf-8"))
             ids.extend(self.encoder[t] for t in self.bpe(token).split(" "))
         return ids
@@ -213,6 +221,41 @@ class SimpleTokenizer:
     def decode(self, tokens):
         text = "".join(self.decoder[t] for t in tokens)
         return bytearray(self.byte_decoder[c] for c in text).decode("utf-8", errors="replace").replace("</w>", " ")
+
+
+def _split_unicode(text: str):
+    """The token boundaries of openai/CLIP's pattern (see SimpleTokenizer.__init__) without the `regex` module: alternatives
+    tried in its order at every position — special tokens, the seven contractions, a run of letters (category L*), ONE number
+    character (N*), a run of anything else that is not whitespace."""
+    import unicodedata
+    kind = lambda ch: unicodedata.category(ch)[0]
+    out, i, n = [], 0, len(text)
+    while i < n:
+        hit = next((sp for sp in ("<|startoftext|>", "<|endoftext|>", "'s", "'t", "'re", "'ve", "'m", "'ll", "'d")
+                    if text[i:i + len(sp)].lower() == sp), None)
+        if hit is not None:
+            out.append(text[i:i + len(hit)])
+            i += len(hit)
+            continue
+        ch = text[i]
+        if ch.isspace():
+            i += 1
+        elif kind(ch) == "L":
+            j = i + 1
+            while j < n and kind(text[j]) == "L":
+                j += 1
+            out.append(text[i:j])
+            i = j
+        elif kind(ch) == "N":
+            out.append(ch)
+            i += 1
+        else:
+            j = i + 1
+            while j < n and not text[j].isspace() and kind(text[j]) not in ("L", "N"):
+                j += 1
+            out.append(text[i:j])
+            i = j
+    return out
 
 
 def tokenize(tokenizer: SimpleTokenizer, texts, context_length: int = 77, truncate: bool = False) -> torch.Tensor:

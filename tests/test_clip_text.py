@@ -102,6 +102,26 @@ def test_simple_tokenizer(tmp_path):
     assert tt[0, -1] == n + 1 and tt[0, 0] == n
 
 
+def test_tokenizer_splits_unicode_like_openai_clip(tmp_path):
+    """openai/CLIP's pattern uses \\p{L} / \\p{N} (third-party `regex` module), not ASCII classes: non-ASCII letters and
+    digits must stay inside / form their own tokens.  The scanner used when `regex` is absent gives the same boundaries."""
+    ct = sub("model.clip_text")
+    strings = ["a person walks forward, then don't stop!!'s 12 steps", "café größe ３ ½ x² naïve—it's", "<|startoftext|>hello<|endoftext|>",
+               "tab\tand\nnewline  'll 've", "日本語のテキスト123 ok", "don''t !'s"]
+    want = [["café", "größe", "３", "½", "x", "²", "naïve", "—", "it", "'s"]]
+    assert ct._split_unicode(strings[1]) == want[0]
+    try:
+        import regex
+    except ImportError:
+        return
+    pat = regex.compile(r"<\|startoftext\|>|<\|endoftext\|>|'s|'t|'re|'ve|'m|'ll|'d|[\p{L}]+|[\p{N}]|[^\s\p{L}\p{N}]+", regex.IGNORECASE)
+    for t in strings:
+        assert pat.findall(t) == ct._split_unicode(t), t
+    make_bpe_file(tmp_path / "bpe.txt.gz")
+    tok = ct.SimpleTokenizer(str(tmp_path / "bpe.txt.gz"))
+    assert tok.pat is not None and tok.decode(tok.encode("Café  ３")).strip() == "café ３"
+
+
 def test_tower_state_dict_names_are_openai_clips():
     ct = sub("model.clip_text")
     tower = ct.CLIPTextTower(vocab_size=1000, transformer_width=256, transformer_heads=4, transformer_layers=2, embed_dim=256)
