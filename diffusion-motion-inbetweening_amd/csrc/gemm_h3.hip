@@ -15,19 +15,12 @@ using H128x64s3 = H3Tile<128, 64, 2, 2, 3, 2>;      // 72 KiB, 2 blocks/CU
 using H64x128s2 = H3Tile<64, 128, 2, 2, 2, 2>;      // 32x64 per wave
 using H128x128w8s3 = H3Tile<128, 128, 4, 2, 3, 2>;  // 8 waves, 32x64 per wave, 96 KiB
 using H128x128w8s2 = H3Tile<128, 128, 4, 2, 2, 4>;  // 8 waves, 64 KiB, 2 blocks/CU (16 waves = 4 per SIMD: at most 128 VGPRs)
-using H128x128w8s2E = H3Tile<128, 128, 4, 2, 2, 4, 0, 1>;  // the same, 8-column-per-lane epilogue (dwordx4 split stores) on interior tiles
-using H128x128w8s2L = H3Tile<128, 128, 4, 2, 2, 2, 1>;  // the same, LDS-DMA requests issued among the trailing MFMAs
-using H128x128w8s2P = H3Tile<128, 128, 4, 2, 2, 2, 2>;  // the same, wait + barrier pinned behind the last MFMA of the K step
-using H128x128w8s2R = H3Tile<128, 128, 4, 2, 2, 2, 3>;  // the same, K step rotated around its barrier
+using H128x128w8s2E = H3Tile<128, 128, 4, 2, 2, 4, 1>;     // the same, 8-column-per-lane epilogue (dwordx4 split stores) on interior tiles
 using H128x256s2 = H3Tile<128, 256, 2, 4, 2, 2>;    // 8 waves, 64x64 per wave, 96 KiB
 using H64x128w8s2 = H3Tile<64, 128, 2, 4, 2, 2>;    // 8 waves, 32x32 per wave: the tail tile of the mixed grid
 using H64x512ln = H3Tile<64, 512, 2, 4, 2, 2>;      // 8 waves, 32x128 per wave: full rows of d = 512 (LN fused)
 using H256x128w16 = H3Tile<256, 128, 8, 2, 3, 4>;   // 16 waves, 32x64 per wave, 3 stages = 144 KiB
 using H128x256w16 = H3Tile<128, 256, 4, 4, 3, 4>;   // 16 waves, 32x64 per wave
-using HA128 = H3ATile<128, 3>;                      // A in registers: 4 waves, 32x128 per wave, 65 KiB, 2 blocks/CU
-using HA256 = H3ATile<256, 3>;                      // 8 waves, 129 KiB, 1 block/CU
-using HA128P = H3ATile<128, 3, 1>;                  // ... barrier pinned at the end of the K step
-using HA256P = H3ATile<256, 3, 1>;
 
 template <class TC, int EPI>
 static hipError_t launch_h3_one(const H3Params& p, hipStream_t stream) {
@@ -42,22 +35,6 @@ static hipError_t launch_h3_one(const H3Params& p, hipStream_t stream) {
     }
     int tiles = ((p.M + TC::BM - 1) / TC::BM) * ((p.N + TC::BN - 1) / TC::BN);
     if (EPI == H3_PLAIN && p.ksplit > 1) tiles *= p.ksplit;
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(TC::NT), TC::LDS_BYTES, stream, p);
-    return hipGetLastError();
-}
-
-template <class TC, int EPI>
-static hipError_t launch_h3a(const H3Params& p, hipStream_t stream) {
-    if (p.cpt || p.a_ld || p.a_row_mul || p.c_row_mul || p.tp || p.ksplit > 1 || (p.K / 32) % 2 != 0) return hipErrorInvalidValue;
-    auto kern = gemm_h3a_kernel<TC, EPI>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)TC::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
-    const int tiles = ((p.M + TC::BM - 1) / TC::BM) * ((p.N + TC::BN - 1) / TC::BN);
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(TC::NT), TC::LDS_BYTES, stream, p);
     return hipGetLastError();
 }
@@ -112,17 +89,6 @@ static hipError_t launch_h3_tiles(const H3Params& p, int tile, hipStream_t s) {
         case 10: return launch_h3_one<H256x128w16, EPI>(p, s);
         case 11: return launch_h3_one<H128x256w16, EPI>(p, s);
         case 20: return launch_h3_mixed<EPI>(p, s);
-#ifdef CMDI_PROBES
-        // schedules that were measured and lost against tile 8 (tools/h3_tile_ab.py, DESIGN.md "GEMM design"); instantiated in
-        // the probes library only
-        case 30: return launch_h3_one<H128x128w8s2L, EPI>(p, s);
-        case 31: return launch_h3_one<H128x128w8s2P, EPI>(p, s);
-        case 32: return launch_h3_one<H128x128w8s2R, EPI>(p, s);
-        case 40: return launch_h3a<HA128, EPI>(p, s);
-        case 41: return launch_h3a<HA256, EPI>(p, s);
-        case 42: return launch_h3a<HA128P, EPI>(p, s);
-        case 43: return launch_h3a<HA256P, EPI>(p, s);
-#endif
         case 21: return launch_h3_one<H64x128w8s2, EPI>(p, s);
         default: return hipErrorInvalidValue;
     }

@@ -60,12 +60,12 @@ __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
 #include "gemm_h3_epi.hpp"
 namespace cmdi {
 
-// LATE_ = 1: the LDS-DMA requests of the next K step are issued BETWEEN the trailing MFMAs of this one (one piece per
-// MFMA) instead of in front of the fragment reads — an LDS-DMA piece costs 60 cycles of issue among bare MFMAs but
-// 100-185 inside a phase that also carries the fragment reads (MI355X_MICROARCH.md, per-instruction constants).
-template <int BM_, int BN_, int WM_, int WN_, int NSTAGE_, int MINW_, int LATE_ = 0, int EPI8_ = 0>
+// (Round 2 measured four more K-loop schedules on this tile — requests between the trailing MFMAs, wait + barrier pinned behind
+// the last MFMA, the K step rotated around its barrier, the A operand from registers; all lost to the one below and were
+// removed in round 3: DESIGN.md "GEMM design".)
+template <int BM_, int BN_, int WM_, int WN_, int NSTAGE_, int MINW_, int EPI8_ = 0>
 struct H3Tile {
-    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, NSTAGE = NSTAGE_, MINW = MINW_, LATE = LATE_;
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, NSTAGE = NSTAGE_, MINW = MINW_;
     static constexpr int EPI8 = EPI8_;             // interior tiles of the split epilogues without residual: 8 columns per lane
     static constexpr int BK = 32;                  // columns per K step = one 128-B line per row
     static constexpr int NW = WM * WN, NT = 64 * NW;
@@ -723,114 +723,11 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
     __builtin_amdgcn_s_barrier();
 
     if (CMDI_DBG(p) & 16) t_loop = __builtin_readcyclecounter();
-    if constexpr (TC::LATE == 3) {
-        // Rotated K step (2 stages): the step's ONE barrier sits in the middle of its MFMA stream.  First half = products of
-        // k-substep 0 (fragments read during the previous second half) + the reads of k-substep 1; barrier (every wave is done
-        // with the stage, the other stage has landed); second half = request step kt+2 into the stage just freed + products
-        // of k-substep 1 + the k-substep-0 reads of step kt+1.  A request has a whole K step to land, and there are MFMAs on
-        // either side of the barrier.  (Past the end the requests re-fetch the last step: branch-free, nobody reads it.)
-        static_assert(NSTAGE == 2, "rotated schedule: ring of 2");
-        issue(kt0 + 1 < nk ? kt0 + 1 : nk - 1, 1);
-        h8 ah0[TM], al0[TM], wh0[TN], wl0[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            ah0[i] = *reinterpret_cast<const h8*>(lds + a_row + i * 4096 + off_hi[0]);
-            al0[i] = *reinterpret_cast<const h8*>(lds + a_row + i * 4096 + off_lo[0]);
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            wh0[j] = *reinterpret_cast<const h8*>(lds + w_row + j * 4096 + off_hi[0]);
-            wl0[j] = *reinterpret_cast<const h8*>(lds + w_row + j * 4096 + off_lo[0]);
-        }
-        int cur = 0;
-        for (int kt = kt0; kt < nk; ++kt) {
-            const char* st = lds + cur * STAGE;
-            const char* sn = lds + (cur ^ 1) * STAGE;
-            h8 ah1[TM], al1[TM], wh1[TN], wl1[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                ah1[i] = *reinterpret_cast<const h8*>(st + a_row + i * 4096 + off_hi[1]);
-                al1[i] = *reinterpret_cast<const h8*>(st + a_row + i * 4096 + off_lo[1]);
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                wh1[j] = *reinterpret_cast<const h8*>(st + w_row + j * 4096 + off_hi[1]);
-                wl1[j] = *reinterpret_cast<const h8*>(st + w_row + j * 4096 + off_lo[1]);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0[i], wh0[j], acc0[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0[i], wl0[j], acc1[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0[i], wh0[j], acc1[i][j], 0, 0, 0);
-            constexpr int NRD = 2 * (TM + TN), NMM = 3 * TM * TN, PAIRS = NRD < NMM ? NRD : NMM;
-#pragma unroll
-            for (int q = 0; q < PAIRS; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            if constexpr (NRD > PAIRS) __builtin_amdgcn_sched_group_barrier(0x100, NRD - PAIRS, 0);
-            if constexpr (NMM > PAIRS) __builtin_amdgcn_sched_group_barrier(0x008, NMM - PAIRS, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            wait_vmcnt<0>();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            issue(kt + 2 < nk ? kt + 2 : nk - 1, cur);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                ah0[i] = *reinterpret_cast<const h8*>(sn + a_row + i * 4096 + off_hi[0]);
-                al0[i] = *reinterpret_cast<const h8*>(sn + a_row + i * 4096 + off_lo[0]);
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                wh0[j] = *reinterpret_cast<const h8*>(sn + w_row + j * 4096 + off_hi[0]);
-                wl0[j] = *reinterpret_cast<const h8*>(sn + w_row + j * 4096 + off_lo[0]);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1[i], wh1[j], acc0[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1[i], wl1[j], acc1[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1[i], wh1[j], acc1[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x010, PW, 0);
-#pragma unroll
-            for (int q = 0; q < PAIRS; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            if constexpr (NRD > PAIRS) __builtin_amdgcn_sched_group_barrier(0x100, NRD - PAIRS, 0);
-            if constexpr (NMM > PAIRS) __builtin_amdgcn_sched_group_barrier(0x008, NMM - PAIRS, 0);
-            cur ^= 1;
-        }
-        wait_vmcnt<0>();                 // the tail's surplus requests must not land in the epilogue's scratch
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    } else {
+    {
     int cur = 0, nxt = NSTAGE - 1;   // stage being multiplied / stage being filled
     for (int kt = kt0; kt < nk; ++kt) {
         const bool more = kt + NSTAGE - 1 < nk;
-        if constexpr (TC::LATE == 0 || TC::LATE == 2) {
-            if (more && !(CMDI_DBG(p) & 1)) issue(kt + NSTAGE - 1, nxt);
-        }
+        if (more && !(CMDI_DBG(p) & 1)) issue(kt + NSTAGE - 1, nxt);
         const char* st = lds + cur * STAGE;
         h8 ah[2][TM], al[2][TM], wh[2][TN], wl[2][TN];
 #pragma unroll
@@ -872,23 +769,10 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
-        if constexpr (TC::LATE == 1) {
-            // branch-free: past the last K step the requests re-fetch a valid step into the stage nobody reads again
-            issue(more ? kt + NSTAGE - 1 : nk - 1, nxt);
-            constexpr int REST = 6 * TM * TN - 2 * (TM + TN);
-            static_assert(REST >= PW + 1, "not enough trailing MFMAs to carry the DMA pieces");
-            __builtin_amdgcn_sched_group_barrier(0x008, REST - PW, 0);
-#pragma unroll
-            for (int q = 0; q < PW; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // (LDS-DMA counts as VMEM, not as a "VMEM read")
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            }
-        } else
         __builtin_amdgcn_sched_group_barrier(0x008, 6 * TM * TN - 2 * (TM + TN), 0);
         // stage kt+1 must have landed (this wave's pieces; the barrier extends it to every wave's);
         // with 3 stages the pieces of stage kt+2, issued above, stay in flight across the barrier
-        if constexpr (TC::LATE == 2) __builtin_amdgcn_sched_barrier(0);   // wait + barrier stay behind the step's last MFMA
-        if (NSTAGE == 3 && (more || TC::LATE == 1)) wait_vmcnt<PW>(); else wait_vmcnt<0>();
+        if (NSTAGE == 3 && more) wait_vmcnt<PW>(); else wait_vmcnt<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         cur = cur + 1 == NSTAGE ? 0 : cur + 1;
@@ -909,182 +793,6 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
         o[2] = (o[2] - o[1]);   // loop duration
         o[1] = (long long)(((unsigned long long)xcc << 32) | hwid);
     }
-}
-
-// ---- "A in registers" tiles ------------------------------------------------------------------------------------------
-// A wave owns 32 WHOLE rows of the tile (WN = 1, 32 x 128 outputs = 8 accumulator fragments): its A fragments are shared
-// with no other wave, so they skip LDS — each lane fetches its own 4 x 16 B of the row's 128-byte K-step line straight into
-// the MFMA operand registers (one K step ahead, two register sets) — and only the W panel is staged (LDS-DMA ring of BN
-// rows).  Against the 32 x 64-per-wave tiles this halves the LDS-DMA requests and drops the LDS fragment reads from 12 to 8
-// per 12 MFMAs.  Plain GEMMs only (no convolution addressing, no split-K); K / 32 even.
-template <int BM_, int NSTAGE_, int PIN_ = 0>
-struct H3ATile {
-    static constexpr int BM = BM_, BN = 128, WM = BM_ / 32, WN = 1, NSTAGE = NSTAGE_, MINW = 2, LATE = 0;
-    static constexpr int PIN = PIN_;
-    static constexpr int EPI8 = 0;   // 1: the step's wait + barrier are pinned behind its last MFMA; 0: the compiler places them
-                                       // (it moves them up between the MFMAs, which rotates the step around its barrier)
-    static constexpr int BK = 32;
-    static constexpr int NW = WM, NT = 64 * NW;
-    static constexpr int TM = 1, TN = 4;
-    static constexpr int STAGE = BN * 128;         // bytes: W rows only
-    static constexpr int PW = BN / 8 / NW;         // LDS-DMA pieces per wave per stage
-    static constexpr size_t EPI_BYTES = (size_t)NW * 32 * 32 * TN * 4;
-    static constexpr size_t MAIN_BYTES = (size_t)NSTAGE * STAGE > EPI_BYTES ? (size_t)NSTAGE * STAGE : EPI_BYTES;
-    static constexpr size_t LDS_BYTES = MAIN_BYTES + (size_t)BM * 8;
-    static_assert(NSTAGE == 3, "the in-loop wait is written for a W ring of 3");
-    static_assert((BN / 8) % NW == 0, "DMA pieces per wave");
-};
-
-template <class TC, int EPI>
-__device__ __forceinline__ void gemm_h3a_body(const H3Params& p, int block_id, char* lds) {
-    constexpr int BM = TC::BM, BN = TC::BN, TN = TC::TN, NW = TC::NW;
-    constexpr int STAGE = TC::STAGE, NSTAGE = TC::NSTAGE, PW = TC::PW;
-    const int M = p.M;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, hi = lane >> 5;
-
-    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
-    const int bid = xcd_remap(block_id, tiles_m * tiles_n);
-    const int m0 = (p.m_fast ? bid % tiles_m : bid / tiles_n) * BM, n0 = (p.m_fast ? bid / tiles_m : bid % tiles_n) * BN;
-
-    f32x16 acc0[1][TN], acc1[1][TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[0][j][r] = 0.f; acc1[0][j][r] = 0.f; }
-
-    const size_t ldk = 2 * (size_t)p.K;
-    const int nk = p.K / 32;
-    // W panel: LDS-DMA pieces, bank swizzle on the source address as in gemm_h3_body
-    const int prow = lane >> 3, pslot = lane & 7;
-    const _Float16* w_src[PW];
-#pragma unroll
-    for (int q = 0; q < PW; ++q) {
-        const int row = (q * NW + wave) * 8 + prow;
-        int grow = n0 + row;
-        grow = grow < p.N ? grow : p.N - 1;
-        w_src[q] = p.W + (size_t)grow * ldk + ((pslot ^ ((row >> 1) & 7)) << 3);
-    }
-    auto issue_w = [&](int kt, int buf) {
-        char* stage = lds + buf * STAGE;
-#pragma unroll
-        for (int q = 0; q < PW; ++q)
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(w_src[q] + kt * 64),
-                (__attribute__((address_space(3))) void*)(stage + (q * NW + wave) * 1024), 16, 0, 0);
-    };
-    // A row of this lane: halves [hi 8, +8) of every 16-column k-substep, hi plane then lo plane (split rows, header)
-    int arow = m0 + wave * 32 + l31;
-    arow = arow < M ? arow : M - 1;
-    const _Float16* a_ptr = p.A + (size_t)arow * ldk + hi * 8;
-    // The loads are inline assembly on purpose: with compiler-visible register loads in flight next to LDS-DMA requests the
-    // compiler's own wait insertion falls back to vmcnt(0) in front of the first use (two kinds of events on one counter),
-    // which would expose the whole memory latency every other K step.  The registers become valid at a_landed(), whose
-    // operands tie every later use to the counted wait.
-    auto load_a = [&](int kt, h8 (&a)[4]) {
-        const _Float16* src = a_ptr + kt * 64;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a[0]) : "v"(src) : "memory");             // hi plane, k-substep 0
-        asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "=v"(a[1]) : "v"(src) : "memory");   // hi plane, k-substep 1
-        asm volatile("global_load_dwordx4 %0, %1, off offset:64" : "=v"(a[2]) : "v"(src) : "memory");   // lo plane, k-substep 0
-        asm volatile("global_load_dwordx4 %0, %1, off offset:96" : "=v"(a[3]) : "v"(src) : "memory");   // lo plane, k-substep 1
-    };
-    auto a_landed = [&](h8 (&a)[4]) {   // everything but the last PW requests (= the newest W stage) has arrived
-        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "n"(PW) : "memory");
-    };
-
-    const int swz = (l31 >> 1) & 7;
-    int off_hi[2], off_lo[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        off_hi[ks] = ((2 * ks + hi) ^ swz) * 16;
-        off_lo[ks] = ((4 + 2 * ks + hi) ^ swz) * 16;
-    }
-    const int w_row = l31 * 128;   // + j * 32 * 128
-
-    // folded LayerNorm: (mean, rstd) of the tile's rows (same arithmetic, same bits as gemm_h3_body)
-    float2* row_stats = reinterpret_cast<float2*>(lds + TC::MAIN_BYTES);
-    if (p.ln_part && tid < BM) {
-        int grow = m0 + tid;
-        grow = grow < M ? grow : M - 1;
-        const float4* pp = reinterpret_cast<const float4*>(p.ln_part + (size_t)grow * 32);
-        float mean_b[16], m2 = 0.f, mean = 0.f;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float4 v = pp[q];
-            mean_b[2 * q] = v.x * (1.0f / 32.0f); mean_b[2 * q + 1] = v.z * (1.0f / 32.0f);
-            m2 += v.y + v.w;
-            mean += v.x + v.z;
-        }
-        mean *= (1.0f / 512.0f);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) { const float dq = mean_b[q] - mean; m2 = __builtin_fmaf(32.0f * dq, dq, m2); }
-        row_stats[tid] = make_float2(mean, 1.0f / sqrtf(__builtin_fmaf(m2, 1.0f / 512.0f, 1e-5f)));
-    }
-
-    h8 a_even[4], a_odd[4];
-    load_a(0, a_even);
-    issue_w(0, 0);
-    issue_w(1, 1);
-    a_landed(a_even);                // A(0) and W(0) have landed, W(1) may be in flight
-    __builtin_amdgcn_s_barrier();
-
-    int cur = 0, nxt = NSTAGE - 1;
-    // One K step.  Requests go out first — A of step kt+1 into the other register set, then W of step kt+2 into the stage
-    // freed by the previous barrier (past the end both re-fetch the last step: branch-free, nobody reads it) — so the wait at
-    // the bottom, "all but the last PW", covers exactly what step kt+1 needs.
-    auto step = [&](int kt, h8 (&ac)[4], h8 (&an)[4]) {
-        load_a(kt + 1 < nk ? kt + 1 : nk - 1, an);
-        issue_w(kt + 2 < nk ? kt + 2 : nk - 1, nxt);
-        const char* st = lds + cur * STAGE;
-        h8 wh[2][TN], wl[2][TN];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                wh[ks][j] = *reinterpret_cast<const h8*>(st + w_row + j * 4096 + off_hi[ks]);
-                wl[ks][j] = *reinterpret_cast<const h8*>(st + w_row + j * 4096 + off_lo[ks]);
-            }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                acc0[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ac[ks], wh[ks][j], acc0[0][j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                acc1[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ac[ks], wl[ks][j], acc1[0][j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                acc1[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ac[2 + ks], wh[ks][j], acc1[0][j], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x010, 4 + PW, 0);        // the requests
-        __builtin_amdgcn_sched_group_barrier(0x100, 2 * TN, 0);        // W fragments of k-substep 0
-#pragma unroll
-        for (int q = 0; q < 2 * TN; ++q) {                              // k-substep 1's under k-substep 0's products
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 6 * TN - 2 * TN, 0);
-        if constexpr (TC::PIN) __builtin_amdgcn_sched_barrier(0);
-        a_landed(an);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        cur = cur + 1 == NSTAGE ? 0 : cur + 1;
-        nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
-    };
-    for (int kt = 0; kt < nk; kt += 2) {
-        step(kt, a_even, a_odd);
-        step(kt + 1, a_odd, a_even);
-    }
-    wait_vmcnt<0>();                 // the tail's surplus requests must not land in the epilogue's scratch
-    __builtin_amdgcn_s_barrier();
-
-    h3_epilogue<TC, EPI>(p, acc0, acc1, m0, n0, M, 0, lds);
-}
-
-template <class TC, int EPI>
-__global__ __launch_bounds__(TC::NT, TC::MINW) void gemm_h3a_kernel(const H3Params p) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    gemm_h3a_body<TC, EPI>(p, blockIdx.x, lds);
 }
 
 template <class TC, int EPI>

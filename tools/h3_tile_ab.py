@@ -5,7 +5,7 @@ from tools.x6_bench import timeit, rel
 dev = torch.device("cuda:0")
 M = 2 * 32 * 197
 g = torch.Generator().manual_seed(1)
-TILES = tuple(int(t) for t in sys.argv[1].split(",")) if len(sys.argv) > 1 else (8, 31, 32)
+TILES = tuple(int(t) for t in sys.argv[1].split(",")) if len(sys.argv) > 1 else (8, 1, 88)
 for (m, n, k, epi, name) in [(M, 1536, 512, 0, "in_proj"), (M, 1024, 512, 1, "linear1"), (M, 512, 512, 3, "out_proj"), (M, 512, 1024, 3, "linear2"),
                             (M // 2, 1536, 512, 0, "in_proj/2"), (M // 2, 512, 1024, 3, "linear2/2")]:
     a = torch.randn(m, k, generator=g).to(dev); w = (torch.randn(n, k, generator=g) * 0.05).to(dev); b = torch.randn(n, generator=g).to(dev); r = torch.randn(m, n, generator=g).to(dev)
