@@ -20,7 +20,6 @@
 //                    V_lo'·(p_hi·2^-11) share ONE accumulator.  Vᵀ fragments come from the row-major
 //                    V tile through ds_read_b64_tr_b16 (hardware 4x4 transpose).
 #include <cstdlib>
-#include <type_traits>
 
 #include "common.hpp"
 #include "gemm_h3.hpp"
@@ -37,14 +36,10 @@ constexpr int TILE = KBLK * ROWB;        // 16 KiB per K or V tile
 constexpr int STAGE = 2 * TILE;
 constexpr int NSTG = 4;                  // LDS ring: 3 stages (96 KiB) in flight ahead of the one being used
 constexpr int kAttnStagDefault = 1;      // two wave groups half a stage apart (attention_h3_kernel); probes build: CMDI_ATTN_STAG
-constexpr int kAttnTrAsmDefault = 0;     // V transpose reads as inline asm (CMDI_ATTN_TRASM, see tr_pair_asm)
-constexpr int kAttnPipeDefault = 0;      // attention_h3_pipe_kernel (CMDI_ATTN_PIPE)
 constexpr int kAttnSplitDefault = 0;     // see launch_attention_h3 (measured: 36.7 vs 35.1 us per layer — no gain, so off)
 
 typedef short s4v __attribute__((ext_vector_type(4)));
 typedef short s8v __attribute__((ext_vector_type(8)));
-typedef unsigned u4v __attribute__((ext_vector_type(4)));
-typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
 // 16-B slot swizzle of a tile row (32 slots per key): slot t of key k is stored at t ^ kswz(k).
 // kswz is a bijection of k & 15 (K: the 16 keys of a ds_read_b128 lane group hit 16 different slots
@@ -71,95 +66,7 @@ __device__ __forceinline__ h8 tr_pair(const char* p0, const char* p1) {
     const s4v b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)p1);
     return __builtin_bit_cast(h8, (s8v)__builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
 }
-// The same read as inline asm (TRASM): the compiler puts `s_waitcnt vmcnt(0)` in front of the first builtin transpose read
-// of every stage — it cannot tell that read from the LDS-DMA requests in flight (it does not do this for ds_read_b128) —
-// which turns the K / V look-ahead into a wait for the NEWEST request.  The asm form is invisible to that analysis; its
-// results need an explicit lgkmcnt wait before use.  (LDS operations complete in order, so the compiler's own counted
-// waits stay correct: younger operations it does not know about only make them longer.)
-__device__ __forceinline__ h8 tr_pair_asm(const char* p0, const char* p1) {
-    s4v a, b;
-    const unsigned a0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p0;
-    const unsigned a1 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p1;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(a) : "v"(a0));
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b) : "v"(a1));
-    return __builtin_bit_cast(h8, (s8v)__builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
-}
 }  // namespace
-
-// Normalise and store one wave's 32 queries (shared by the forward kernels): split rows for the out_proj GEMM through the
-// wave's LDS slice, fp32 rows, and the softmax row statistics (max in ln units, 1 / sum) for the backward kernels.
-template <bool STASH>
-__device__ __forceinline__ void attn_write_out(char* lds, f32x16 (&o)[4], float l_run, float m_run, float* __restrict__ out,
-                                               _Float16* __restrict__ out_s, int* __restrict__ range_flag,
-                                               float* __restrict__ row_stats, int S, int d_model, int b, int h, int bh,
-                                               int q0, int wave, int lane, bool active) {
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int q = q0 + l31;
-    const bool qok = active && q < S;
-    // the ring is free from here on (round 3: the split output leaves through it as whole rows): every wave — the lagging
-    // group reads its last V tile after the loop's last barrier — must be past its last LDS read first
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (active) {
-        const float lsum = l_run + __shfl_xor(l_run, 32, 64);
-        const float inv = 1.0f / lsum;
-        if (out_s) {
-            // Split rows for the out_proj GEMM.  A lane holds ONE query's values at dims 32 db + 8 g4 + 4 hi + e: stored from
-            // registers that is 32 dwordx2 stores per lane, each instruction touching 32 rows with 16 bytes (rounds 1-2; the
-            // store tail was ~9 % of a block's life).  Now: the wave's 32 queries x 512 B (the head's 4 chunks of 64 B hi |
-            // 64 B lo) are assembled in a private LDS slice (rows padded to 528 B: conflict-free ds_write_b64 per 16-lane
-            // group) and leave as 16 dwordx4 stores per lane, every instruction two whole 512-byte rows.
-            constexpr int RSTR = 528;
-            char* ws = lds + wave * (32 * RSTR);
-            bool overflow = false;
-#pragma unroll
-            for (int db = 0; db < 4; ++db)
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    h4 oh, ol;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float v = o[db][4 * g4 + e] * inv;
-                        _Float16 a, c;
-                        split_f16(v, a, c);
-                        oh[e] = a; ol[e] = c;
-                        overflow |= qok && !(fabsf(v) < 65504.0f);
-                    }
-                    char* wp = ws + l31 * RSTR + db * 128 + (g4 * 8 + 4 * hi) * 2;
-                    *reinterpret_cast<h4*>(wp) = oh;
-                    *reinterpret_cast<h4*>(wp + 64) = ol;
-                }
-            if (overflow && range_flag) atomicOr(range_flag, 1);
-            // (wave-private slice: LDS operations of one wave execute in order, no barrier needed)
-            _Float16* ob = out_s + ((size_t)b * S + q0) * (2 * d_model) + split_pos(h * DH);
-#pragma unroll
-            for (int pc = 0; pc < 16; ++pc) {
-                const int row = 2 * pc + hi;
-                const uint4 v = *reinterpret_cast<const uint4*>(ws + row * RSTR + l31 * 16);
-                if (q0 + row < S)
-                    *reinterpret_cast<uint4*>(reinterpret_cast<char*>(ob + (size_t)row * (2 * d_model)) + l31 * 16) = v;
-            }
-        }
-        if (qok) {
-            if constexpr (STASH) {
-                if (hi == 0) {
-                    row_stats[((size_t)bh * S + q) * 2] = m_run * 0.6931471805599453f;   // back to ln units
-                    row_stats[((size_t)bh * S + q) * 2 + 1] = inv;
-                }
-            }
-            if (out) {
-                float* ob = out + ((size_t)b * S + q) * d_model + h * DH + 4 * hi;
-#pragma unroll
-                for (int db = 0; db < 4; ++db)
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4)
-                        *reinterpret_cast<float4*>(ob + db * 32 + g4 * 8) =
-                            make_float4(o[db][4 * g4] * inv, o[db][4 * g4 + 1] * inv,
-                                        o[db][4 * g4 + 2] * inv, o[db][4 * g4 + 3] * inv);
-            }
-        }
-    }
-}
 
 // NW waves per block (32 queries each) and an LDS ring of NS K/V stages.  (8, 4): one block per (sequence, head) and per
 // CU, K / V staged once, three stages in flight.  (4, 2): the queries of a (sequence, head) are split over two blocks of
@@ -171,7 +78,7 @@ __device__ __forceinline__ void attn_write_out(char* lds, f32x16 (&o)[4], float 
 // [Vᵀ·Pᵀ of the previous stage, K·Qᵀ, softmax] inside a barrier interval where the leading group runs [K·Qᵀ, softmax,
 // Vᵀ·Pᵀ]: one group's softmax falls under the other's products.  The ring then keeps the previous stage alive, so the
 // look-ahead is NS - 2 stages instead of NS - 1.  STAG = 1: waves NW/2.. lag; STAG = 2: odd waves lag.
-template <bool STASH, int NW = NWAVE, int NS = NSTG, int STAG = 0, bool TRASM = false>
+template <bool STASH, int NW = NWAVE, int NS = NSTG, int STAG = 0>
 __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const _Float16* __restrict__ qkv,
                                                               float* __restrict__ out,
                                                               _Float16* __restrict__ out_s,
@@ -353,19 +260,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const _Float16
             for (int db = 0; db < 4; ++db) {
                 const int k0 = 16 * kk + v_kl, k1 = k0 + 8;
                 const int t = db * 8 + v_slot;
-                if constexpr (TRASM) {
-                    vh[db] = tr_pair_asm(vt + k0 * ROWB + ((t ^ kswz(k0)) << 4) + v_half,
-                                         vt + k1 * ROWB + ((t ^ kswz(k1)) << 4) + v_half);
-                    vl[db] = tr_pair_asm(vt + k0 * ROWB + (((t + 4) ^ kswz(k0)) << 4) + v_half,
-                                         vt + k1 * ROWB + (((t + 4) ^ kswz(k1)) << 4) + v_half);
-                } else {
-                    vh[db] = tr_pair(vt + k0 * ROWB + ((t ^ kswz(k0)) << 4) + v_half,
-                                     vt + k1 * ROWB + ((t ^ kswz(k1)) << 4) + v_half);
-                    vl[db] = tr_pair(vt + k0 * ROWB + (((t + 4) ^ kswz(k0)) << 4) + v_half,
-                                     vt + k1 * ROWB + (((t + 4) ^ kswz(k1)) << 4) + v_half);
-                }
+                vh[db] = tr_pair(vt + k0 * ROWB + ((t ^ kswz(k0)) << 4) + v_half,
+                                 vt + k1 * ROWB + ((t ^ kswz(k1)) << 4) + v_half);
+                vl[db] = tr_pair(vt + k0 * ROWB + (((t + 4) ^ kswz(k0)) << 4) + v_half,
+                                 vt + k1 * ROWB + (((t + 4) ^ kswz(k1)) << 4) + v_half);
             }
-            if constexpr (TRASM) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int db = 0; db < 4; ++db)
                 o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[db], ph, o[db], 0, 0, 0);
@@ -403,440 +302,74 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const _Float16
     if (active && lag) pv(nkb - 1);
 
     if (dbg & 16) t2 = __builtin_readcyclecounter();
-    attn_write_out<STASH>(lds, o, l_run, m_run, out, out_s, range_flag, row_stats, S, d_model, b, h, bh, q0, wave, lane, active);
+    // the ring is free from here on (round 3: the split output leaves through it as whole rows): every wave — the lagging
+    // group reads its last V tile after the loop's last barrier — must be past its last LDS read first
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (active) {
+        const float lsum = l_run + __shfl_xor(l_run, 32, 64);
+        const float inv = 1.0f / lsum;
+        if (out_s) {
+            // Split rows for the out_proj GEMM.  A lane holds ONE query's values at dims 32 db + 8 g4 + 4 hi + e: stored from
+            // registers that is 32 dwordx2 stores per lane, each instruction touching 32 rows with 16 bytes (rounds 1-2; the
+            // store tail was ~9 % of a block's life).  Now: the wave's 32 queries x 512 B (the head's 4 chunks of 64 B hi |
+            // 64 B lo) are assembled in a private LDS slice (rows padded to 528 B: conflict-free ds_write_b64 per 16-lane
+            // group) and leave as 16 dwordx4 stores per lane, every instruction two whole 512-byte rows.
+            constexpr int RSTR = 528;
+            char* ws = lds + wave * (32 * RSTR);
+            bool overflow = false;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    h4 oh, ol;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = o[db][4 * g4 + e] * inv;
+                        _Float16 a, c;
+                        split_f16(v, a, c);
+                        oh[e] = a; ol[e] = c;
+                        overflow |= qok && !(fabsf(v) < 65504.0f);
+                    }
+                    char* wp = ws + l31 * RSTR + db * 128 + (g4 * 8 + 4 * hi) * 2;
+                    *reinterpret_cast<h4*>(wp) = oh;
+                    *reinterpret_cast<h4*>(wp + 64) = ol;
+                }
+            if (overflow && range_flag) atomicOr(range_flag, 1);
+            // (wave-private slice: LDS operations of one wave execute in order, no barrier needed)
+            _Float16* ob = out_s + ((size_t)b * S + q0) * (2 * d_model) + split_pos(h * DH);
+#pragma unroll
+            for (int pc = 0; pc < 16; ++pc) {
+                const int row = 2 * pc + hi;
+                const uint4 v = *reinterpret_cast<const uint4*>(ws + row * RSTR + l31 * 16);
+                if (q0 + row < S)
+                    *reinterpret_cast<uint4*>(reinterpret_cast<char*>(ob + (size_t)row * (2 * d_model)) + l31 * 16) = v;
+            }
+        }
+        if (qok) {
+            if constexpr (STASH) {
+                if (hi == 0) {
+                    row_stats[((size_t)bh * S + q) * 2] = m_run * 0.6931471805599453f;   // back to ln units
+                    row_stats[((size_t)bh * S + q) * 2 + 1] = inv;
+                }
+            }
+            if (out) {
+                float* ob = out + ((size_t)b * S + q) * d_model + h * DH + 4 * hi;
+#pragma unroll
+                for (int db = 0; db < 4; ++db)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4)
+                        *reinterpret_cast<float4*>(ob + db * 32 + g4 * 8) =
+                            make_float4(o[db][4 * g4] * inv, o[db][4 * g4 + 1] * inv,
+                                        o[db][4 * g4 + 2] * inv, o[db][4 * g4 + 3] * inv);
+            }
+        }
+    }
     if constexpr (!STASH) {
         if ((dbg & 16) && row_stats && tid == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             long long* o = reinterpret_cast<long long*>(row_stats) + (size_t)blockIdx.x * 4;
             o[0] = t1 - t0; o[1] = t2 - t1; o[2] = __builtin_readcyclecounter() - t2; o[3] = 0;
-        }
-    }
-}
-
-// Software-pipelined forward kernel (round 3): 4 waves per block, ONE per SIMD with the whole register file, 64 queries
-// (two groups of 32) per wave.  In attention_h3_kernel a stage is [K·Qᵀ (matrix pipe), softmax (VALU), Vᵀ·Pᵀ (matrix pipe)]
-// in sequence inside a wave and only the partner wave of the SIMD can fill the other pipe; its 256-register budget has no
-// room for a second score tile.  Here a wave overlaps the pipes on its own, in an issue order pinned by sched_barrier (left
-// alone the scheduler clusters the MFMAs and runs the vector arithmetic after them):
-//   interval kb:  scores -> s[] (frees the score accumulators)
-//                 [ K·Qᵀ of stage kb+1, both groups  |  softmax of stage kb, group 0 ]      48 MFMAs, a piece after each
-//                 [ Vᵀ·Pᵀ of stage kb, group 0        |  softmax of stage kb, group 1 ]      24 MFMAs
-//                 [ Vᵀ·Pᵀ of stage kb, group 1 ]                                             24 MFMAs
-// K fragments are read from LDS once per 64 queries.  K is needed one stage earlier than V, so the two have separate LDS
-// rings of 4 x 16 KiB (slot = stage & 3 for both; the key loop is unrolled over the ring so every LDS offset is an immediate).
-// The same operand tricks, lazy reference maximum and output path as attention_h3_kernel.
-namespace {
-constexpr int NKS = 4, NVS = 4;
-constexpr int PNW = 4;                   // waves per block
-template <int N>
-__device__ __forceinline__ void wait_vmcnt_upto(int n) {   // n (a multiple of 4) pieces may stay in flight
-    if constexpr (N == 0) { wait_vmcnt<0>(); }
-    else { if (n >= N) wait_vmcnt<N>(); else wait_vmcnt_upto<N - 4>(n); }
-}
-// ds_read_b64_tr_b16 as inline asm.  Through the builtin the compiler puts `s_waitcnt vmcnt(0)` in front of the first
-// transpose read of every stage (it cannot tell the read from the LDS-DMA requests still in flight — it does not do that
-// for ds_read_b128), which turns the K / V look-ahead into a wait for the newest request.  The asm form is invisible to
-// that analysis; the price is that ITS results need an explicit lgkmcnt wait (tr_wait) before use.  (LDS operations
-// complete in order, so the compiler's own counted waits stay correct: unknown younger operations only make them longer.)
-template <int OFF>
-__device__ __forceinline__ s4v tr_read_asm(unsigned addr) {
-    s4v v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-    return v;
-}
-__device__ __forceinline__ void tr_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ float max_halves(float x) {   // max over lanes l and l ^ 32 (v_permlane32_swap: no LDS round trip)
-    float a = x, c = x;
-    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(c));
-    return fmaxf(a, c);
-}
-}  // namespace
-
-// ABL (probes build only): ablations for timing — 1 no softmax pieces inside the regions, 2 no Vᵀ·Pᵀ MFMAs, 4 no K·Qᵀ MFMAs,
-// 8 no V fragment reads, 32 no K fragment reads (results are then meaningless)
-template <bool STASH, int ABL = 0>
-__global__ __launch_bounds__(64 * PNW, 1) void attention_h3_pipe_kernel(const _Float16* __restrict__ qkv,
-                                                                    float* __restrict__ out,
-                                                                    _Float16* __restrict__ out_s,
-                                                                    int* __restrict__ range_flag,
-                                                                    float* __restrict__ row_stats, int S, int H,
-                                                                    float scale, int dbg_arg) {
-#ifdef CMDI_PROBES
-    const int dbg = dbg_arg;
-#else
-    constexpr int dbg = 0;
-#endif
-    constexpr int NW = PNW;
-    extern __shared__ __attribute__((aligned(16))) char lds[];  // [NKS K tiles | NVS V tiles]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int bh = blockIdx.x, b = bh / H, h = bh % H;
-    const int d_model = H * DH;
-    long long t0 = 0, t1 = 0, t2 = 0;
-    if (dbg & 16) t0 = __builtin_readcyclecounter();
-    const size_t ld = 6 * (size_t)d_model;     // halves per token row
-    const long qoff = 2 * h * DH, koff = 2 * (d_model + h * DH), voff = 2 * (2 * d_model + h * DH);
-    const _Float16* base = qkv + (size_t)b * S * ld;
-    const int q0 = wave * 64;
-    const bool active = q0 < S;                      // wave-uniform
-    const int nkb = (S + KBLK - 1) / KBLK;
-
-    // Q as the B operand of Sᵀ = K·Qᵀ: lane (query l31 of group g, k-group hi) holds dims 16 ks + 8 hi .. + 7
-    h8 qh[2][8], ql[2][8];
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        const int q = q0 + 32 * g + l31;
-        const _Float16* qp = base + (size_t)(q < S ? q : S - 1) * ld + qoff + 8 * hi;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const _Float16* pch = qp + (ks >> 1) * 64 + (ks & 1) * 16;
-            qh[g][ks] = *reinterpret_cast<const h8*>(pch);
-            ql[g][ks] = *reinterpret_cast<const h8*>(pch + 32);
-        }
-    }
-    // the vector side of the register file (256 of the 512) cannot hold all of Q next to the softmax's working set: the lo
-    // planes live in accumulation registers (an MFMA reads its A / B operands from either half)
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+a"(ql[g][ks]));
-    f32x16 o[2][4];  // Oᵀ: o[g][db][r] = O[q][32 db + (r&3) + 8 (r>>2) + 4 hi]
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[g][db][r] = 0.f;
-    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};   // m_run in log2 units
-    const float scale2 = scale * 1.4426950408889634f;
-
-    // LDS fragment addresses.  The slot swizzle is an XOR of a lane value with a constant that has only bits 1-3 set: EIGHT
-    // lane addresses per operand; ring slot, k-substep, plane and dim block are immediate offsets.
-    const char* kaddr[8];   // K fragment (ks, plane): slot t = 8 (ks >> 1) + 4 plane + 2 (ks & 1) + hi of row l31
-    unsigned vaddr[8];      // V transpose-read source as LDS byte addresses (see attention_h3_kernel for the lane mapping)
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
-    {
-        const int kv = kswz(l31) ^ hi;
-        const int G = lane >> 4, L = lane & 15;
-        const int v_kl = 4 * (G >> 1) + (L >> 2);
-        const int vv = (2 * (G & 1) + ((L & 3) >> 1)) ^ kswz(v_kl);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            kaddr[j] = lds + l31 * ROWB + (((2 * j) ^ kv) << 4);
-            vaddr[j] = lds0 + NKS * TILE + v_kl * ROWB + (((2 * j) ^ vv) << 4) + (L & 1) * 8;
-        }
-    }
-
-    // ---- K / V requests: 16 pieces of 1 KiB per tile, 4 per wave ------------------------------------------------
-    constexpr int PCS = 16 / NW;
-    const int uwave = __builtin_amdgcn_readfirstlane(wave);
-    unsigned k_off[PCS];
-#pragma unroll
-    for (int it = 0; it < PCS; ++it) {
-        const int g = it * NW + uwave;
-        const int kl = 2 * g + (lane >> 5);
-        const int t = (lane & 31) ^ kswz(kl);
-        k_off[it] = (unsigned)(((size_t)kl * ld + (size_t)koff + t * 8) * 2);
-    }
-    const unsigned row_bytes = (unsigned)(ld * 2);
-    const unsigned v_delta = (unsigned)((voff - koff) * 2);          // V sits d_model split columns behind K
-    const size_t n_seq = gridDim.x / H;
-    const size_t span = (n_seq - b) * (size_t)S * row_bytes;
-    const auto kv_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(base), 0,
-                                                           (int)(span < 0xffffffffull ? span : 0xffffffffull), 0x00020000);
-    auto stage_tile_kv = [&](char* tile, unsigned soff) __attribute__((always_inline)) {
-#pragma unroll
-        for (int it = 0; it < PCS; ++it)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(kv_rsrc, (__attribute__((address_space(3))) void*)(tile + (it * NW + uwave) * 1024),
-                                                     16, (int)k_off[it], (int)soff, 0, 0);
-    };
-    auto req_k = [&](int st) __attribute__((always_inline)) { if (st < nkb) { stage_tile_kv(lds + (st & 3) * TILE, st * KBLK * row_bytes); return PCS; } return 0; };
-    auto req_v = [&](int st) __attribute__((always_inline)) { if (st < nkb) { stage_tile_kv(lds + (NKS + (st & 3)) * TILE, st * KBLK * row_bytes + v_delta); return PCS; } return 0; };
-    // prologue: what intervals -3 .. -1 would have requested, K(0) first
-    req_k(0);
-    const int later = req_k(1) + req_v(0);
-    const int tail = req_k(2) + req_v(1);
-    wait_vmcnt_upto<4 * PCS>(later + tail);      // Q and K(0) are in
-    __builtin_amdgcn_s_barrier();
-    if (dbg & 16) t1 = __builtin_readcyclecounter();
-
-    f32x16 A0[2], A1[2];     // scores: A0 = K_hi·Q_hi, A1 = K_hi·Q_lo + K_lo·Q_hi
-    float s[2][16];
-    u4v phw[2][2], plw[2][2];   // p_hi / p_lo as MFMA operands, [group][16-key half], two f16 per word
-    if constexpr (ABL != 0) {
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) { phw[g][kk] = u4v{0, 0, 0, 0}; plw[g][kk] = u4v{0, 0, 0, 0}; }
-    }
-    float alpha[2] = {1.f, 1.f}, mloc[2] = {0.f, 0.f}, m_new[2] = {0.f, 0.f}, psum[2] = {0.f, 0.f};
-    bool moved[2] = {false, false};
-
-    auto kfrag = [&](int slot, int ks, int plane) __attribute__((always_inline)) {
-        const int bt = (ks >> 1) * 8 + (ks & 1) * 2 + plane * 4;
-        return *reinterpret_cast<const h8*>(kaddr[(bt & 14) >> 1] + slot * TILE + (bt & 16) * 16);
-    };
-    // the scores leave the accumulators at once (so the next stage's products can be issued into them)
-    auto combine = [&](int g, int kb, bool last) __attribute__((always_inline)) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float v = (A0[g][r] + A1[g][r] * kLoInv) * scale2;
-            if (last) {
-                const int key = kb * KBLK + mfma32_row(r, lane);
-                v = key < S ? v : -INFINITY;
-            }
-            asm("" : "+v"(v));   // opaque: ONE copy (otherwise the raw sums stay alive for fma(raw, scale, -max))
-            s[g][r] = v;
-        }
-    };
-    // The online softmax of s[g][] in 11 small pieces, so that it can be issued between MFMAs in a fixed order.  Every
-    // piece ends in an (empty) volatile asm on its results: sched_barrier only binds the machine scheduler, and without
-    // it the exponentials are sunk to their first use, behind the region they are meant to fill.
-    auto vpiece = [&](int g, int i) __attribute__((always_inline)) {
-        constexpr float LAZY = 8.0f;
-        if (i == 0) {
-            float m = s[g][0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) m = fmaxf(m, s[g][r]);
-            mloc[g] = max_halves(m);
-        } else if (i == 1) {
-            // lazy reference maximum (see attention_h3_kernel): it moves only when exceeded by more than 2^LAZY
-            moved[g] = mloc[g] > m_run[g] + LAZY;                  // first block: m_run = -inf
-            m_new[g] = moved[g] ? mloc[g] : m_run[g];
-            alpha[g] = __builtin_amdgcn_exp2f(m_run[g] - m_new[g]);   // 1 where nothing moved, 0 on the first block
-            l_run[g] *= alpha[g];
-            m_run[g] = m_new[g];
-            psum[g] = 0.f;
-            asm volatile("" : "+v"(alpha[g]), "+v"(m_new[g]));
-        } else if (i < 10) {
-            const int r = 2 * (i - 2);
-            const float p0 = __builtin_amdgcn_exp2f(s[g][r] - m_new[g]);       // masked keys: 2^-inf = 0
-            const float p1 = __builtin_amdgcn_exp2f(s[g][r + 1] - m_new[g]);
-            psum[g] += p0 + p1;
-            h2 a2, l2;
-            a2[0] = (_Float16)p0; a2[1] = (_Float16)p1;
-            l2[0] = (_Float16)(p0 - (float)a2[0]); l2[1] = (_Float16)(p1 - (float)a2[1]);
-            unsigned aw = __builtin_bit_cast(unsigned, a2), lw = __builtin_bit_cast(unsigned, l2);
-            asm volatile("" : "+v"(aw), "+v"(lw), "+v"(psum[g]));
-            phw[g][r >> 3][(r & 7) >> 1] = aw;
-            plw[g][r >> 3][(r & 7) >> 1] = lw;
-        } else if (i == 10) {
-            l_run[g] += psum[g];
-        }
-    };
-    constexpr int NPIECE = 11;
-    // (rare after the first stages.  Written against the accumulation registers directly: as plain C++ the multiply wants
-    // its operands in vector registers and the register allocator then copies all 128 accumulator values across at the
-    // top of EVERY stage, and keeps 128 vector registers for them)
-    auto rescale = [&](int g) __attribute__((always_inline)) {
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float e = o[g][db][r], tmp;
-                asm volatile("v_accvgpr_read_b32 %0, %1\n\tv_mul_f32 %0, %0, %2\n\ts_nop 0\n\tv_accvgpr_write_b32 %1, %0"
-                             : "=&v"(tmp), "+a"(e) : "v"(alpha[g]));
-                o[g][db][r] = e;
-            }
-    };
-    // scores of the stage in ring slot `slot`, both groups (plain: prologue only)
-    auto scores_plain = [&](int slot) __attribute__((always_inline)) {
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { A0[g][r] = 0.f; A1[g][r] = 0.f; }
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const h8 kh = kfrag(slot, ks, 0), kl = kfrag(slot, ks, 1);
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                A0[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[g][ks], A0[g], 0, 0, 0);
-                A1[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[g][ks], A1[g], 0, 0, 0);
-                A1[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[g][ks], A1[g], 0, 0, 0);
-            }
-        }
-    };
-#define CMDI_SB() __builtin_amdgcn_sched_barrier(0)
-    // region 1: K·Qᵀ of the stage in `slot` for both groups; a softmax piece of group 0 (then pieces 0-1 of group 1) behind
-    // every second MFMA
-    auto region1 = [&](auto slot_c) __attribute__((always_inline)) {
-        constexpr int slot = decltype(slot_c)::value;
-        f32x16 z;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) z[r] = 0.f;
-        h8 kh = qh[0][0], kl = qh[0][1], nh = kh, nl = kl;
-        if constexpr (!(ABL & 32)) { kh = kfrag(slot, 0, 0); kl = kfrag(slot, 0, 1); }
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            if constexpr (!(ABL & 32)) if (ks < 7) { nh = kfrag(slot, ks + 1, 0); nl = kfrag(slot, ks + 1, 1); }
-            // six MFMAs, three piece positions: pieces 3 ks .. 3 ks + 2 of the sequence [g0: 0..10 | g1: 0, 1]
-            auto piece = [&](int j) __attribute__((always_inline)) {
-                const int i = 3 * ks + j;
-                if constexpr (ABL & 1) return;
-                if (i < NPIECE) vpiece(0, i); else if (i < NPIECE + 2) vpiece(1, i - NPIECE);
-            };
-            if constexpr (!(ABL & 4)) {
-            A0[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[0][ks], ks == 0 ? z : A0[0], 0, 0, 0);
-            A0[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[1][ks], ks == 0 ? z : A0[1], 0, 0, 0);
-            }
-            CMDI_SB(); piece(0); CMDI_SB();
-            // (the B operand straight from the accumulation registers: the compiler's own MFMAs only take vector registers)
-            if constexpr (ABL & 4) {
-            } else if (ks == 0) {
-                asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=a"(A1[0]) : "v"(kh), "a"(ql[0][ks]));
-                asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=a"(A1[1]) : "v"(kh), "a"(ql[1][ks]));
-            } else {
-                asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(A1[0]) : "v"(kh), "a"(ql[0][ks]));
-                asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(A1[1]) : "v"(kh), "a"(ql[1][ks]));
-            }
-            CMDI_SB(); piece(1); CMDI_SB();
-            if constexpr (!(ABL & 4)) {
-            A1[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[0][ks], A1[0], 0, 0, 0);
-            A1[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[1][ks], A1[1], 0, 0, 0);
-            }
-            CMDI_SB(); piece(2); CMDI_SB();
-            kh = nh; kl = nl;
-        }
-    };
-    // Oᵀ += Vᵀ · Pᵀ of group g from ring slot `slot`; OTHER >= 0: softmax pieces 2.. of group OTHER behind the MFMAs
-    auto pv = [&](auto slot_c, auto g_c, auto other_c) __attribute__((always_inline)) {
-        constexpr int slot = decltype(slot_c)::value, g = decltype(g_c)::value, other = decltype(other_c)::value;
-        // fragments of step (kk, dp): dim blocks 2 dp, 2 dp + 1, hi and lo planes, keys k0 = 16 kk + v_kl and k0 + 8 (their
-        // swizzles differ by 2); slot index = db * 8 + plane * 4 + lane part
-        s4v f[2][8];
-        auto fetch = [&](auto step_c, s4v (&d)[8]) __attribute__((always_inline)) {
-            constexpr int step = decltype(step_c)::value, kk = step >> 1, dp = step & 1;
-            constexpr int imm0 = slot * TILE + kk * 16 * ROWB + ((2 * dp) >> 1) * 256;       // db = 2 dp: ch = 0
-            constexpr int imm1 = slot * TILE + kk * 16 * ROWB + ((2 * dp + 1) >> 1) * 256;   // db = 2 dp + 1: ch = 8
-            d[0] = tr_read_asm<imm0>(vaddr[0]);              d[1] = tr_read_asm<imm0 + 8 * ROWB>(vaddr[1]);   // vh[0]: ch = 0, ch ^ 2
-            d[2] = tr_read_asm<imm0>(vaddr[2]);              d[3] = tr_read_asm<imm0 + 8 * ROWB>(vaddr[3]);   // vl[0]: cl = 4, cl ^ 2 = 6
-            d[4] = tr_read_asm<imm1>(vaddr[4]);              d[5] = tr_read_asm<imm1 + 8 * ROWB>(vaddr[5]);   // vh[1]: ch = 8, 10
-            d[6] = tr_read_asm<imm1>(vaddr[6]);              d[7] = tr_read_asm<imm1 + 8 * ROWB>(vaddr[7]);   // vl[1]: cl = 12, 14
-        };
-        auto frag = [&](const s4v (&d)[8], int i) __attribute__((always_inline)) {
-            return __builtin_bit_cast(h8, (s8v)__builtin_shufflevector(d[2 * i], d[2 * i + 1], 0, 1, 2, 3, 4, 5, 6, 7));
-        };
-        int nxt = 2;
-        if constexpr (ABL & 8) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { f[0][i] = s4v{0, 0, 0, 0}; f[1][i] = s4v{0, 0, 0, 0}; }
-        } else {
-            fetch(std::integral_constant<int, 0>{}, f[0]);
-        }
-        auto step = [&](auto step_c) __attribute__((always_inline)) {
-            constexpr int st = decltype(step_c)::value, kk = st >> 1, dp = st & 1, cur = st & 1;
-            if constexpr (!(ABL & 8)) tr_wait();                             // this step's fragments are in
-            if constexpr (st < 3 && !(ABL & 8)) fetch(std::integral_constant<int, st + 1>{}, f[cur ^ 1]);   // next step's under this step's MFMAs
-            CMDI_SB();
-            const h8 phv = __builtin_bit_cast(h8, phw[g][kk]), plv = __builtin_bit_cast(h8, plw[g][kk]);
-            const h8 ps = phv * (_Float16)kLoInv;   // packed f16 multiply: exact (power of two) above 2^-14
-            const h8 vh[2] = {frag(f[cur], 0), frag(f[cur], 2)}, vl[2] = {frag(f[cur], 1), frag(f[cur], 3)};
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const int d2 = j & 1, db = 2 * dp + d2;
-                const h8 av = j < 4 ? vh[d2] : vl[d2];
-                const h8 bv = j < 2 ? phv : (j < 4 ? plv : ps);
-                if constexpr (!(ABL & 2)) o[g][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, o[g][db], 0, 0, 0);
-                if constexpr (other >= 0 && !(ABL & 1)) {
-                    if (j & 1) {            // a piece of the other group's softmax behind every second MFMA
-                        CMDI_SB();
-                        if (nxt < NPIECE) vpiece(other, nxt);
-                        ++nxt;
-                        CMDI_SB();
-                    }
-                }
-            }
-            CMDI_SB();
-        };
-        step(std::integral_constant<int, 0>{});
-        step(std::integral_constant<int, 1>{});
-        step(std::integral_constant<int, 2>{});
-        step(std::integral_constant<int, 3>{});
-    };
-
-    if (!active) {
-        // waves without queries (S <= 192) only request their share of K / V and keep the barriers; kept apart from the
-        // compute path so that no accumulator is live across a conditional there
-        wait_vmcnt_upto<2 * PCS>(tail);
-        __builtin_amdgcn_s_barrier();
-        for (int kb = 0; kb < nkb; ++kb) {
-            const int now = req_k(kb + 3) + req_v(kb + 2);
-            wait_vmcnt_upto<2 * PCS>(now);
-            __builtin_amdgcn_s_barrier();
-        }
-        // (attn_write_out's barrier)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_s_barrier();
-        return;
-    }
-    scores_plain(0);
-    wait_vmcnt_upto<2 * PCS>(tail);              // K(1), V(0) are in
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
-    // one barrier interval (kb & 3 == slot): requests of K(kb+3) / V(kb+2), the three regions, then everything requested
-    // BEFORE this interval has to be in
-    auto interval = [&](auto slot_c, auto last_c, int kb) __attribute__((always_inline)) {
-        constexpr int slot = decltype(slot_c)::value;
-        constexpr bool last = decltype(last_c)::value;
-        const int now = req_k(kb + 3) + req_v(kb + 2);
-        {
-            combine(0, kb, last);
-            combine(1, kb, last);
-            CMDI_SB();
-            if constexpr (!last) {
-                region1(std::integral_constant<int, (slot + 1) & 3>{});
-            } else {
-#pragma unroll
-                for (int i = 0; i < NPIECE; ++i) vpiece(0, i);
-                vpiece(1, 0);
-                vpiece(1, 1);
-            }
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(moved[0]) != 0, 0)) rescale(0);   // cold: after the first stages almost never
-            pv(slot_c, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(moved[1]) != 0, 0)) rescale(1);
-            pv(slot_c, std::integral_constant<int, 1>{}, std::integral_constant<int, -1>{});
-        }
-        wait_vmcnt_upto<2 * PCS>(now);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    };
-    // all stages but the last run the full interval (the score accumulators are ALWAYS redefined inside the loop: a
-    // conditional region would cost a second register set and 64 copies per stage); the last one is peeled
-    {
-        using F = std::false_type;
-        int kb = 0;
-        while (true) {
-            if (kb >= nkb - 1) break;
-            interval(std::integral_constant<int, 0>{}, F{}, kb); ++kb;
-            if (kb >= nkb - 1) break;
-            interval(std::integral_constant<int, 1>{}, F{}, kb); ++kb;
-            if (kb >= nkb - 1) break;
-            interval(std::integral_constant<int, 2>{}, F{}, kb); ++kb;
-            if (kb >= nkb - 1) break;
-            interval(std::integral_constant<int, 3>{}, F{}, kb); ++kb;
-        }
-        using T = std::true_type;
-        switch (kb & 3) {
-            case 0: interval(std::integral_constant<int, 0>{}, T{}, kb); break;
-            case 1: interval(std::integral_constant<int, 1>{}, T{}, kb); break;
-            case 2: interval(std::integral_constant<int, 2>{}, T{}, kb); break;
-            default: interval(std::integral_constant<int, 3>{}, T{}, kb); break;
-        }
-    }
-#undef CMDI_SB
-
-    if (dbg & 16) t2 = __builtin_readcyclecounter();
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-        attn_write_out<STASH>(lds, o[g], l_run[g], m_run[g], out, out_s, range_flag, row_stats, S, d_model, b, h, bh,
-                              q0 + 32 * g, 2 * wave + g, lane, q0 + 32 * g < S);
-    if constexpr (!STASH) {
-        if ((dbg & 16) && row_stats && tid == 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            long long* st = reinterpret_cast<long long*>(row_stats) + (size_t)blockIdx.x * 4;
-            st[0] = t1 - t0; st[1] = t2 - t1; st[2] = __builtin_readcyclecounter() - t2; st[3] = 0;
         }
     }
 }
@@ -1263,7 +796,7 @@ hipError_t launch_attention_bwd_h3(const _Float16* qkv_split, const float* o_fwd
     return hipGetLastError();
 }
 
-template <int NW, int NS, int STAG = 0, bool TRASM = false>
+template <int NW, int NS, int STAG = 0>
 static hipError_t launch_attention_h3_cfg(const _Float16* qkv_split, float* out, _Float16* out_split, int* range_flag,
                                           float* row_stats, int n_seq, int S, int H, int dbg, long head_rows,
                                           hipStream_t stream) {
@@ -1273,58 +806,20 @@ static hipError_t launch_attention_h3_cfg(const _Float16* qkv_split, float* out,
     constexpr size_t lds = lds_ring > lds_epi ? lds_ring : lds_epi;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_h3_kernel<true, NW, NS, STAG, TRASM>),
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_h3_kernel<true, NW, NS, STAG>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_h3_kernel<false, NW, NS, STAG, TRASM>),
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_h3_kernel<false, NW, NS, STAG>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e1 != hipSuccess) return e1;
         if (e2 != hipSuccess) return e2;
         attr_done = true;
     }
     if (row_stats && !(dbg & 16))
-        hipLaunchKernelGGL((attention_h3_kernel<true, NW, NS, STAG, TRASM>), grid, dim3(64 * NW), lds, stream, qkv_split,
+        hipLaunchKernelGGL((attention_h3_kernel<true, NW, NS, STAG>), grid, dim3(64 * NW), lds, stream, qkv_split,
                            out, out_split, range_flag, row_stats, S, H, scale, dbg, head_rows);
     else
-        hipLaunchKernelGGL((attention_h3_kernel<false, NW, NS, STAG, TRASM>), grid, dim3(64 * NW), lds, stream, qkv_split,
+        hipLaunchKernelGGL((attention_h3_kernel<false, NW, NS, STAG>), grid, dim3(64 * NW), lds, stream, qkv_split,
                            out, out_split, range_flag, row_stats, S, H, scale, dbg, head_rows);
-    return hipGetLastError();
-}
-
-static hipError_t launch_attention_h3_pipe(const _Float16* qkv_split, float* out, _Float16* out_split, int* range_flag,
-                                           float* row_stats, int n_seq, int S, int H, int dbg, hipStream_t stream) {
-    dim3 grid(n_seq * H);
-    const float scale = 1.0f / sqrtf((float)DH);
-    constexpr size_t lds_ring = (size_t)(NKS + NVS) * TILE, lds_epi = (size_t)2 * PNW * 32 * 528;
-    constexpr size_t lds = lds_ring > lds_epi ? lds_ring : lds_epi;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_h3_pipe_kernel<true>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_h3_pipe_kernel<false>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e1 != hipSuccess) return e1;
-        if (e2 != hipSuccess) return e2;
-        attr_done = true;
-    }
-#ifdef CMDI_PROBES
-#define CMDI_PIPE_ABL(A)                                                                                                  \
-    if ((dbg & 47) == (A)) {                                                                                             \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attention_h3_pipe_kernel<false, (A)>),                         \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                       \
-        hipLaunchKernelGGL((attention_h3_pipe_kernel<false, (A)>), grid, dim3(64 * PNW), lds, stream, qkv_split, out,    \
-                           out_split, range_flag, row_stats, S, H, scale, dbg);                                          \
-        return hipGetLastError();                                                                                        \
-    }
-    CMDI_PIPE_ABL(1) CMDI_PIPE_ABL(2) CMDI_PIPE_ABL(4) CMDI_PIPE_ABL(6) CMDI_PIPE_ABL(7) CMDI_PIPE_ABL(8) CMDI_PIPE_ABL(32)
-    CMDI_PIPE_ABL(40) CMDI_PIPE_ABL(47)
-#undef CMDI_PIPE_ABL
-#endif
-    if (row_stats && !(dbg & 16))
-        hipLaunchKernelGGL((attention_h3_pipe_kernel<true>), grid, dim3(64 * PNW), lds, stream, qkv_split, out, out_split,
-                           range_flag, row_stats, S, H, scale, dbg);
-    else
-        hipLaunchKernelGGL((attention_h3_pipe_kernel<false>), grid, dim3(64 * PNW), lds, stream, qkv_split, out, out_split,
-                           range_flag, row_stats, S, H, scale, dbg);
     return hipGetLastError();
 }
 
@@ -1339,10 +834,6 @@ hipError_t launch_attention_h3(const _Float16* qkv_split, float* out, _Float16* 
 #else
     constexpr int dbg = 0;
 #endif
-    // CMDI_ATTN_PIPE = 1: the software-pipelined 64-queries-per-wave kernel
-    static const int pipe = std::getenv("CMDI_ATTN_PIPE") ? std::atoi(std::getenv("CMDI_ATTN_PIPE")) : kAttnPipeDefault;
-    if (pipe && !head_major && S <= 256)
-        return launch_attention_h3_pipe(qkv_split, out, out_split, range_flag, row_stats, n_seq, S, H, dbg, stream);
     // schedule: CMDI_ATTN_SPLIT = 1 -> two 4-wave blocks per (sequence, head), two blocks per CU; 0 -> one 8-wave block
     static const int split = std::getenv("CMDI_ATTN_SPLIT") ? std::atoi(std::getenv("CMDI_ATTN_SPLIT")) : kAttnSplitDefault;
     if (split && S > 128)
@@ -1354,9 +845,6 @@ hipError_t launch_attention_h3(const _Float16* qkv_split, float* out, _Float16* 
     if (stag == 2)
         return launch_attention_h3_cfg<NWAVE, NSTG, 2>(qkv_split, out, out_split, range_flag, row_stats, n_seq, S, H, dbg, head_rows, stream);
 #endif
-    static const int trasm = std::getenv("CMDI_ATTN_TRASM") ? std::atoi(std::getenv("CMDI_ATTN_TRASM")) : kAttnTrAsmDefault;
-    if (trasm)
-        return launch_attention_h3_cfg<NWAVE, NSTG, kAttnStagDefault, true>(qkv_split, out, out_split, range_flag, row_stats, n_seq, S, H, dbg, head_rows, stream);
     return launch_attention_h3_cfg<NWAVE, NSTG, kAttnStagDefault>(qkv_split, out, out_split, range_flag, row_stats, n_seq, S, H, dbg, head_rows, stream);
 }
 
