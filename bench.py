@@ -49,6 +49,7 @@ sub = lambda n: importlib.import_module(f"{PKG}.{n}")
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 F16_MFMA_PEAK_TFLOPS = 2500.0   # same guide: dense f16/bf16 MFMA (v_mfma_f32_32x32x16_f16)
+HBM_PEAK_GBPS = 8000.0          # same guide: HBM3E
 N_FEATS, T_FRAMES = 263, 196
 CONFIGS = {
     # name: (batch per GPU, respacing, sampler, cfg, edit)
@@ -375,8 +376,11 @@ def roofline_attention(eng, run_loop):
             "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "launches": launches,
             "avg_launch_us": avg_s * 1e6, "flops_per_launch": flop,
             "algorithmic_bytes": 4.0 * nseq * S * 4 * H * d_head,       # q, k, v in + o out, 4 bytes per value
-            "note": "per key stage a wave pays MFMA issue + LDS fragment reads + softmax VALU nearly in series (DESIGN.md 3): "
-                    "the kernel is bound by its own instruction stream, not by the pipe's peak and not by HBM"}
+            "hbm_frac": 4.0 * nseq * S * 4 * H * d_head / avg_s / 1e9 / HBM_PEAK_GBPS,
+            "note": "one block per (sequence, head) and CU: a load burst (Q + first K/V stages), the key loop, a store burst, entered "
+                    "by all CUs together; with every MFMA / softmax / LDS read removed the same kernel takes 22.5 us at 64 "
+                    "sequences (its memory floor, profiles/r03_attention_pipe_experiment.txt); the arithmetic of the key loop "
+                    "comes on top because 8 waves x 256 registers leave no room for a second work item per CU (DESIGN.md 3)"}
 
 
 def job_layout(cfg: dict, world: int, rank: int, shard_bounds) -> dict:
