@@ -231,7 +231,11 @@ def test_f16x3_range_guard():
         model.seqTransEncoder.layers[0].linear1.weight[3, 7] = 7e4
     with pytest.raises(N.RangeError, match="f16 range"):
         model.engine(torch.device(DEV), max_batch=2, max_frames=20)
-    x, t = torch.randn(2, 263, 1, 20, device=DEV), torch.tensor([5, 9], device=DEV)
+    # seeded input: a 7e4 weight amplifies the fp32 rounding of one token feature by 7e4 in front of a GELU, so an unlucky
+    # draw (that pre-activation near 0 for some token) moves single outputs by 1e-3 relative in ANY fp32 implementation
+    # (3.6e-5 rel-L2 seen once in round 3 with an unseeded draw; seeds 0-7: 5.8e-7 ... 6.4e-7 in all three modes)
+    x = torch.randn(2, 263, 1, 20, generator=torch.Generator().manual_seed(0)).to(DEV)
+    t = torch.tensor([5, 9], device=DEV)
     sd2 = dict(sd)
     sd2["seqTransEncoder.layers.0.linear1.weight"] = sd["seqTransEncoder.layers.0.linear1.weight"].copy()
     sd2["seqTransEncoder.layers.0.linear1.weight"][3, 7] = 7e4
