@@ -17,6 +17,8 @@ _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "csrc" / "libcondmdi_hip.so"
 if __import__("os").environ.get("CMDI_PROBES_LIB") == "1":   # tools/ only: the instrumented build (build.py --probes)
     LIB_PATH = _PKG / "csrc" / "libcondmdi_hip_probes.so"
+if __import__("os").environ.get("CMDI_LIB_VARIANT"):        # tools/ only: experiment builds (tools/st_policy_build.sh)
+    LIB_PATH = _PKG / "csrc" / ("libcondmdi_hip_" + __import__("os").environ["CMDI_LIB_VARIANT"] + ".so")
 
 CMDI_MEAN_START_X, CMDI_MEAN_EPSILON = 0, 1
 CMDI_SAMPLER_DDPM, CMDI_SAMPLER_DDIM = 0, 1

@@ -56,6 +56,44 @@ __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
     lo = (_Float16)((x - (float)hi) * kLoScale);
 }
 
+// Output stores carry `sc1` (device scope: written through the XCD's L2 instead of parked there as dirty lines).  The
+// outputs of these GEMMs (26-78 MB) are never re-read by the kernel that writes them, and as dirty L2 lines they evict the
+// weight panel every block of that XCD re-reads: measured at C2 (in-run counters of the in_proj GEMM) 187 -> 162 MB of L2
+// misses + write-backs per launch (1.76 -> 1.52 x the algorithmic bytes), kernel -1 %, step -0.6 ... -2.8 % by box.
+// `nt` stores are 16 % slower, `sc0 sc1` and `nt` operand requests slower still (profiles/r03_store_policy.txt).
+// The persistent kernel (gemm_h3_epi.hpp) keeps plain stores: there sc1 costs 2 % (in_proj at B=256: 530 vs 520 us), and on
+// the attention kernel's output rows it is neutral.  CMDI_OUT_SC1=0 (experiment builds, tools/st_policy_build.sh) restores
+// plain stores here too.
+// (Inline asm, because no builtin carries the scope bit on a 128-bit store.  The compiler's hazard recognizer does not look
+// inside: a store of more than 8 bytes must not be followed at once by a VALU write of its data registers — it reads them
+// a cycle late — hence the s_nop behind the dwordx4 form.  Found the hard way: with sc1 stores in the
+// persistent kernel's epilogue its split rows came out wrong until the s_nop was there.)
+#ifndef CMDI_OUT_SC1
+#define CMDI_OUT_SC1 1
+#endif
+#ifndef CMDI_A_AUX
+#define CMDI_A_AUX 0     // cache policy bits of the A / W requests (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
+#endif
+#ifndef CMDI_W_AUX
+#define CMDI_W_AUX 0
+#endif
+typedef float f4v_ __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void h3_store_f4(float* dst, float4 v) {
+#if CMDI_OUT_SC1
+    const f4v_ t = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(t) : "memory");
+#else
+    *reinterpret_cast<float4*>(dst) = v;
+#endif
+}
+__device__ __forceinline__ void h3_store_h4(_Float16* dst, h4 v) {
+#if CMDI_OUT_SC1
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+#else
+    *reinterpret_cast<h4*>(dst) = v;
+#endif
+}
+
 }  // namespace cmdi
 #include "gemm_h3_epi.hpp"
 namespace cmdi {
@@ -183,8 +221,8 @@ __device__ __forceinline__ void h3_epilogue(const H3Params& p, f32x16 (&acc0)[TC
                     overflow |= !(fabsf(y[e]) < 65504.0f);
                 }
                 _Float16* dst = p.Cs + (size_t)m * (2 * BN) + split_pos(n);
-                *reinterpret_cast<h4*>(dst) = oh;
-                *reinterpret_cast<h4*>(dst + 32) = ol;
+                h3_store_h4(dst, oh);
+                h3_store_h4(dst + 32, ol);
             }
         }
         if (overflow && p.range_flag) atomicOr(p.range_flag, 1);
@@ -392,7 +430,7 @@ __device__ __forceinline__ void h3_epilogue(const H3Params& p, f32x16 (&acc0)[TC
                             } else {
                                 v[0] += rr[it].x; v[1] += rr[it].y; v[2] += rr[it].z; v[3] += rr[it].w;
                             }
-                            if (p.C) *reinterpret_cast<float4*>(p.C + off) = make_float4(v[0], v[1], v[2], v[3]);
+                            if (p.C) h3_store_f4(p.C + off, make_float4(v[0], v[1], v[2], v[3]));
                         }
                         if constexpr (EPI == H3_GELUGRAD_SPLIT) {
                             v[0] *= gelu_erf_grad(rr[it].x); v[1] *= gelu_erf_grad(rr[it].y);
@@ -417,8 +455,8 @@ __device__ __forceinline__ void h3_epilogue(const H3Params& p, f32x16 (&acc0)[TC
                             if constexpr (EPI == H3_PLAIN_SPLIT) {
                                 if (p.cs_head_major) dst = p.Cs + ((size_t)(n >> 7) * M + m) * 256 + split_pos(n & 127);
                             }
-                            *reinterpret_cast<h4*>(dst) = oh;
-                            *reinterpret_cast<h4*>(dst + 32) = ol;
+                            h3_store_h4(dst, oh);
+                            h3_store_h4(dst + 32, ol);
                         }
                         if constexpr (EPI == H3_RESID) {
                             if (p.out_part) {
@@ -472,12 +510,12 @@ __device__ __forceinline__ void h3_epilogue(const H3Params& p, f32x16 (&acc0)[TC
                         overflow |= !(fabsf(v[e]) < 65504.0f);
                     }
                     _Float16* dst = p.Cs + ((size_t)b * p.tok_S + 1 + fr) * (2 * p.N) + npos;
-                    *reinterpret_cast<h4*>(dst) = oh;
-                    *reinterpret_cast<h4*>(dst + 32) = ol;
+                    h3_store_h4(dst, oh);
+                    h3_store_h4(dst + 32, ol);
                     if (p.tok_dup) {
                         dst += (size_t)p.tok_dup * p.tok_S * (2 * p.N);
-                        *reinterpret_cast<h4*>(dst) = oh;
-                        *reinterpret_cast<h4*>(dst + 32) = ol;
+                        h3_store_h4(dst, oh);
+                        h3_store_h4(dst + 32, ol);
                     }
                     continue;
                 }
@@ -502,7 +540,7 @@ __device__ __forceinline__ void h3_epilogue(const H3Params& p, f32x16 (&acc0)[TC
                         const float4 rr = *reinterpret_cast<const float4*>(p.R + (p.r_ld ? (size_t)m * p.r_ld + n : off));
                         v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
                     }
-                    if (p.C) *reinterpret_cast<float4*>(p.C + off) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (p.C) h3_store_f4(p.C + off, make_float4(v[0], v[1], v[2], v[3]));
                     if (p.Cs) {
                         h4 oh, ol;
 #pragma unroll
@@ -513,8 +551,8 @@ __device__ __forceinline__ void h3_epilogue(const H3Params& p, f32x16 (&acc0)[TC
                             overflow |= !(fabsf(v[e]) < 65504.0f);
                         }
                         _Float16* dst = p.Cs + (size_t)m * (p.cs_ld ? p.cs_ld : 2 * p.N) + npos;
-                        *reinterpret_cast<h4*>(dst) = oh;
-                        *reinterpret_cast<h4*>(dst + 32) = ol;
+                        h3_store_h4(dst, oh);
+                        h3_store_h4(dst + 32, ol);
                     }
                 } else if constexpr (EPI == H3_RESID) {
                     if (p.Rs) {
@@ -535,7 +573,7 @@ __device__ __forceinline__ void h3_epilogue(const H3Params& p, f32x16 (&acc0)[TC
                         const float4 rr = *reinterpret_cast<const float4*>(p.R + (p.r_ld ? (size_t)m * p.r_ld + n : off));
                         v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
                     }
-                    if (p.C) *reinterpret_cast<float4*>(p.C + off) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (p.C) h3_store_f4(p.C + off, make_float4(v[0], v[1], v[2], v[3]));
                     if (p.Cs) {
                         h4 oh, ol;
 #pragma unroll
@@ -546,8 +584,8 @@ __device__ __forceinline__ void h3_epilogue(const H3Params& p, f32x16 (&acc0)[TC
                             overflow |= !(fabsf(v[e]) < 65504.0f);
                         }
                         _Float16* dst = p.Cs + (size_t)m * (p.cs_ld ? p.cs_ld : 2 * p.N) + npos;
-                        *reinterpret_cast<h4*>(dst) = oh;
-                        *reinterpret_cast<h4*>(dst + 32) = ol;
+                        h3_store_h4(dst, oh);
+                        h3_store_h4(dst + 32, ol);
                     }
                     if (p.out_part) {
                         // partial LayerNorm statistics of the row just written, over this lane group's 32 columns (8 lanes
@@ -587,8 +625,8 @@ __device__ __forceinline__ void h3_epilogue(const H3Params& p, f32x16 (&acc0)[TC
                     if constexpr (EPI == H3_PLAIN_SPLIT) {
                         if (p.cs_head_major) dst = p.Cs + ((size_t)(n >> 7) * M + m) * 256 + split_pos(n & 127);
                     }
-                    *reinterpret_cast<h4*>(dst) = oh;
-                    *reinterpret_cast<h4*>(dst + 32) = ol;
+                    h3_store_h4(dst, oh);
+                    h3_store_h4(dst + 32, ol);
                 }
             }
         }
@@ -671,11 +709,11 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
 #pragma unroll
         for (int q = 0; q < BM / 8 / NW; ++q)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(stage + (q * NW + wave) * 1024),
-                                                     16, (int)a_voff[q], a_soff, 0, 0);
+                                                     16, (int)a_voff[q], a_soff, 0, CMDI_A_AUX);
 #pragma unroll
         for (int q = 0; q < BN / 8 / NW; ++q)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(stage + BM * 128 + (q * NW + wave) * 1024),
-                                                     16, (int)w_voff[q], kt * 128, 0, 0);
+                                                     16, (int)w_voff[q], kt * 128, 0, CMDI_W_AUX);
     };
 
     const int swz = (l31 >> 1) & 7;
