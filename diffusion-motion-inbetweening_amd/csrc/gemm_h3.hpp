@@ -71,6 +71,10 @@ __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
 #ifndef CMDI_OUT_SC1
 #define CMDI_OUT_SC1 1
 #endif
+#ifndef CMDI_H3_SETPRIO
+#define CMDI_H3_SETPRIO 1   // wave priority during the fragment reads + products of a K step (in_proj 75.7 -> 74.5 us: the waves
+                            // in their product phase issue ahead of the co-resident block's epilogue / request / wait phases)
+#endif
 #ifndef CMDI_A_AUX
 #define CMDI_A_AUX 0     // cache policy bits of the A / W requests (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
 #endif
@@ -768,6 +772,9 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
         if (more && !(CMDI_DBG(p) & 1)) issue(kt + NSTAGE - 1, nxt);
         const char* st = lds + cur * STAGE;
         h8 ah[2][TM], al[2][TM], wh[2][TN], wl[2][TN];
+#if CMDI_H3_SETPRIO
+        __builtin_amdgcn_s_setprio(CMDI_H3_SETPRIO);
+#endif
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -808,6 +815,9 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 6 * TM * TN - 2 * (TM + TN), 0);
+#if CMDI_H3_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         // stage kt+1 must have landed (this wave's pieces; the barrier extends it to every wave's);
         // with 3 stages the pieces of stage kt+2, issued above, stay in flight across the barrier
         if (NSTAGE == 3 && more) wait_vmcnt<PW>(); else wait_vmcnt<0>();
