@@ -75,6 +75,9 @@ __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
 #define CMDI_H3_SETPRIO 1   // wave priority during the fragment reads + products of a K step (in_proj 75.7 -> 74.5 us: the waves
                             // in their product phase issue ahead of the co-resident block's epilogue / request / wait phases)
 #endif
+#ifndef CMDI_AUX_SC1
+#define CMDI_AUX_SC1 1    // the stashing forward's pre-activation rows (reconstruction guidance) as well
+#endif
 #ifndef CMDI_A_AUX
 #define CMDI_A_AUX 0     // cache policy bits of the A / W requests (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
 #endif
@@ -440,7 +443,11 @@ __device__ __forceinline__ void h3_epilogue(const H3Params& p, f32x16 (&acc0)[TC
                             v[0] *= gelu_erf_grad(rr[it].x); v[1] *= gelu_erf_grad(rr[it].y);
                             v[2] *= gelu_erf_grad(rr[it].z); v[3] *= gelu_erf_grad(rr[it].w);
                         } else if constexpr (EPI != H3_RESID) {
+#if CMDI_AUX_SC1
+                            if (p.aux) h3_store_f4(p.aux + off, make_float4(v[0], v[1], v[2], v[3]));
+#else
                             if (p.aux) *reinterpret_cast<float4*>(p.aux + off) = make_float4(v[0], v[1], v[2], v[3]);
+#endif
                         }
                         if constexpr (EPI == H3_GELU_SPLIT) {
 #pragma unroll
