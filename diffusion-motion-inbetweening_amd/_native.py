@@ -17,8 +17,11 @@ _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "csrc" / "libcondmdi_hip.so"
 if __import__("os").environ.get("CMDI_PROBES_LIB") == "1":   # tools/ only: the instrumented build (build.py --probes)
     LIB_PATH = _PKG / "csrc" / "libcondmdi_hip_probes.so"
-if __import__("os").environ.get("CMDI_LIB_VARIANT"):        # tools/ only: experiment builds (tools/st_policy_build.sh)
-    LIB_PATH = _PKG / "csrc" / ("libcondmdi_hip_" + __import__("os").environ["CMDI_LIB_VARIANT"] + ".so")
+if __import__("os").environ.get("CMDI_LIB_VARIANT"):        # tools/ only: experiment builds (tools/variant_build.sh)
+    _variant = __import__("os").environ["CMDI_LIB_VARIANT"]
+    if not __import__("re").fullmatch(r"[A-Za-z0-9_]+", _variant):   # a name, never a path
+        raise ValueError(f"CMDI_LIB_VARIANT must match [A-Za-z0-9_]+, got {_variant!r}")
+    LIB_PATH = _PKG / "csrc" / ("libcondmdi_hip_" + _variant + ".so")
 
 CMDI_MEAN_START_X, CMDI_MEAN_EPSILON = 0, 1
 CMDI_SAMPLER_DDPM, CMDI_SAMPLER_DDIM = 0, 1
@@ -96,6 +99,7 @@ SIGNATURES = {
     "cmdi_conv_rows_h3": (C.c_int, [_VP, _I32, _VP, _VP, _VP, _VP, _VP] + [_I32] * 12 + [_VP]),
     "cmdi_gemm_h3_ln": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _VP]),
     "cmdi_attention_fwd_h3": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _VP]),
+    "cmdi_attention_vjp_h3": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _VP]),
     "cmdi_precision": (C.c_int, [_VP]),
     "cmdi_range_status": (C.c_int, [_VP, C.POINTER(_I32), _VP]),
     "cmdi_range_clear": (C.c_int, [_VP, _VP]),

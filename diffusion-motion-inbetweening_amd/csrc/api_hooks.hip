@@ -123,10 +123,7 @@ int cmdi_range_clear(cmdi_handle e, cmdi_stream stream) {
     if (!e) return fail(CMDI_E_INVALID, "null handle");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (e->range_flag) HIPCHK(hipMemsetAsync(e->range_flag, 0, sizeof(int), s));
-    if (e->unet) {
-        int uf = 0;   // (the U-Net's flag is read-and-cleared in one call)
-        if (unet_range_flag(e->unet, &uf, s) != 0) return fail(CMDI_E_HIP, "UNET: range flag read-back failed");
-    }
+    if (e->unet && unet_range_clear(e->unet, s) != 0) return fail(CMDI_E_HIP, "UNET: range flag clear failed");
     return CMDI_OK;
 }
 
@@ -225,6 +222,34 @@ int cmdi_attention_fwd_h3(const void* d_qkv_split, float* d_out, int32_t n_seq, 
                                static_cast<hipStream_t>(stream)));
     return CMDI_OK;
 }
+
+int cmdi_attention_vjp_h3(const void* d_qkv_split, const float* d_dout, void* d_dqkv_split, float* d_work,
+                          int32_t n_seq, int32_t seq_len, int32_t n_heads, cmdi_stream stream) {
+    if (!d_qkv_split || !d_dout || !d_dqkv_split || !d_work || n_seq < 1 || seq_len < 1 || seq_len > 224 || n_heads < 1)
+        return fail(CMDI_E_INVALID, "bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t M = (size_t)n_seq * seq_len, d = (size_t)n_heads * 128, nhs = (size_t)n_seq * n_heads * seq_len;
+    float* o_fwd = d_work;                                  // [M, d]
+    _Float16* dout_s = reinterpret_cast<_Float16*>(o_fwd + M * d);   // [M, 2d] halves = M*d floats
+    float* row_stats = o_fwd + 2 * M * d;                   // [n_seq*H*S, 2]
+    float* rowdot = row_stats + 2 * nhs;                    // [n_seq*H*S]
+    const _Float16* qs = static_cast<const _Float16*>(d_qkv_split);
+    HIPCHK(launch_attention_h3(qs, o_fwd, nullptr, nullptr, row_stats, n_seq, seq_len, n_heads, s));
+    HIPCHK(launch_split_f16(d_dout, dout_s, (int64_t)M, (int)d, (int)d, nullptr, s));
+    HIPCHK(launch_attention_bwd_h3(qs, o_fwd, row_stats, d_dout, dout_s, static_cast<_Float16*>(d_dqkv_split), rowdot,
+                                   n_seq, seq_len, n_heads, s));
+    return CMDI_OK;
+}
+
+#ifdef CMDI_PROBES
+// probes library only (not in include/condmdi.h): cycle stamps of the attention backward kernels, [3][1024][24] int64
+int cmdi_probe_bwd_stamps(void* host_dst) {
+    if (!host_dst) return fail(CMDI_E_INVALID, "null");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(read_bwd_stamps(host_dst));
+    return CMDI_OK;
+}
+#endif
 
 void cmdi_philox4x32_10(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]) {
     philox4x32_10_host(counter, key, out);

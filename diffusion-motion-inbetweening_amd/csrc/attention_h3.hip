@@ -47,12 +47,15 @@ typedef short s8v __attribute__((ext_vector_type(8)));
 // 4 different 64-B quarters).
 __device__ __forceinline__ int kswz(int k) { return ((k & 3) << 2) | ((k >> 2) & 3); }
 
-// One 32-key stage of K and V by LDS-DMA: 32 pieces of 1 KiB (2 keys each), 32 / NW per wave.  Round 3: `buffer_load ... offen
-// lds` through a descriptor that starts at the sequence's first row and ENDS WITH THE LAUNCH'S LAST ROW — the lane's byte
-// offset inside a stage is a constant of the kernel (computed once, kv_lane_offset), the stage position is the scalar offset,
-// and keys past the sequence need no clamp: inside the tensor they are the next sequence's (finite) rows, past its end the
-// hardware returns zeros; their scores are masked by a select and their P is exactly 0.  (Rounds 1-2: flat global_load_lds,
-// ~15 vector instructions of address arithmetic and clamping per piece, inside the key loop.)
+// One 32-key stage of K and V by LDS-DMA: 32 pieces of 1 KiB (2 keys each), 32 / NW per wave: `buffer_load ... offen lds`
+// through a descriptor that starts at the sequence's first row and ENDS WITH THE SEQUENCE'S LAST ROW (token-major layout).
+// The lane's byte offset inside a stage is a constant of the kernel (kv_lane_offset); the stage position is ADDED TO THAT
+// VECTOR OFFSET (round 4, ADVICE r3: the scalar offset of a raw buffer access is excluded from the hardware's range check,
+// the vector offset is not), so rows past the sequence read as zeros whatever lies behind them in memory — a neighbouring
+// sequence's overflowed rows or a NaN pattern behind the tensor cannot reach the P·V product (0·NaN).  Their scores are
+// masked by a select and their P is exactly 0.  (Rounds 1-2: flat global_load_lds with per-piece clamping, ~15 vector
+// instructions per piece inside the key loop; one v_add per piece now.)  Head-major layout: the descriptor ends with the
+// last head's V matrix (rows of the next sequence are finite split rows there; past the tensor the hardware returns zeros).
 template <int NW = NWAVE>
 __device__ __forceinline__ unsigned kv_lane_offset(int it, size_t ld, long koff, long voff, int wave, int lane) {
     const int pc = it * NW + wave;               // 0..15 K pieces, 16..31 V pieces (2 keys each)
@@ -155,9 +158,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const _Float16
     const unsigned row_bytes = (unsigned)(ld * 2);
     // token-major: the descriptor ends with the last row of the launch's last sequence; head-major: with the V matrix of the
     // last head (operand matrices of head_rows rows each)
-    const size_t n_seq = gridDim.x / H;
     const size_t span = head_rows ? (size_t)3 * H * hm * 2 - (size_t)b * S * row_bytes
-                                  : (n_seq - b) * (size_t)S * row_bytes;
+                                  : (size_t)S * row_bytes;
     const auto kv_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(base), 0,
                                                            (int)(span < 0xffffffffull ? span : 0xffffffffull), 0x00020000);
     auto stage_kv = [&](char* stage, int key0) {
@@ -165,8 +167,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const _Float16
         for (int it = 0; it < PCS; ++it) {
             const int pc = it * NW + uwave;
             char* dst = stage + (pc >> 4) * TILE + (pc & 15) * 1024;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(kv_rsrc, (__attribute__((address_space(3))) void*)dst, 16, (int)kv_off[it],
-                                                     (int)(key0 * row_bytes), 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(kv_rsrc, (__attribute__((address_space(3))) void*)dst, 16,
+                                                     (int)(kv_off[it] + key0 * row_bytes), 0, 0, 0);
         }
     };
 #pragma unroll
@@ -386,6 +388,21 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const _Float16
 // (Kᵀ, Qᵀ, dOᵀ) come from row-major LDS tiles through ds_read_b64_tr_b16.  dS has no bound, so its products
 // use the scaled-lo split with two accumulators; P (in [0,1]) uses the single-accumulator form.
 // Register budget: one wave per SIMD (launch_bounds(256, 1)).
+#ifdef CMDI_PROBES
+// bench-only cycle stamps of the backward kernels (probes build; tools/attn_bwd_bench.py reads them through
+// cmdi_probe_bwd_stamps): [kernel][block][slot], written by thread 0 of a block
+__device__ long long g_bwd_stamps[3][1024][24];
+#define BWD_STAMP(kern, slot)                                                                                   \
+    do {                                                                                                        \
+        if (threadIdx.x == 0 && blockIdx.x < 1024) {                                                            \
+            asm volatile("" ::: "memory");                                                                      \
+            g_bwd_stamps[kern][blockIdx.x][slot] = (long long)__builtin_readcyclecounter();                     \
+        }                                                                                                       \
+    } while (0)
+#else
+#define BWD_STAMP(kern, slot) do { } while (0)
+#endif
+
 namespace {
 constexpr int BW = 4;   // waves per backward block
 
@@ -584,6 +601,7 @@ __global__ __launch_bounds__(64 * BW, 1) void attn_bwd_q_h3_kernel(const _Float1
     const int qc = q < S ? q : S - 1;
     const int nkt = (S + KBLK - 1) / KBLK;
 
+    BWD_STAMP(0, 0);
     h8 qh[8], ql[8], doh[8], dol[8];
     load_row_frags(qh, ql, base + (size_t)qc * ld + qoff, hi);
     load_row_frags(doh, dol, d_o + ((size_t)b * S + qc) * ldo + qoff, hi);
@@ -603,6 +621,7 @@ __global__ __launch_bounds__(64 * BW, 1) void attn_bwd_q_h3_kernel(const _Float1
     stage_tile(lds + TILE, base, ld, voff, 0, S, wave, lane);
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
+    BWD_STAMP(0, 1);
     for (int t = 0; t < nkt; ++t) {
         const int cur = t & 1;
         if (t + 1 < nkt) {
@@ -613,7 +632,9 @@ __global__ __launch_bounds__(64 * BW, 1) void attn_bwd_q_h3_kernel(const _Float1
             const char* kt = lds + cur * STAGE;
             const char* vt = kt + TILE;
             const f32x16 st = tile_dot_h3(kt, qh, ql, l31, hi);     // Sᵀ (unscaled): lane = query, regs = keys
+            if (t == 1) BWD_STAMP(0, 12);
             const f32x16 dpt = tile_dot_h3(vt, doh, dol, l31, hi);  // dPᵀ
+            if (t == 1) BWD_STAMP(0, 13);
             float ds[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -621,10 +642,13 @@ __global__ __launch_bounds__(64 * BW, 1) void attn_bwd_q_h3_kernel(const _Float1
                 const float p = (key < S && qok) ? __builtin_amdgcn_exp2f(st[r] * scale2 - mx) * inv : 0.f;
                 ds[r] = p * (dpt[r] - dsum) * scale;
             }
+            if (t == 1) BWD_STAMP(0, 14);
             acc_unbounded(dq0, dq1, ds, kt, troff);                 // dQᵀ += Kᵀ · dSᵀ
+            if (t == 1) BWD_STAMP(0, 15);
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();
+        BWD_STAMP(0, 2 + t);
     }
     if (qok) {
 #pragma unroll
@@ -633,6 +657,11 @@ __global__ __launch_bounds__(64 * BW, 1) void attn_bwd_q_h3_kernel(const _Float1
             for (int r = 0; r < 16; ++r) dq0[d][r] += dq1[d][r] * kLoInv;
         store_split_head(d_qkv + ((size_t)b * S + q) * ld + qoff + 4 * hi, dq0);
     }
+    BWD_STAMP(0, 10);
+#ifdef CMDI_PROBES
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    BWD_STAMP(0, 11);
 }
 
 // ---- dK / dV: wave = 32 keys, loop over query tiles ------------------------------------------------------
@@ -668,6 +697,7 @@ __global__ __launch_bounds__(64 * BW, WHICH == 1 ? 2 : 1) void attn_bwd_kv_h3_ke
     const float scale2 = scale * 1.4426950408889634f;
     const TrOff troff = make_troff(lane);
 
+    BWD_STAMP(1 + WHICH, 0);
     h8 kh[8], kl[8], vh[8], vl[8];
     load_row_frags(kh, kl, base + (size_t)kc * ld + koff, hi);
     if constexpr (WHICH == 0) load_row_frags(vh, vl, base + (size_t)kc * ld + voff, hi);
@@ -697,6 +727,7 @@ __global__ __launch_bounds__(64 * BW, WHICH == 1 ? 2 : 1) void attn_bwd_kv_h3_ke
     stage_q(0, 0);
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
+    BWD_STAMP(1 + WHICH, 1);
     for (int t = 0; t < nqt; ++t) {
         const int cur = t & 1;
         if (t + 1 < nqt) stage_q(t + 1, cur ^ 1);
@@ -705,6 +736,7 @@ __global__ __launch_bounds__(64 * BW, WHICH == 1 ? 2 : 1) void attn_bwd_kv_h3_ke
             const char* dot = qt + TILE;
             const float* sp = reinterpret_cast<const float*>(qt + STAGE);
             const f32x16 s = tile_dot_h3<WHICH == 0>(qt, kh, kl, l31, hi);     // S (unscaled): lane = key, regs = queries
+            if (t == 1) BWD_STAMP(1 + WHICH, 12);
             float p[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -715,13 +747,17 @@ __global__ __launch_bounds__(64 * BW, WHICH == 1 ? 2 : 1) void attn_bwd_kv_h3_ke
                 acc_prob(acc0, p, dot, troff);                     // dVᵀ += dOᵀ · P
             } else {
                 const f32x16 dp = tile_dot_h3(dot, vh, vl, l31, hi);   // dP
+                if (t == 1) BWD_STAMP(1 + WHICH, 13);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) p[r] = p[r] * (dp[r] - sp[64 + mfma32_row(r, lane)]) * scale;
+                if (t == 1) BWD_STAMP(1 + WHICH, 14);
                 acc_unbounded(acc0, acc1, p, qt, troff);           // dKᵀ += Qᵀ · dS
             }
+            if (t == 1) BWD_STAMP(1 + WHICH, 15);
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();
+        BWD_STAMP(1 + WHICH, 2 + t);
     }
     if (kok) {
         if constexpr (WHICH == 0) {
@@ -733,6 +769,11 @@ __global__ __launch_bounds__(64 * BW, WHICH == 1 ? 2 : 1) void attn_bwd_kv_h3_ke
         _Float16* row = d_qkv + ((size_t)b * S + key) * ld + 4 * hi;
         store_split_head(row + (WHICH == 0 ? koff : voff), acc0);
     }
+    BWD_STAMP(1 + WHICH, 10);
+#ifdef CMDI_PROBES
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    BWD_STAMP(1 + WHICH, 11);
 }
 
 // D[(b*H + h)*S + q] = sum over the head's 128 dims of dO·O (fp32); one wave per token row, d_model = H*128
@@ -769,7 +810,8 @@ hipError_t launch_attention_bwd_h3(const _Float16* qkv_split, const float* o_fwd
     if (S < 1 || S > 224) return hipErrorInvalidValue;
     const float scale = 1.0f / sqrtf((float)DH);
     constexpr size_t lds_q = 2ull * STAGE, lds_kv = 2ull * (STAGE + 512);
-    static bool attr_done = false;
+    static bool attr_done_dev[kMaxDevices] = {};
+    bool& attr_done = attr_done_dev[device_slot()];
     if (!attr_done) {
         hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_q_h3_kernel),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
@@ -796,6 +838,12 @@ hipError_t launch_attention_bwd_h3(const _Float16* qkv_split, const float* o_fwd
     return hipGetLastError();
 }
 
+#ifdef CMDI_PROBES
+hipError_t read_bwd_stamps(void* host_dst) {
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_bwd_stamps), sizeof(long long) * 3 * 1024 * 24);
+}
+#endif
+
 template <int NW, int NS, int STAG = 0>
 static hipError_t launch_attention_h3_cfg(const _Float16* qkv_split, float* out, _Float16* out_split, int* range_flag,
                                           float* row_stats, int n_seq, int S, int H, int dbg, long head_rows,
@@ -804,7 +852,8 @@ static hipError_t launch_attention_h3_cfg(const _Float16* qkv_split, float* out,
     const float scale = 1.0f / sqrtf((float)DH);
     constexpr size_t lds_ring = (size_t)NS * STAGE, lds_epi = (size_t)NW * 32 * 528;   // K/V ring | output rows (epilogue)
     constexpr size_t lds = lds_ring > lds_epi ? lds_ring : lds_epi;
-    static bool attr_done = false;
+    static bool attr_done_dev[kMaxDevices] = {};
+    bool& attr_done = attr_done_dev[device_slot()];
     if (!attr_done) {
         hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_h3_kernel<true, NW, NS, STAG>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

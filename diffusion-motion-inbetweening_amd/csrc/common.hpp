@@ -10,6 +10,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kWave = 64;
 
+// Function attributes (dynamic LDS size) and CU counts belong to a DEVICE: a launcher's one-time setup is keyed by the
+// current device, so a process that drives several GPUs sets every one of them up.  Slot 0 doubles as the
+// fallback for device ids beyond the table.
+constexpr int kMaxDevices = 16;
+inline int device_slot() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) d = 0;
+    return d;
+}
+
 // Row r (0..15) of a 32x32 MFMA C/D fragment held by lane `lane`:
 // col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
 __device__ __forceinline__ int mfma32_row(int r, int lane) {

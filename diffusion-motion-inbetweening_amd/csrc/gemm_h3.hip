@@ -25,7 +25,8 @@ using H128x256w16 = H3Tile<128, 256, 4, 4, 3, 4>;   // 16 waves, 32x64 per wave
 template <class TC, int EPI>
 static hipError_t launch_h3_one(const H3Params& p, hipStream_t stream) {
     auto kern = gemm_h3_kernel<TC, EPI>;
-    static bool attr_done = false;  // benign race: the attribute call is idempotent
+    static bool attr_done_dev[kMaxDevices] = {};  // benign race: the attribute call is idempotent
+    bool& attr_done = attr_done_dev[device_slot()];
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -60,7 +61,8 @@ static hipError_t launch_h3_mixed(const H3Params& p0, hipStream_t stream) {
     const int n_small = ((p.M - p.m_split + TS::BM - 1) / TS::BM) * ((p.N + TS::BN - 1) / TS::BN);
     auto kern = gemm_h3_mixed_kernel<TB, TS, EPI>;
     constexpr size_t lds = TB::LDS_BYTES > TS::LDS_BYTES ? TB::LDS_BYTES : TS::LDS_BYTES;
-    static bool attr_done = false;
+    static bool attr_done_dev[kMaxDevices] = {};
+    bool& attr_done = attr_done_dev[device_slot()];
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -59,6 +59,9 @@ hipError_t launch_attention_h3(const _Float16* qkv_split, float* out, _Float16* 
 hipError_t launch_attention_bwd_h3(const _Float16* qkv_split, const float* o_fwd, const float* row_stats,
                                    const float* d_out, const _Float16* d_out_split, _Float16* d_qkv_split,
                                    float* d_rowdot, int n_seq, int S, int H, hipStream_t stream);
+#ifdef CMDI_PROBES
+hipError_t read_bwd_stamps(void* host_dst);
+#endif
 // ---- attention_bwd_f32.hip ------------------------------------------------------------------
 // d_qkv[M,3d] from d_out[M,d]; P is recomputed from the forward's row statistics; d_rowdot is a
 // [n_seq*H*S] scratch (D = rowsum(dO*O)) written by the dQ kernel and read by the dK/dV kernel.
@@ -118,6 +121,7 @@ int unet_forward(UnetModel* u, const float* x, const float* obs, const uint8_t* 
 int unet_backward(UnetModel* u, const float* gout, const uint8_t* mask, const unsigned* gs_bits, int B, int nseq, int T,
                   float* gx, hipStream_t s);
 int unet_range_flag(UnetModel* u, int* flag, hipStream_t s);
+int unet_range_clear(UnetModel* u, hipStream_t s);
 hipError_t launch_unet_emb(float* emb, const float* time_table, const float* text_term, const int64_t* t_dev,
                            int64_t t_scalar, int n_seq, int n_per_pass, int d, int n_time_rows, hipStream_t stream);
 

@@ -1000,7 +1000,8 @@ int res_block_bwd(UnetModel* u, const ResBlock& r, const RBStash& st, const floa
 int attn_backward(UnetModel* u, const AttnSite& a, int nseq, float* dy, int ld, hipStream_t s) {
     const Lvl L = lvl(a.level);
     const int C = u->C[1], rows = nseq * L.Tp, l = a.level;
-    static bool attr_done = false;
+    static bool attr_done_dev[kMaxDevices] = {};
+    bool& attr_done = attr_done_dev[device_slot()];
     if (!attr_done) {
         UCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(linattn_core_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)LA_BWD_LDS));
@@ -1198,6 +1199,11 @@ int unet_range_flag(UnetModel* u, int* flag, hipStream_t s) {
     if (hipStreamSynchronize(s) != hipSuccess) return -1;
     if (*flag) (void)hipMemsetAsync(u->range_flag, 0, sizeof(int), s);
     return 0;
+}
+
+// ordered on the stream, no read-back (cmdi_range_clear: legal inside a hipGraph capture, no hidden sync at a chain's start)
+int unet_range_clear(UnetModel* u, hipStream_t s) {
+    return hipMemsetAsync(u->range_flag, 0, sizeof(int), s) == hipSuccess ? 0 : -1;
 }
 
 hipError_t launch_unet_emb(float* emb, const float* time_table, const float* text_term, const int64_t* t_dev,

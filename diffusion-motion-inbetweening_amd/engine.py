@@ -436,6 +436,34 @@ def attention_fwd_h3(qkv: torch.Tensor, n_seq: int, seq_len: int, n_heads: int) 
     return out
 
 
+def attention_fwd_h3_split(qkv_split: torch.Tensor, n_seq: int, seq_len: int, n_heads: int) -> torch.Tensor:
+    """attention_fwd_h3 on rows that are ALREADY split ([>= n_seq*S, 6*H*128] f16; rows past n_seq*S are not part of the
+    launch — the test that poisons the memory behind the tensor uses them)."""
+    lib = N.load()
+    assert qkv_split.dtype == torch.float16 and qkv_split.is_contiguous() and qkv_split.shape[1] == 6 * n_heads * 128
+    assert qkv_split.shape[0] >= n_seq * seq_len
+    out = torch.empty((n_seq * seq_len, n_heads * 128), dtype=torch.float32, device=qkv_split.device)
+    with torch.cuda.device(qkv_split.device):
+        N.check(lib.cmdi_attention_fwd_h3(N.ptr(qkv_split), N.ptr(out), n_seq, seq_len, n_heads,
+                                          N.current_stream(qkv_split.device)))
+    return out
+
+
+def attention_vjp_h3(qkv: torch.Tensor, dout: torch.Tensor, n_seq: int, seq_len: int, n_heads: int) -> torch.Tensor:
+    """d qkv [n_seq*S, 3*H*128] (fp32, un-split) of the split-f16 attention core for the output gradient `dout` (test hook)."""
+    lib = N.load()
+    d = n_heads * 128
+    M = n_seq * seq_len
+    assert qkv.shape == (M, 3 * d) and dout.shape == (M, d) and dout.dtype == torch.float32 and dout.is_contiguous()
+    qs = split_f16(qkv)
+    dqs = torch.zeros((M, 6 * d), dtype=torch.float16, device=qkv.device)
+    work = torch.empty(2 * M * d + 3 * n_seq * n_heads * seq_len, dtype=torch.float32, device=qkv.device)
+    with torch.cuda.device(qkv.device):
+        N.check(lib.cmdi_attention_vjp_h3(N.ptr(qs), N.ptr(dout), N.ptr(dqs), N.ptr(work), n_seq, seq_len, n_heads,
+                                          N.current_stream(qkv.device)))
+    return unsplit_f16(dqs)
+
+
 def philox4x32_10(counter, key):
     """Host Philox4x32-10 block (known-answer tests)."""
     lib = N.load()

@@ -231,6 +231,11 @@ BIG_CASES = {
                     seed=509, ragged=True, skip=90, init_image=True, keep=(0, 63, 64, 127, 128, 255)),
     "c5_rank": dict(kind="chain", text=True, cfg=True, weight_seed=47, B=128, T=196, respacing=[10], sampler="ddpm",
                     seed=510, ragged=True, keep=(0, 31, 32, 63, 64, 127)),
+    # (VERDICT r3 task 5b) BASELINE config 2 itself, END TO END: B=32 x 196 frames, text CFG, ragged lengths, ALL 1000
+    # ancestral steps through the reference on CPU (~15 min), so that the two-pipeline / two-stream one-call schedule is
+    # compared with reference values over the whole chain, not its first 20 steps.  Sample 0's x_t every 100 steps.
+    "big_c2_long": dict(kind="chain", text=True, cfg=True, weight_seed=41, B=32, T=196, respacing=None, sampler="ddpm",
+                        seed=511, ragged=True, keep=BIG_KEEP, every=100),
 }
 
 

@@ -20,7 +20,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import check_fingerprint, load_golden, max_abs, rel_l2, sub
+from conftest import check_fingerprint, load_golden, max_abs, ok, rel_l2, sub
 from oracle import diffusion_oracle as do
 from oracle import weights
 from oracle.mdm_oracle import MDMOracle
@@ -79,11 +79,11 @@ def test_gemm_nt(tile, shape):
     r = torch.randn(m, n, generator=g)
     ref = (a.double() @ w.double().T + b.double())
     out = eng.gemm_nt(a.to(DEV), w.to(DEV), b.to(DEV), tile=tile).cpu()
-    assert rel_l2(out.numpy(), ref.numpy()) <= 2e-6
+    assert ok("gemm_nt.rel_l2.0", rel_l2(out.numpy(), ref.numpy()), 2e-6)
     out = eng.gemm_nt(a.to(DEV), w.to(DEV), b.to(DEV), tile=tile, epi=3, resid=r.to(DEV)).cpu()
-    assert rel_l2(out.numpy(), (ref + r.double()).numpy()) <= 2e-6
+    assert ok("gemm_nt.rel_l2.1", rel_l2(out.numpy(), (ref + r.double()).numpy()), 2e-6)
     out = eng.gemm_nt(a.to(DEV), w.to(DEV), b.to(DEV), tile=tile, epi=1).cpu()
-    assert rel_l2(out.numpy(), torch.nn.functional.gelu(ref).numpy()) <= 2e-6
+    assert ok("gemm_nt.rel_l2.2", rel_l2(out.numpy(), torch.nn.functional.gelu(ref).numpy()), 2e-6)
 
 
 # ---- split-f16 (fp32-equivalent) GEMM family -------------------------------------------------------
@@ -121,18 +121,18 @@ def test_gemm_h3(tile, shape):
     out = eng.gemm_h3(a_s, w_s, b.to(DEV), tile=tile).cpu()
     e_h3 = rel_l2(out.numpy(), ref.numpy())
     e_f32 = rel_l2(eng.gemm_nt(a.to(DEV), w.to(DEV), b.to(DEV)).cpu().numpy(), ref.numpy())
-    assert e_h3 <= 2e-6 and e_h3 <= 1.5 * e_f32 + 1e-8, (e_h3, e_f32)
+    assert ok("gemm_h3.rel_l2.plain", e_h3, 2e-6) and e_h3 <= 1.5 * e_f32 + 1e-8, (e_h3, e_f32)
     out = eng.gemm_h3(a_s, w_s, b.to(DEV), tile=tile, epi=3, resid=r.to(DEV)).cpu()
-    assert rel_l2(out.numpy(), (ref + r.double()).numpy()) <= 2e-6
+    assert ok("gemm_h3.rel_l2.0", rel_l2(out.numpy(), (ref + r.double()).numpy()), 2e-6)
     if n % 32 == 0:   # the residual handed over as split rows (what LayerNorm leaves behind for the next GEMM)
         r_s = eng.split_f16(r.to(DEV))
         out = eng.gemm_h3(a_s, w_s, b.to(DEV), tile=tile, epi=4, resid=r_s).cpu()
-        assert rel_l2(out.numpy(), (ref + eng.unsplit_f16(r_s).cpu().double()).numpy()) <= 2e-6
-        assert rel_l2(out.numpy(), (ref + r.double()).numpy()) <= 2e-6
+        assert ok("gemm_h3.rel_l2.1", rel_l2(out.numpy(), (ref + eng.unsplit_f16(r_s).cpu().double()).numpy()), 2e-6)
+        assert ok("gemm_h3.rel_l2.2", rel_l2(out.numpy(), (ref + r.double()).numpy()), 2e-6)
     out = eng.unsplit_f16(eng.gemm_h3(a_s, w_s, b.to(DEV), tile=tile, epi=1)).cpu()
-    assert rel_l2(out.numpy(), torch.nn.functional.gelu(ref).numpy()) <= 2e-6
+    assert ok("gemm_h3.rel_l2.3", rel_l2(out.numpy(), torch.nn.functional.gelu(ref).numpy()), 2e-6)
     out = eng.unsplit_f16(eng.gemm_h3(a_s, w_s, b.to(DEV), tile=tile, split_out=True)).cpu()
-    assert rel_l2(out.numpy(), ref.numpy()) <= 2e-6
+    assert ok("gemm_h3.rel_l2.4", rel_l2(out.numpy(), ref.numpy()), 2e-6)
 
 
 @pytest.mark.parametrize("shape", [(333, 512, 512), (128, 256, 64), (129, 256, 96), (197 * 4, 1536, 512), (1000, 512, 1024),
@@ -157,7 +157,7 @@ def test_gemm_h3_persistent_is_bitwise_the_tiled_kernel(shape):
         ref = eng.gemm_h3(a_s, w_s, b, tile=8, epi=epi, **kw)
         out = eng.gemm_h3(a_s, w_s, b, tile=50, epi=epi, **kw)
         assert torch.equal(out, ref), (shape, epi, kw.keys())
-    assert rel_l2(eng.gemm_h3(a_s, w_s, b, tile=50).cpu().numpy(), ref64.cpu().numpy()) <= 2e-6
+    assert ok("gemm_h3_persistent_is_bitwise_the_tiled_kernel.rel_l2.0", rel_l2(eng.gemm_h3(a_s, w_s, b, tile=50).cpu().numpy(), ref64.cpu().numpy()), 2e-6)
 
 
 # ---- bf16x6: exact three-plane bf16 operands, six MFMA products (fp32-class, no operand truncation) -----------------
@@ -193,14 +193,14 @@ def test_gemm_x6(variant, shape):
     out = eng.gemm_x6(a.to(DEV), wx, b.to(DEV), variant=variant).cpu()
     e_x6 = rel_l2(out.numpy(), ref.numpy())
     e_f32 = rel_l2(eng.gemm_nt(a.to(DEV), w.to(DEV), b.to(DEV)).cpu().numpy(), ref.numpy())
-    assert e_x6 <= 2e-6 and e_x6 <= 1.1 * e_f32 + 1e-8, (e_x6, e_f32)
+    assert ok("gemm_x6.rel_l2.plain", e_x6, 2e-6) and e_x6 <= 1.1 * e_f32 + 1e-8, (e_x6, e_f32)
     out = eng.gemm_x6(a.to(DEV), wx, b.to(DEV), epi=3, resid=r.to(DEV), variant=variant).cpu()
-    assert rel_l2(out.numpy(), (ref + r.double()).numpy()) <= 2e-6
+    assert ok("gemm_x6.rel_l2.0", rel_l2(out.numpy(), (ref + r.double()).numpy()), 2e-6)
     out = eng.gemm_x6(a.to(DEV), wx, b.to(DEV), epi=1, variant=variant).cpu()
-    assert rel_l2(out.numpy(), torch.nn.functional.gelu(ref).numpy()) <= 2e-6
+    assert ok("gemm_x6.rel_l2.1", rel_l2(out.numpy(), torch.nn.functional.gelu(ref).numpy()), 2e-6)
     # no range limit: operands far outside the f16 range
     big = eng.gemm_x6((a * 1e6).to(DEV), eng.pack_x6((w * 1e5).to(DEV)), None, variant=variant).cpu()
-    assert rel_l2(big.numpy(), (ref - b.double()).numpy() * 1e11) <= 2e-6
+    assert ok("gemm_x6.rel_l2.2", rel_l2(big.numpy(), (ref - b.double()).numpy() * 1e11), 2e-6)
 
 
 @pytest.mark.parametrize("shape", [(333, 512), (12608, 1024), (64, 32)])
@@ -217,8 +217,8 @@ def test_fused_layernorm_gemm(shape):
     ref = torch.nn.functional.layer_norm(x, (512,), gamma.double(), beta.double(), 1e-5)
     y, ys = eng.gemm_h3_ln(eng.split_f16(a.to(DEV)), eng.split_f16(w.to(DEV)), b.to(DEV), r.to(DEV),
                            gamma.to(DEV), beta.to(DEV), want_split=True)
-    assert rel_l2(y.cpu().numpy(), ref.numpy()) <= 2e-6, rel_l2(y.cpu().numpy(), ref.numpy())
-    assert rel_l2(eng.unsplit_f16(ys).cpu().numpy(), ref.numpy()) <= 2e-6
+    assert ok("fused_layernorm_gemm.rel_l2.0", rel_l2(y.cpu().numpy(), ref.numpy()), 2e-6), rel_l2(y.cpu().numpy(), ref.numpy())
+    assert ok("fused_layernorm_gemm.rel_l2.1", rel_l2(eng.unsplit_f16(ys).cpu().numpy(), ref.numpy()), 2e-6)
 
 
 def test_f16x3_range_guard():
@@ -245,7 +245,7 @@ def test_f16x3_range_guard():
         model.invalidate_engine()
         out = model(x, t, y={})
         assert model._engine.precision == (precision or "bf16x6")
-        assert rel_l2(out.cpu().numpy(), want) <= 2e-5, (precision, rel_l2(out.cpu().numpy(), want))
+        assert ok("f16x3_range_guard.rel_l2.0", rel_l2(out.cpu().numpy(), want), 2e-5), (precision, rel_l2(out.cpu().numpy(), want))
 
 
 @pytest.mark.parametrize("scale,expect", [(5.0e3, "f16x3"), (4.0e4, "bf16x6")])
@@ -278,7 +278,7 @@ def test_real_scale_activations_and_range_fallback(scale, expect):
     assert (pre < 65504.0) == (expect == "f16x3") and pre > 5e3, pre
     sch = do.Schedule(do.named_betas("cosine", 1000), do.space_timesteps(1000, [3]))
     want = do.sample_loop(sch, oracle, x_T, noise)
-    assert rel_l2(out, want) <= 1e-4, rel_l2(out, want)
+    assert ok("real_scale_activations_and_range_fallback.rel_l2.0", rel_l2(out, want), 1e-4), rel_l2(out, want)
 
 
 # ---- attention -----------------------------------------------------------------------------------
@@ -295,19 +295,69 @@ def test_attention_core_vs_torch(S, kernel):
     p = torch.softmax(q @ k.transpose(-1, -2) / 128 ** 0.5, dim=-1)
     ref = (p @ v).transpose(1, 2).reshape(n_seq * S, 512)
     out = getattr(eng, kernel)(qkv.to(DEV), n_seq, S, H).cpu()
-    assert rel_l2(out.numpy(), ref.numpy()) <= 2e-6, rel_l2(out.numpy(), ref.numpy())
+    assert ok("attention_core_vs_torch.rel_l2.0", rel_l2(out.numpy(), ref.numpy()), 2e-6), rel_l2(out.numpy(), ref.numpy())
 
 
 # ---- RNG -------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("S", [197, 61, 33])
+def test_attention_h3_ignores_memory_behind_a_sequence(S):
+    """the K / V stages of the split-f16 kernel read whole 32-key blocks; keys past the sequence are fetched
+    through a buffer descriptor that ends with the sequence, with the stage position in the range-checked vector offset.
+    NaN patterns directly behind the tensor (last sequence) and Inf rows in the NEXT sequence (first sequence) must not
+    reach the output: 0 * NaN in the P·V product would.  Output bit-identical to the run with zeros there."""
+    eng = sub("engine")
+    n_seq, H = 2, 4
+    M = n_seq * S
+    g = torch.Generator().manual_seed(100 + S)
+    qs = eng.split_f16(torch.randn(M, 3 * H * 128, generator=g).to(DEV))
+    buf = torch.zeros(M + 64, qs.shape[1], dtype=torch.float16, device=DEV)
+    buf[:M] = qs
+    clean = eng.attention_fwd_h3_split(buf, n_seq, S, H)
+    buf[M:] = float("nan")
+    dirty = eng.attention_fwd_h3_split(buf, n_seq, S, H)
+    assert torch.isfinite(dirty).all() and torch.equal(clean, dirty)
+    # sequence 0 must not see sequence 1's rows either: make them Inf / NaN and compare sequence 0's output
+    buf[S:M] = float("inf")
+    buf[S:M, ::3] = float("nan")
+    first = eng.attention_fwd_h3_split(buf, n_seq, S, H)[:S]
+    assert torch.isfinite(first).all() and torch.equal(first, clean[:S])
+
+
+@pytest.mark.parametrize("S", [197, 61, 16, 17, 224, 33, 193, 1, 129, 160])
+def test_attention_vjp_h3_vs_torch_autograd(S):
+    """The input-VJP of the attention core alone (dQ / dK / dV kernels of attention_h3.hip through cmdi_attention_vjp_h3)
+    against float64 torch.autograd of softmax(QK^T / sqrt(128)) V — every tile count 1..7 on both axes, tails of 1, 5 and
+    16 rows, a sharpened softmax and a spiked key."""
+    eng = sub("engine")
+    n_seq, H = 3, 4
+    g = torch.Generator().manual_seed(1000 + S)
+    qkv = torch.randn(n_seq * S, 3 * H * 128, generator=g)
+    qkv[:, :512] *= 3.0
+    qkv[S - 1, 512:1024] *= 4.0
+    dout = torch.randn(n_seq * S, H * 128, generator=g)
+    x = qkv.double().requires_grad_(True)
+    q, k, v = (x[:, i * 512:(i + 1) * 512].view(n_seq, S, H, 128).transpose(1, 2) for i in range(3))
+    p = torch.softmax(q @ k.transpose(-1, -2) / 128 ** 0.5, dim=-1)
+    out = (p @ v).transpose(1, 2).reshape(n_seq * S, 512)
+    want, = torch.autograd.grad((out * dout.double()).sum(), x)
+    got = eng.attention_vjp_h3(qkv.to(DEV), dout.to(DEV), n_seq, S, H).cpu()
+    whole = float(np.linalg.norm(want.numpy()))
+    for i, part in enumerate("qkv"):
+        a, b = got[:, i * 512:(i + 1) * 512].numpy(), want[:, i * 512:(i + 1) * 512].numpy()
+        # (S = 1: P = 1, so dQ = dK = 0 exactly in the reference: the error is then measured against the whole gradient)
+        err = float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b), 1e-3 * whole))
+        assert ok(f"attention_vjp_h3.d{part}", err, 5e-6), (part, err)
+
+
 def test_engine_rng_matches_oracle():
     Engine = sub("engine").Engine
     e = Engine(n_layers=0, d_model=0, d_ff=0, n_heads=0, n_feats=263, max_frames=196, max_batch=4,
                device=DEV)
     z = e.randn((4, 263, 1, 196), seed=0x1234ABCD5678, first_sample=3, step=7).cpu().numpy()
     want = do.engine_randn(4, 263 * 196, seed=0x1234ABCD5678, first_sample=3, step=7)
-    assert max_abs(z.reshape(4, -1), want) <= 2e-6
+    assert ok("engine_rng_matches_oracle.max_abs.0", max_abs(z.reshape(4, -1), want), 2e-6)
     odd = e.randn((3, 263, 1, 59), seed=5, step=-1).cpu().numpy()  # per-sample size not % 4
-    assert max_abs(odd.reshape(3, -1), do.engine_randn(3, 263 * 59, seed=5)) <= 2e-6
+    assert ok("engine_rng_matches_oracle.max_abs.1", max_abs(odd.reshape(3, -1), do.engine_randn(3, 263 * 59, seed=5)), 2e-6)
 
 
 # ---- denoiser --------------------------------------------------------------------------------------
@@ -321,8 +371,8 @@ def test_forward_uncond_vs_reference(cases, precision):
                         max_frames=inp["x"].shape[-1]).precision == precision
     out = model(tt(inp["x"]), tt(inp["t"]), y={}).cpu().numpy()
     ref = load_golden("fwd_uncond")["out"]
-    assert max_abs(out, ref) <= 1e-4 and rel_l2(out, ref) <= 2e-5, (max_abs(out, ref), rel_l2(out, ref))
-    assert rel_l2(out, MDMOracle(sd).forward(inp["x"], inp["t"])) <= 2e-5
+    assert ok("forward_uncond_vs_reference.max_abs.0", max_abs(out, ref), 1e-4) and ok("forward_uncond_vs_reference.rel_l2.0", rel_l2(out, ref), 2e-5), (max_abs(out, ref), rel_l2(out, ref))
+    assert ok("forward_uncond_vs_reference.rel_l2.1", rel_l2(out, MDMOracle(sd).forward(inp["x"], inp["t"])), 2e-5)
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
@@ -339,7 +389,7 @@ def test_forward_text_cfg_vs_reference(cases, precision):
     wrapped = sub("model.cfg_sampler").ClassifierFreeSampleModel(model)
     cfg = wrapped(x, t, y=dict(y, text_scale=tt(inp["text_scale"]))).cpu().numpy()
     for mine, key in ((oc, "out_cond"), (ou, "out_uncond"), (cfg, "out_cfg")):
-        assert max_abs(mine, g[key]) <= 2e-4 and rel_l2(mine, g[key]) <= 2e-5, \
+        assert ok("forward_text_cfg_vs_reference.max_abs.0", max_abs(mine, g[key]), 2e-4) and ok("forward_text_cfg_vs_reference.rel_l2.0", rel_l2(mine, g[key]), 2e-5), \
             (key, max_abs(mine, g[key]), rel_l2(mine, g[key]))
 
 
@@ -362,16 +412,16 @@ def test_forward_other_shapes_vs_oracle(precision, B, T):
     want, _, _ = oracle.forward_cfg(x, t, enc, scale)
     got = model(tt(x), tt(t), y=y).cpu().numpy()
     assert np.isfinite(got).all()
-    assert max_abs(got, want) <= 2e-4 and rel_l2(got, want) <= 2e-5, (max_abs(got, want), rel_l2(got, want))
+    assert ok("forward_other_shapes_vs_oracle.max_abs.0", max_abs(got, want), 2e-4) and ok("forward_other_shapes_vs_oracle.rel_l2.0", rel_l2(got, want), 2e-5), (max_abs(got, want), rel_l2(got, want))
     gout = rng.standard_normal(shape).astype(np.float32)
     z = tt(x).requires_grad_(True)
     with torch.enable_grad():
         out = model(z, tt(t), y=y)
         gx, = torch.autograd.grad((out * tt(gout)).sum(), z)
-    assert rel_l2(out.detach().cpu().numpy(), want) <= 2e-5
+    assert ok("forward_other_shapes_vs_oracle.rel_l2.1", rel_l2(out.detach().cpu().numpy(), want), 2e-5)
     want_gx = oracle.vjp_cfg(x, t, gout, enc, scale)
     want_gx = want_gx[0] if isinstance(want_gx, tuple) else want_gx
-    assert rel_l2(gx.cpu().numpy(), want_gx) <= 5e-5, rel_l2(gx.cpu().numpy(), want_gx)
+    assert ok("forward_other_shapes_vs_oracle.rel_l2.2", rel_l2(gx.cpu().numpy(), want_gx), 5e-5), rel_l2(gx.cpu().numpy(), want_gx)
 
 
 @pytest.mark.parametrize("fold", ["0", "1"])
@@ -386,7 +436,7 @@ def test_forward_layernorm_schedules(cases, monkeypatch, fold):
     g = load_golden("fwd_text")
     out = model(tt(inp["x"]), tt(inp["t"]), y={"text_embed": tt(inp["enc_text"]), "text_scale": tt(inp["text_scale"])})
     out = out.cpu().numpy()
-    assert max_abs(out, g["out_cfg"]) <= 2e-4 and rel_l2(out, g["out_cfg"]) <= 2e-5, (max_abs(out, g["out_cfg"]), rel_l2(out, g["out_cfg"]))
+    assert ok("forward_layernorm_schedules.max_abs.0", max_abs(out, g["out_cfg"]), 2e-4) and ok("forward_layernorm_schedules.rel_l2.0", rel_l2(out, g["out_cfg"]), 2e-5), (max_abs(out, g["out_cfg"]), rel_l2(out, g["out_cfg"]))
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
@@ -402,14 +452,14 @@ def test_vjp_vs_reference_autograd(cases, precision):
                       text_scale=tt(inp["text_scale"]))
     g = load_golden("vjp_text_cfg")
     out = eng.mdm_forward(tt(inp["x"]), tt(inp["t"])).cpu().numpy()
-    assert rel_l2(out, g["out"]) <= 2e-5
+    assert ok("vjp_vs_reference_autograd.rel_l2.0", rel_l2(out, g["out"]), 2e-5)
     gx = eng.mdm_vjp(tt(inp["gout"])).cpu().numpy()
-    assert rel_l2(gx, g["gx"]) <= 5e-5, rel_l2(gx, g["gx"])
+    assert ok("vjp_vs_reference_autograd.rel_l2.1", rel_l2(gx, g["gx"]), 5e-5), rel_l2(gx, g["gx"])
     # the VJP is linear in gout: tiny and huge output gradients must come back to the same
     # tolerance (f16x3: the power-of-two gradient scale keeps them inside the f16 range)
     for k in (1e-12, 1e9):
         gk = eng.mdm_vjp(tt(inp["gout"] * np.float32(k))).cpu().numpy().astype(np.float64) / k
-        assert rel_l2(gk, g["gx"]) <= 5e-5, (k, rel_l2(gk, g["gx"]))
+        assert ok("vjp_vs_reference_autograd.rel_l2.2", rel_l2(gk, g["gx"]), 5e-5), (k, rel_l2(gk, g["gx"]))
 
 
 def test_torch_autograd_through_the_native_denoiser(cases):
@@ -423,10 +473,10 @@ def test_torch_autograd_through_the_native_denoiser(cases):
     y = {"text_embed": tt(inp["enc_text"]), "text_scale": tt(inp["text_scale"])}
     with torch.enable_grad():
         out = model(z, tt(inp["t"]), y=y)
-        assert out.requires_grad and rel_l2(out.detach().cpu().numpy(), g["out"]) <= 2e-5
+        assert out.requires_grad and ok("torch_autograd_through_the_native_denoiser.rel_l2.0", rel_l2(out.detach().cpu().numpy(), g["out"]), 2e-5)
         loss = (out * tt(inp["gout"])).sum()           # d loss / d out = gout
         gx, = torch.autograd.grad(loss, z)
-    assert rel_l2(gx.cpu().numpy(), g["gx"]) <= 5e-5, rel_l2(gx.cpu().numpy(), g["gx"])
+    assert ok("torch_autograd_through_the_native_denoiser.rel_l2.1", rel_l2(gx.cpu().numpy(), g["gx"]), 5e-5), rel_l2(gx.cpu().numpy(), g["gx"])
     # a second forward invalidates the first graph's stash: the stale backward must fail loudly
     with torch.enable_grad():
         o1 = model(z, tt(inp["t"]), y=y)
@@ -506,13 +556,16 @@ def run_chain(cases, name, precision):
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_chain_vs_reference(cases, name, precision):
     final, dumps, g = run_chain(cases, name, precision)
-    assert rel_l2(final, g["final"]) <= 1e-4, rel_l2(final, g["final"])
+    assert ok("chain_vs_reference.rel_l2.0", rel_l2(final, g["final"]), 1e-4), rel_l2(final, g["final"])
     assert len(dumps) == g["pred_xstart"].shape[0]
     for k, d in enumerate(dumps):
-        assert rel_l2(d, g["pred_xstart"][k]) <= 1e-4, (k, rel_l2(d, g["pred_xstart"][k]))
+        assert ok("chain_vs_reference.rel_l2.1", rel_l2(d, g["pred_xstart"][k]), 1e-4), (k, rel_l2(d, g["pred_xstart"][k]))
 
 
 # ---- BASELINE shapes and chain lengths vs the reference (tests/golden/make_golden_big.py) ------------------
+_BIG_NOISE = {}     # the injected noise stream of the most recent BIG case, on the device
+
+
 def big_setup(cases, name, precision):
     case = cases.BIG_CASES[name]
     inp = cases.make_big_inputs(case)
@@ -535,8 +588,13 @@ def big_setup(cases, name, precision):
                  gradient_schedule=case["grad_schedule"], diffusion_steps=1000,
                  stop_recguidance_at=case["stop_recguidance_at"])
     n = diffusion.num_timesteps - case.get("skip", 0)
-    noise = torch.from_numpy(np.stack([cases.big_draw(case, 1 + k) for k in range(n)]))
-    diffusion.injected_noise = noise.to(DEV)
+    if name not in _BIG_NOISE:     # (big_c2_long: 1000 draws x 6.6 MB, built once for the three precision modes)
+        noise = torch.empty((n,) + inp["draw0"].shape, dtype=torch.float32, device=DEV)
+        for k in range(n):
+            noise[k].copy_(torch.from_numpy(cases.big_draw(case, 1 + k)))
+        _BIG_NOISE.clear()
+        _BIG_NOISE[name] = noise
+    diffusion.injected_noise = _BIG_NOISE[name]
     kw = dict(noise=tt(inp["draw0"]), clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=case.get("skip", 0),
               init_image=tt(inp["init_image"]) if "init_image" in inp else None)
     if case["sampler"] == "ddim":
@@ -544,12 +602,12 @@ def big_setup(cases, name, precision):
     return case, inp, g, model, diffusion, kw
 
 
-def stats_close(got, want, tol):
-    """Per-sample (sum, sum^2) of every sample vs the reference's float64 values: |d sum| <= tol * sqrt(N * sum^2)
-    (the scale of a sum of N terms), |d sum^2| <= tol * sum^2."""
+def stats_err(got, want):
+    """Per-sample (sum, sum^2) of every sample vs the reference's float64 values, as ONE relative figure: the largest of
+    |d sum| / sqrt(N * sum^2) (the scale of a sum of N terms) and |d sum^2| / sum^2 over the samples."""
     n = 263 * 196
-    return bool(np.all(np.abs(got[:, 0] - want[:, 0]) <= tol * np.sqrt(n * want[:, 1])) and
-                np.all(np.abs(got[:, 1] - want[:, 1]) <= tol * want[:, 1]))
+    return float(max(np.max(np.abs(got[:, 0] - want[:, 0]) / np.sqrt(n * want[:, 1])),
+                     np.max(np.abs(got[:, 1] - want[:, 1]) / want[:, 1])))
 
 
 @pytest.mark.parametrize("name", ["big_c2", "big_c3"])
@@ -568,8 +626,37 @@ def test_baseline_shape_chain_vs_reference(cases, name, precision):
     keep = list(case["keep"])
     err = rel_l2(final[keep], g["final"])
     per = [rel_l2(final[k], g["final"][i]) for i, k in enumerate(keep)]
-    assert err <= 1e-4 and max(per) <= 2e-4, (err, per)
-    assert stats_close(cases.sample_stats(final), g["stats"], 2e-4)
+    assert ok("baseline_shape_chain.rel_l2", err, 1e-4) and ok("baseline_shape_chain.per_sample", max(per), 2e-4), (err, per)
+    assert ok("baseline_shape_chain.stats", stats_err(cases.sample_stats(final), g["stats"]), 2e-4)
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_baseline_config2_full_1000_step_chain_vs_reference(cases, precision):
+    """BASELINE config 2 END TO END (VERDICT r3 task 5b): B=32 x 196 frames, text CFG, ragged lengths, all 1000 ancestral steps
+    on injected noise through the one-call path — i.e. the two-pipeline, two-stream schedule that bench.py times — against the
+    real reference's CPU chain (tests/golden/make_golden_big.py big_c2_long, ~13 min of reference time): six stored samples
+    (three per pipeline) and float64 (sum, sum^2) of all 32.  The per-step generator (cmdi_step per yield) gives the same
+    chain bit for bit, and sample 0's x_t is compared with the reference every 100 steps on the way."""
+    name = "big_c2_long"
+    case, inp, g, model, diffusion, kw = big_setup(cases, name, precision)
+    final = diffusion.p_sample_loop(model, inp["draw0"].shape, **kw)
+    eng = model.model._engine
+    assert eng.pipeline_parts() == 2, "the two-pipeline schedule was not taken at the BASELINE shape"
+    final = final.cpu().numpy()
+    keep = list(case["keep"])
+    err = rel_l2(final[keep], g["final"])
+    per = [rel_l2(final[k], g["final"][i]) for i, k in enumerate(keep)]
+    assert np.isfinite(final).all()
+    assert ok("baseline_config2_full_chain.rel_l2", err, 1e-4) and ok("baseline_config2_full_chain.per_sample", max(per), 2e-4), (err, per)
+    assert ok("baseline_config2_full_chain.stats", stats_err(cases.sample_stats(final), g["stats"]), 2e-4)
+    if precision == PRECISIONS[0]:
+        at = {int(i): k for k, i in enumerate(g["dump_at"])}
+        last = None
+        for i, out in enumerate(diffusion.p_sample_loop_progressive(model, inp["draw0"].shape, **kw)):
+            last = out["sample"]
+            if i in at:
+                assert ok("baseline_config2_full_chain.on_the_way", rel_l2(last[:1].cpu().numpy(), g["dumps"][at[i]]), 1e-4), i
+        assert np.array_equal(last.cpu().numpy(), final)
 
 
 @pytest.mark.parametrize("name", ["c4_ddim", "c4_ddpm", "c5_rank"])
@@ -589,8 +676,8 @@ def test_c4_c5_shape_chains_vs_reference(cases, name, precision):
     keep = list(case["keep"])
     err = rel_l2(final[keep], g["final"])
     per = [rel_l2(final[k], g["final"][i]) for i, k in enumerate(keep)]
-    assert err <= 1e-4 and max(per) <= 2e-4, (err, per)
-    assert stats_close(cases.sample_stats(final), g["stats"], 2e-4)
+    assert ok("c4_c5_shape_chains.rel_l2", err, 1e-4) and ok("c4_c5_shape_chains.per_sample", max(per), 2e-4), (err, per)
+    assert ok("c4_c5_shape_chains.stats", stats_err(cases.sample_stats(final), g["stats"]), 2e-4)
 
 
 C4C5_PARTS = {256: 2, 128: 2}     # engine pipelines at these batch sizes (api_sampler.hip n_parts), as observed
@@ -641,7 +728,7 @@ def test_reference_callers_replayed_on_the_gpu(cases, name, progress):
     kw["progress"] = progress
     out = short.p_sample_loop(model, shape, model_kwargs=model_kwargs, **kw).cpu().numpy()
     err = rel_l2(out, g["ref_sample"])
-    assert np.isfinite(out).all() and err <= (2e-4 if name == "conditional_synthesis" else 1e-4), err
+    assert np.isfinite(out).all() and ok(f"reference_callers_replayed.{name}", err, 2e-4 if name == "conditional_synthesis" else 1e-4), err
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
@@ -664,7 +751,7 @@ def test_forced_two_pipelines_on_small_golden(cases, precision, monkeypatch):
                                     model_kwargs={"y": y})
     assert model.model._engine.pipeline_parts() == 2
     g = load_golden(name)
-    assert rel_l2(final.cpu().numpy(), g["final"]) <= 1e-4, rel_l2(final.cpu().numpy(), g["final"])
+    assert ok("forced_two_pipelines_on_small_golden.rel_l2.0", rel_l2(final.cpu().numpy(), g["final"]), 1e-4), rel_l2(final.cpu().numpy(), g["final"])
 
 
 # measured drift (gpurun_out/drift_*.json): bound = 4x the larger of the two engines' measured value
@@ -700,8 +787,8 @@ def test_long_chain_drift_vs_reference(cases, name, precision):
         json.dump(summary, fh, indent=1)
     print(json.dumps(summary))
     assert np.isfinite(final).all()
-    assert summary["final_vs_ref_f64"] <= LONG_TOL[name], summary
-    assert summary["final_vs_ref_f32"] <= LONG_TOL[name], summary
+    assert ok(f"long_chain_drift.{name}.vs_f64", summary["final_vs_ref_f64"], LONG_TOL[name]), summary
+    assert ok(f"long_chain_drift.{name}.vs_f32", summary["final_vs_ref_f32"], LONG_TOL[name]), summary
     # the one-call loop (what p_sample_loop runs) gives the same chain as the per-step generator
     whole = (diffusion.ddim_sample_loop if case["sampler"] == "ddim" else diffusion.p_sample_loop)(
         model, inp["draw0"].shape, **kw).cpu().numpy()
@@ -719,8 +806,8 @@ def test_epsilon_model_chain_vs_reference(cases, name, precision):
     for i, out in enumerate(prog(model, inp["draw0"].shape, **kw)):
         final = out["sample"]
         if i in at:
-            assert rel_l2(out["sample"][:1].cpu().numpy(), g["dumps"][at[i]]) <= 1e-4
-    assert rel_l2(final.cpu().numpy(), g["final"]) <= 1e-4, rel_l2(final.cpu().numpy(), g["final"])
+            assert ok("epsilon_model_chain_vs_reference.rel_l2.0", rel_l2(out["sample"][:1].cpu().numpy(), g["dumps"][at[i]]), 1e-4)
+    assert ok("epsilon_model_chain_vs_reference.rel_l2.1", rel_l2(final.cpu().numpy(), g["final"]), 1e-4), rel_l2(final.cpu().numpy(), g["final"])
     # imputation / reconstruction guidance on an eps-model: refused like the reference (:407,430)
     y = dict(kw["model_kwargs"]["y"], imputate=True, stop_imputation_at=0, inpainting_mask=torch.zeros(inp["draw0"].shape, dtype=torch.bool, device=DEV),
              inpainted_motion=tt(inp["draw0"]), replacement_distribution='conditional')
@@ -766,9 +853,9 @@ def test_forward_b256_vs_reference(cases, precision):
     out = model(tt(inp["x"]), tt(inp["t"]), y={"text_embed": tt(inp["enc_text"]), "text_scale": tt(inp["text_scale"])})
     out = out.cpu().numpy()
     keep = list(case["keep"])
-    assert max_abs(out[keep], g["out_cfg"]) <= 2e-4 and rel_l2(out[keep], g["out_cfg"]) <= 2e-5, \
+    assert ok("forward_b256_vs_reference.max_abs.0", max_abs(out[keep], g["out_cfg"]), 2e-4) and ok("forward_b256_vs_reference.rel_l2.0", rel_l2(out[keep], g["out_cfg"]), 2e-5), \
         (max_abs(out[keep], g["out_cfg"]), rel_l2(out[keep], g["out_cfg"]))
-    assert stats_close(cases.sample_stats(out), g["stats"], 5e-5)
+    assert ok("forward_b256_vs_reference.stats", stats_err(cases.sample_stats(out), g["stats"]), 5e-5)
 
 
 def test_sharded_p_sample_loop_equals_the_full_batch():
@@ -906,9 +993,9 @@ def test_cond_fn_chain_vs_reference(cases, name, precision):
     final = loop(model, inp["x_T"].shape, **kw).cpu().numpy()
     dumps = loop(model, inp["x_T"].shape, dump_steps=list(cases.DUMP_STEPS), **kw)
     g = load_golden(name)
-    assert rel_l2(final, g["final"]) <= 1e-4, rel_l2(final, g["final"])
+    assert ok("cond_fn_chain_vs_reference.rel_l2.0", rel_l2(final, g["final"]), 1e-4), rel_l2(final, g["final"])
     for k, d in enumerate(dumps):
-        assert rel_l2(d.cpu().numpy(), g["pred_xstart"][k]) <= 1e-4, (k, rel_l2(d.cpu().numpy(), g["pred_xstart"][k]))
+        assert ok("cond_fn_chain_vs_reference.rel_l2.1", rel_l2(d.cpu().numpy(), g["pred_xstart"][k]), 1e-4), (k, rel_l2(d.cpu().numpy(), g["pred_xstart"][k]))
     # the guidance is not a no-op: the unguided chain on the same noise ends elsewhere
     plain = loop(model, inp["x_T"].shape, **{k: v for k, v in kw.items() if k not in ("cond_fn", "cond_fn_with_grad")})
     assert rel_l2(plain.cpu().numpy(), g["final"]) > 1e-2
@@ -964,7 +1051,7 @@ def test_gelu_epilogue_accuracy():
     x64 = x.astype(np.float64)
     want = 0.5 * x64 * (1.0 + special.erf(x64 / np.sqrt(2.0)))
     err = np.abs(got - want) / np.maximum(1.0, np.abs(x64))
-    assert err.max() <= 2.5e-7, (err.max(), x64.flat[err.argmax()])
+    assert ok("gelu_epilogue_accuracy.max_err", err.max(), 2.5e-7), (err.max(), x64.flat[err.argmax()])
 
 
 def test_bench_c5_runs_on_one_gpu():
@@ -1060,14 +1147,14 @@ def test_recover_xyz_vs_reference(cases, abs_3d):
     assert np.array_equal(g["fingerprint"], cases.fingerprint(inp))
     ref = g[f"xyz_abs{int(abs_3d)}"]
     out = mp.sample_to_xyz(tt(inp["sample"]), inp["mean"], inp["std"], 22, abs_3d).cpu().numpy()
-    tol = 2e-5 * max(1.0, float(np.abs(ref).max()))
-    assert out.shape == ref.shape and max_abs(out, ref) <= tol, max_abs(out, ref)
-    assert max_abs(out, recover_xyz(inp["sample"], inp["mean"], inp["std"], 22, abs_3d)) <= tol
+    scale = max(1.0, float(np.abs(ref).max()))     # relative to the largest coordinate
+    assert out.shape == ref.shape and ok("recover_xyz.vs_reference", max_abs(out, ref) / scale, 2e-5), max_abs(out, ref)
+    assert ok("recover_xyz.vs_oracle", max_abs(out, recover_xyz(inp["sample"], inp["mean"], inp["std"], 22, abs_3d)) / scale, 2e-5)
     # the reference-signature wrapper: un-normalised [B, 1, T, 263] in, [B, 1, T, 22, 3] out
     data = tt(inp["sample"]).permute(0, 2, 3, 1) * tt(inp["std"]) + tt(inp["mean"])
     xyz = mp.recover_from_ric(data, 22, abs_3d)
     assert xyz.shape == (3, 1, 196, 22, 3)
-    assert max_abs(xyz[:, 0].permute(0, 2, 3, 1).cpu().numpy(), ref) <= tol
+    assert ok("recover_xyz.wrapper", max_abs(xyz[:, 0].permute(0, 2, 3, 1).cpu().numpy(), ref) / scale, 2e-5)
 
 
 # ---- convolution over token rows (UNET building block) ------------------------------------------------------
@@ -1121,7 +1208,7 @@ def test_conv_rows_h3_vs_torch(kind):
     assert float(got[:, :h_out].abs().max()) == 0.0 and float(got[:, h_out + T_out:].abs().max()) == 0.0  # halo
     got = got[:, h_out:h_out + T_out].permute(0, 2, 1)
     want = ref + bias.double()[None, :, None]
-    assert rel_l2(got.numpy(), want.numpy()) <= 2e-6, rel_l2(got.numpy(), want.numpy())
+    assert ok("conv_rows_h3_vs_torch.rel_l2.0", rel_l2(got.numpy(), want.numpy()), 2e-6), rel_l2(got.numpy(), want.numpy())
 
 
 # ---- MDM_UNET denoiser -------------------------------------------------------------
@@ -1154,7 +1241,7 @@ def test_unet_forward_vs_reference(cases):
     cfg = wrapped(x, t, y=dict(y, text_scale=tt(inp["text_scale"])), **kw).cpu().numpy()
     for mine, key in ((oc, "out_cond"), (ou, "out_uncond"), (cfg, "out_cfg")):
         assert np.isfinite(mine).all()
-        assert max_abs(mine, g[key]) <= 2e-4 and rel_l2(mine, g[key]) <= 2e-5, \
+        assert ok("unet_forward_vs_reference.max_abs.0", max_abs(mine, g[key]), 2e-4) and ok("unet_forward_vs_reference.rel_l2.0", rel_l2(mine, g[key]), 2e-5), \
             (key, max_abs(mine, g[key]), rel_l2(mine, g[key]))
 
 
@@ -1175,7 +1262,7 @@ def test_unet_vs_oracle_other_shapes(cases, B, T):
     want, _, _ = UnetOracle(sd).forward_cfg(x, t, enc, scale, obs, m)
     wrapped = sub("model.cfg_sampler").ClassifierFreeSampleModel(model)
     got = wrapped(tt(x), tt(t), y={"text_embed": tt(enc), "text_scale": tt(scale)}, obs_x0=tt(obs), obs_mask=tt(m)).cpu().numpy()
-    assert max_abs(got, want) <= 2e-4 and rel_l2(got, want) <= 2e-5, (max_abs(got, want), rel_l2(got, want))
+    assert ok("unet_vs_oracle_other_shapes.max_abs.0", max_abs(got, want), 2e-4) and ok("unet_vs_oracle_other_shapes.rel_l2.0", rel_l2(got, want), 2e-5), (max_abs(got, want), rel_l2(got, want))
 
 
 def test_unet_chain_vs_reference(cases):
@@ -1196,7 +1283,7 @@ def test_unet_chain_vs_reference(cases):
     diffusion.injected_noise = tt(ci["noise"])
     final = diffusion.p_sample_loop(wrapped, ci["x_T"].shape, noise=tt(ci["x_T"]), clip_denoised=False,
                                     model_kwargs={"y": y, "obs_x0": tt(ci["x0"]), "obs_mask": obs_mask}).cpu().numpy()
-    assert rel_l2(final, g["final"]) <= 1e-4, rel_l2(final, g["final"])
+    assert ok("unet_chain_vs_reference.rel_l2.0", rel_l2(final, g["final"]), 1e-4), rel_l2(final, g["final"])
 
 
 def test_unet_vjp_vs_reference_autograd(cases):
@@ -1212,16 +1299,16 @@ def test_unet_vjp_vs_reference_autograd(cases):
     z = tt(vi["x"]).requires_grad_(True)
     with torch.enable_grad():
         out = wrapped(z, tt(vi["t"]), y=y, **kw)
-        assert rel_l2(out.detach().cpu().numpy(), g["out"]) <= 2e-5
+        assert ok("unet_vjp_vs_reference_autograd.rel_l2.0", rel_l2(out.detach().cpu().numpy(), g["out"]), 2e-5)
         gx, = torch.autograd.grad((out * tt(vi["gout"])).sum(), z)
     gx = gx.cpu().numpy()
     assert float(np.abs(gx[vi["obs_mask"]]).max()) == 0.0          # observed entries are replaced by obs_x0
-    assert rel_l2(gx, g["gx"]) <= 5e-5, rel_l2(gx, g["gx"])
+    assert ok("unet_vjp_vs_reference_autograd.rel_l2.1", rel_l2(gx, g["gx"]), 5e-5), rel_l2(gx, g["gx"])
     eng = model._engine            # the engine (and activation stash) of the forward pass above
     assert eng is not None and eng.want_grad
     for k in (1e-12, 1e9):
         gk = eng.mdm_vjp(tt(vi["gout"] * np.float32(k))).cpu().numpy().astype(np.float64) / k
-        assert rel_l2(gk, g["gx"]) <= 5e-5, (k, rel_l2(gk, g["gx"]))
+        assert ok("unet_vjp_vs_reference_autograd.rel_l2.2", rel_l2(gk, g["gx"]), 5e-5), (k, rel_l2(gk, g["gx"]))
 
 
 def make_unet_attention(cases):
@@ -1253,7 +1340,7 @@ def test_unet_attention_forward_and_vjp_vs_reference(cases):
     cfg = wrapped(x, t, y=dict(y, text_scale=tt(inp["text_scale"])), **kw).cpu().numpy()
     for mine, key in ((oc, "out_cond"), (ou, "out_uncond"), (cfg, "out_cfg")):
         assert np.isfinite(mine).all()
-        assert max_abs(mine, g[key]) <= 2e-4 and rel_l2(mine, g[key]) <= 2e-5, \
+        assert ok("unet_attention_forward_and_vjp_vs_reference.max_abs.0", max_abs(mine, g[key]), 2e-4) and ok("unet_attention_forward_and_vjp_vs_reference.rel_l2.0", rel_l2(mine, g[key]), 2e-5), \
             (key, max_abs(mine, g[key]), rel_l2(mine, g[key]))
     z = tt(inp["x"]).requires_grad_(True)
     with torch.enable_grad():
@@ -1261,11 +1348,11 @@ def test_unet_attention_forward_and_vjp_vs_reference(cases):
         gx, = torch.autograd.grad((out * tt(inp["gout"])).sum(), z)
     gx = gx.cpu().numpy()
     assert float(np.abs(gx[inp["obs_mask"]]).max()) == 0.0
-    assert rel_l2(gx, g["gx"]) <= 5e-5, rel_l2(gx, g["gx"])
+    assert ok("unet_attention_forward_and_vjp_vs_reference.rel_l2.1", rel_l2(gx, g["gx"]), 5e-5), rel_l2(gx, g["gx"])
     eng = model._engine
     for k in (1e-12, 1e9):   # linear in gout: the power-of-two gradient scale passes through the attention sites
         gk = eng.mdm_vjp(tt(inp["gout"] * np.float32(k))).cpu().numpy().astype(np.float64) / k
-        assert rel_l2(gk, g["gx"]) <= 5e-5, (k, rel_l2(gk, g["gx"]))
+        assert ok("unet_attention_forward_and_vjp_vs_reference.rel_l2.2", rel_l2(gk, g["gx"]), 5e-5), (k, rel_l2(gk, g["gx"]))
 
 
 @pytest.mark.parametrize("B,T", [(3, 100), (1, 224)])
@@ -1284,7 +1371,7 @@ def test_unet_attention_vs_oracle_other_shapes(cases, B, T):
     want, _, _ = UnetOracle(sd).forward_cfg(x, t, enc, scale, obs, m)
     wrapped = sub("model.cfg_sampler").ClassifierFreeSampleModel(model)
     got = wrapped(tt(x), tt(t), y={"text_embed": tt(enc), "text_scale": tt(scale)}, obs_x0=tt(obs), obs_mask=tt(m)).cpu().numpy()
-    assert max_abs(got, want) <= 2e-4 and rel_l2(got, want) <= 2e-5, (max_abs(got, want), rel_l2(got, want))
+    assert ok("unet_attention_vs_oracle_other_shapes.max_abs.0", max_abs(got, want), 2e-4) and ok("unet_attention_vs_oracle_other_shapes.rel_l2.0", rel_l2(got, want), 2e-5), (max_abs(got, want), rel_l2(got, want))
 
 
 @pytest.mark.parametrize("fuse", ["0", "3"])
@@ -1297,7 +1384,7 @@ def test_unet_forward_groupnorm_fusion_modes(cases, monkeypatch, fuse):
     wrapped = sub("model.cfg_sampler").ClassifierFreeSampleModel(model)
     cfg = wrapped(tt(inp["x"]), tt(inp["t"]), y={"text_embed": tt(inp["enc_text"]), "text_scale": tt(inp["text_scale"])},
                   obs_x0=tt(inp["obs_x0"]), obs_mask=tt(inp["obs_mask"])).cpu().numpy()
-    assert max_abs(cfg, g["out_cfg"]) <= 2e-4 and rel_l2(cfg, g["out_cfg"]) <= 2e-5, rel_l2(cfg, g["out_cfg"])
+    assert ok("unet_forward_groupnorm_fusion_modes.max_abs.0", max_abs(cfg, g["out_cfg"]), 2e-4) and ok("unet_forward_groupnorm_fusion_modes.rel_l2.0", rel_l2(cfg, g["out_cfg"]), 2e-5), rel_l2(cfg, g["out_cfg"])
 
 
 def test_unet_xl_geometry_vs_torch_port(cases):
@@ -1332,13 +1419,13 @@ def test_unet_xl_geometry_vs_torch_port(cases):
     y = {"text_embed": tt(enc), "text_scale": tt(scale)}
     with torch.no_grad():   # plain forward (split-K at the coarse levels, no stash)
         plain = net(tt(x), tt(t), y=y, obs_x0=tt(obs), obs_mask=tt(m)).cpu().numpy()
-    assert max_abs(plain, want_out.detach().numpy()) <= 2e-4 and rel_l2(plain, want_out.detach().numpy()) <= 2e-5
+    assert ok("unet_xl_geometry_vs_torch_port.max_abs.0", max_abs(plain, want_out.detach().numpy()), 2e-4) and ok("unet_xl_geometry_vs_torch_port.rel_l2.0", rel_l2(plain, want_out.detach().numpy()), 2e-5)
     z = tt(x).requires_grad_(True)
     with torch.enable_grad():
         out = net(z, tt(t), y=y, obs_x0=tt(obs), obs_mask=tt(m))
         got, = torch.autograd.grad((out * tt(gout)).sum(), z)
-    assert rel_l2(out.detach().cpu().numpy(), want_out.detach().numpy()) <= 2e-5
-    assert rel_l2(got.cpu().numpy(), want_gx.numpy()) <= 5e-5, rel_l2(got.cpu().numpy(), want_gx.numpy())
+    assert ok("unet_xl_geometry_vs_torch_port.rel_l2.1", rel_l2(out.detach().cpu().numpy(), want_out.detach().numpy()), 2e-5)
+    assert ok("unet_xl_geometry_vs_torch_port.rel_l2.2", rel_l2(got.cpu().numpy(), want_gx.numpy()), 5e-5), rel_l2(got.cpu().numpy(), want_gx.numpy())
 
 
 @pytest.mark.parametrize("B,T,keyframe,cfg", [(3, 100, True, False), (1, 224, False, True), (2, 33, True, True)])
@@ -1381,8 +1468,8 @@ def test_unet_vjp_other_configs_vs_torch_port(cases, B, T, keyframe, cfg):
     with torch.enable_grad():
         out = net(z, tt(t), y=y, **gkw)
         got, = torch.autograd.grad((out * tt(gout)).sum(), z)
-    assert rel_l2(out.detach().cpu().numpy(), oc.detach().numpy()) <= 2e-5
-    assert rel_l2(got.cpu().numpy(), want.numpy()) <= 5e-5, rel_l2(got.cpu().numpy(), want.numpy())
+    assert ok("unet_vjp_other_configs_vs_torch_port.rel_l2.0", rel_l2(out.detach().cpu().numpy(), oc.detach().numpy()), 2e-5)
+    assert ok("unet_vjp_other_configs_vs_torch_port.rel_l2.1", rel_l2(got.cpu().numpy(), want.numpy()), 5e-5), rel_l2(got.cpu().numpy(), want.numpy())
 
 
 def test_unet_recon_guidance_chain_vs_reference(cases):
@@ -1404,7 +1491,7 @@ def test_unet_recon_guidance_chain_vs_reference(cases):
     final = diffusion.p_sample_loop(wrapped, ci["x_T"].shape, noise=tt(ci["x_T"]), clip_denoised=False,
                                     model_kwargs={"y": y, "obs_x0": tt(ci["x0"]), "obs_mask": obs_mask}).cpu().numpy()
     assert np.isfinite(final).all()
-    assert rel_l2(final, g["final"]) <= 2e-4, rel_l2(final, g["final"])
+    assert ok("unet_recon_guidance_chain_vs_reference.rel_l2.0", rel_l2(final, g["final"]), 2e-4), rel_l2(final, g["final"])
 
 
 def test_keyframes_mask_built_on_device(cases):
