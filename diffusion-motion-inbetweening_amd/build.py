@@ -34,6 +34,7 @@ UNITS = {
     "attention_f32.hip": [],
     "attention_h3.hip": [],
     "attention_bwd_f32.hip": [],
+    "attention_bwd_h3.hip": [],
     "unet.hip": [],
     "clip_text.hip": [],
     "elementwise.hip": [],

@@ -357,7 +357,7 @@ int run_layers_bwd(cmdi_engine* e, int seq0, int nseq, hipStream_t s) {
             }
             HIPCHK(launch_attention_bwd_h3(st.qkvS + r0 * 6 * d, st.attn + r0 * d,
                                            st.row_stats + (size_t)seq0 * e->H * S * 2, dH, dOS, dqkvS,
-                                           e->drowdot + (size_t)seq0 * e->H * S, nseq, S, e->H, s));
+                                           e->drowdot + attention_bwd_scratch_floats(seq0, S, e->H), nseq, S, e->H, s));
             {   // dA = dqkv · Wqkv + dB
                 H3Params p = hp(dqkvS, w.in_wTs, dA, nullptr, d, 3 * d);
                 p.R = dB;

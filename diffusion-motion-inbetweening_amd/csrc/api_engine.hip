@@ -232,7 +232,10 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
         }
         ALLOC(e->dA, Mmax * d); ALLOC(e->dB, Mmax * d); ALLOC(e->dH, Mmax * d);
         ALLOC(e->dqkv, Mmax * 3 * d); ALLOC(e->dffn, Mmax * f);
-        ALLOC(e->drowdot, nseq * e->H * Smax);
+        {   // f32 backward: D per (head, query); f16x3 backward: per-tile row statistics (attention_bwd_h3.hip)
+            const size_t plain = (size_t)nseq * e->H * Smax, tiles = attention_bwd_scratch_floats((int)nseq, (int)Smax, e->H);
+            ALLOC(e->drowdot, plain > tiles ? plain : tiles);
+        }
         ALLOC(e->gout, nseq * C * e->Tmax); ALLOC(e->gx, nseq * C * e->Tmax);
     }
     return CMDI_OK;

@@ -232,7 +232,7 @@ int cmdi_attention_vjp_h3(const void* d_qkv_split, const float* d_dout, void* d_
     float* o_fwd = d_work;                                  // [M, d]
     _Float16* dout_s = reinterpret_cast<_Float16*>(o_fwd + M * d);   // [M, 2d] halves = M*d floats
     float* row_stats = o_fwd + 2 * M * d;                   // [n_seq*H*S, 2]
-    float* rowdot = row_stats + 2 * nhs;                    // [n_seq*H*S]
+    float* rowdot = row_stats + 2 * nhs;                    // attention_bwd_scratch_floats(): <= 3.5 * n_seq*H*S + 96*n_seq*H
     const _Float16* qs = static_cast<const _Float16*>(d_qkv_split);
     HIPCHK(launch_attention_h3(qs, o_fwd, nullptr, nullptr, row_stats, n_seq, seq_len, n_heads, s));
     HIPCHK(launch_split_f16(d_dout, dout_s, (int64_t)M, (int)d, (int)d, nullptr, s));

@@ -376,474 +376,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const _Float16
     }
 }
 
-// =====================================================================================================
-// dX-only backward of the attention core on the f16 matrix pipe (reconstruction-guidance VJP; replaces
-// torch.autograd through torch MultiheadAttention, reference call site diffusion/gaussian_diffusion.py:
-// 411-416).  With P = softmax(S), S = scale·Q Kᵀ, O = P V:
-//   dV = Pᵀ dO,  dP = dO Vᵀ,  D[q] = sum_d dO·O,  dS = P ∘ (dP − D),  dQ = scale·dS K,  dK = scale·dSᵀ Q.
-// P is recomputed from the forward's row statistics (max, 1/sum); nothing S×S is stored; no atomics.
-// Same two-kernel split as attention_bwd_f32.hip (a wave owns 32 rows of the axis it reduces INTO), same
-// operand tricks as the forward kernel above: products oriented so that a lane owns one row of that axis
-// and its 16 accumulator registers ARE the B operand of the follow-up product; the transposed A operands
-// (Kᵀ, Qᵀ, dOᵀ) come from row-major LDS tiles through ds_read_b64_tr_b16.  dS has no bound, so its products
-// use the scaled-lo split with two accumulators; P (in [0,1]) uses the single-accumulator form.
-// Register budget: one wave per SIMD (launch_bounds(256, 1)).
-#ifdef CMDI_PROBES
-// bench-only cycle stamps of the backward kernels (probes build; tools/attn_bwd_bench.py reads them through
-// cmdi_probe_bwd_stamps): [kernel][block][slot], written by thread 0 of a block
-__device__ long long g_bwd_stamps[3][1024][24];
-#define BWD_STAMP(kern, slot)                                                                                   \
-    do {                                                                                                        \
-        if (threadIdx.x == 0 && blockIdx.x < 1024) {                                                            \
-            asm volatile("" ::: "memory");                                                                      \
-            g_bwd_stamps[kern][blockIdx.x][slot] = (long long)__builtin_readcyclecounter();                     \
-        }                                                                                                       \
-    } while (0)
-#else
-#define BWD_STAMP(kern, slot) do { } while (0)
-#endif
-
-namespace {
-constexpr int BW = 4;   // waves per backward block
-
-// 32 rows x 512 B (one head of a split [rows, ld] matrix, columns coloff..) -> LDS tile, swizzled as K/V
-__device__ __forceinline__ void stage_tile(char* dst, const _Float16* __restrict__ base, size_t ld,
-                                           int coloff, int row0, int S, int wave, int lane) {
-#pragma unroll
-    for (int it = 0; it < 16 / BW; ++it) {
-        const int g = it * BW + wave;
-        const int rl = 2 * g + (lane >> 5);
-        const int t = (lane & 31) ^ kswz(rl);
-        int row = row0 + rl;
-        row = row < S ? row : S - 1;
-        const _Float16* src = base + (size_t)row * ld + coloff + t * 8;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(dst + g * 1024), 16, 0, 0);
-    }
-}
-
-// B-operand fragments of one row (lane = row l31, k-group hi): dims 16 ks + 8 hi .. + 7, hi and lo planes
-__device__ __forceinline__ void load_row_frags(h8 fh[8], h8 fl[8], const _Float16* __restrict__ rowp, int hi) {
-    const _Float16* p = rowp + 8 * hi;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-        const _Float16* pch = p + (ks >> 1) * 64 + (ks & 1) * 16;
-        fh[ks] = *reinterpret_cast<const h8*>(pch);
-        fl[ks] = *reinterpret_cast<const h8*>(pch + 32);
-    }
-}
-
-// raw = tile · fragᵀ over the 128 head dims (A = tile rows from LDS, B = row fragments in registers), split
-// products; returns hi·hi + (hi·lo + lo·hi)·2^-11
-template <bool BATCH = true>
-__device__ __forceinline__ f32x16 tile_dot_h3(const char* tile, const h8 fh[8], const h8 fl[8], int l31, int hi) {
-    f32x16 a0, a1, a2;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; a2[r] = 0.f; }
-    const int fk = kswz(l31);
-    const char* rowp = tile + l31 * ROWB;
-    // two half-passes of 4 k-steps: the 8 fragment reads of a half are issued back to back, then its 12 MFMAs —
-    // one LDS round trip per half instead of one per read (at one wave per SIMD nothing else hides that latency)
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        h8 th[4], tl[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int ks = half * 4 + q;
-            const int t = (ks >> 1) * 8 + (ks & 1) * 2 + hi;
-            th[q] = *reinterpret_cast<const h8*>(rowp + ((t ^ fk) << 4));
-            tl[q] = *reinterpret_cast<const h8*>(rowp + (((t + 4) ^ fk) << 4));
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int ks = half * 4 + q;
-            a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[q], fh[ks], a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[q], fl[ks], a1, 0, 0, 0);
-            a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl[q], fh[ks], a2, 0, 0, 0);
-        }
-        if constexpr (BATCH) {   // (the dV kernel runs two waves per SIMD in 248 registers: pinning costs it spills)
-            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);    // 8 DS reads
-            __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);   // 12 MFMAs
-        }
-    }
-    f32x16 o;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] = a0[r] + (a1[r] + a2[r]) * kLoInv;
-    return o;
-}
-
-// transposed A-operand fragments (dims db*32.. x 16 rows of k-step kk) of a row-major LDS tile, both planes.
-// Per-lane byte offsets are precomputed once (TrOff): the swizzle only touches slot bits 0-3, so k-step kk
-// (+16 rows = +8 KiB) and the dim-block pair (db >> 1, +256 B) are immediate offsets.
-struct TrOff { int o[2][2][2]; };   // [db & 1][plane][row half (+8 rows)]
-__device__ __forceinline__ TrOff make_troff(int lane) {
-    const int G = lane >> 4, L = lane & 15;
-    TrOff t;
-#pragma unroll
-    for (int d1 = 0; d1 < 2; ++d1)
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-            for (int rh = 0; rh < 2; ++rh) {
-                const int r = 4 * (G >> 1) + (L >> 2) + 8 * rh;
-                const int slot = d1 * 8 + pl * 4 + 2 * (G & 1) + ((L & 3) >> 1);
-                t.o[d1][pl][rh] = r * ROWB + ((slot ^ kswz(r)) << 4) + (L & 1) * 8;
-            }
-    return t;
-}
-__device__ __forceinline__ void tr_frags(h8& fh, h8& fl, const char* tile, int db, int kk, const TrOff& t) {
-    const char* p = tile + kk * (16 * ROWB) + (db >> 1) * 256;
-    fh = tr_pair(p + t.o[db & 1][0][0], p + t.o[db & 1][0][1]);
-    fl = tr_pair(p + t.o[db & 1][1][0], p + t.o[db & 1][1][1]);
-}
-
-// out0/out1[db] += tileᵀ · x  with x (unbounded) split as hi + lo'·2^-11: two accumulators per dim block
-__device__ __forceinline__ void acc_unbounded(f32x16 o0[4], f32x16 o1[4], const float x[16], const char* tile,
-                                              const TrOff& lane) {
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        h8 xh, xl;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            _Float16 a, b;
-            split_f16(x[8 * kk + e], a, b);
-            xh[e] = a; xl[e] = b;
-        }
-        h8 th[4], tl[4];
-#pragma unroll
-        for (int db = 0; db < 4; ++db) tr_frags(th[db], tl[db], tile, db, kk, lane);
-#pragma unroll
-        for (int db = 0; db < 4; ++db) o0[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[db], xh, o0[db], 0, 0, 0);
-#pragma unroll
-        for (int db = 0; db < 4; ++db) o1[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[db], xl, o1[db], 0, 0, 0);
-#pragma unroll
-        for (int db = 0; db < 4; ++db) o1[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl[db], xh, o1[db], 0, 0, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);   // the 16 transpose reads of this k-step back to back,
-        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);   // then its 12 MFMAs: one LDS round trip per k-step
-    }
-}
-
-// out[db] += tileᵀ · p  with p in [0, 1]: p = p_hi + p_lo (unscaled), one accumulator (see the forward kernel)
-__device__ __forceinline__ void acc_prob(f32x16 o[4], const float p[16], const char* tile, const TrOff& lane) {
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        h8 ph, pl, ps;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float pv = p[8 * kk + e];
-            const _Float16 a = (_Float16)pv;
-            ph[e] = a;
-            pl[e] = (_Float16)(pv - (float)a);
-        }
-        ps = ph * (_Float16)kLoInv;
-        h8 th[4], tl[4];
-#pragma unroll
-        for (int db = 0; db < 4; ++db) tr_frags(th[db], tl[db], tile, db, kk, lane);
-#pragma unroll
-        for (int db = 0; db < 4; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[db], ph, o[db], 0, 0, 0);
-#pragma unroll
-        for (int db = 0; db < 4; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[db], pl, o[db], 0, 0, 0);
-#pragma unroll
-        for (int db = 0; db < 4; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl[db], ps, o[db], 0, 0, 0);
-    }
-}
-
-// (lane = row, registers = dims) accumulators -> split row [.. 512 B ..] at dst (+ 4 hi applied by caller)
-__device__ __forceinline__ void store_split_head(_Float16* dst, const f32x16 v[4]) {
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            h4 oh, ol;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                _Float16 a, c;
-                split_f16(v[db][4 * g4 + e], a, c);
-                oh[e] = a; ol[e] = c;
-            }
-            *reinterpret_cast<h4*>(dst + db * 64 + g4 * 8) = oh;
-            *reinterpret_cast<h4*>(dst + db * 64 + g4 * 8 + 32) = ol;
-        }
-}
-}  // namespace
-
-// Backward grid: 2 blocks (row halves) per (sequence, head), both streaming the same tiles of the other operand.  Linear
-// block ids are dealt round-robin over the 8 XCDs, so ids i and i + 8 share an XCD and start together: pairing the two
-// halves that way lets the second reader find the tiles in that XCD's L2 instead of fetching them from HBM again.
-__device__ __forceinline__ void bwd_block(int id, int nbh, int& bh, int& half) {
-    const int full = nbh & ~7;
-    if (id < 2 * full) { bh = ((id >> 4) << 3) | (id & 7); half = (id >> 3) & 1; }
-    else { const int r = id - 2 * full; bh = full + (r >> 1); half = r & 1; }
-}
-
-// ---- dQ: wave = 32 queries, loop over key tiles --------------------------------------------------------
-__global__ __launch_bounds__(64 * BW, 1) void attn_bwd_q_h3_kernel(const _Float16* __restrict__ qkv,
-                                                                   const _Float16* __restrict__ d_o,
-                                                                   const float* __restrict__ row_stats,
-                                                                   const float* __restrict__ rowdot,
-                                                                   _Float16* __restrict__ d_qkv, int S, int H,
-                                                                   float scale) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];  // [2][K tile | V tile]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, hi = lane >> 5;
-    int bh, half;
-    bwd_block(blockIdx.x, gridDim.x >> 1, bh, half);
-    if (half * BW * 32 >= S) return;   // short sequences: the second half block has no rows (whole block, before any barrier)
-    const int b = bh / H, h = bh % H;
-    const int d_model = H * DH;
-    const size_t ld = 6 * (size_t)d_model, ldo = 2 * (size_t)d_model;
-    const int qoff = 2 * h * DH, koff = 2 * (d_model + h * DH), voff = 2 * (2 * d_model + h * DH);
-    const _Float16* base = qkv + (size_t)b * S * ld;
-    const int q0 = (half * BW + wave) * 32;
-    const bool active = q0 < S;
-    const int q = q0 + l31;
-    const bool qok = active && q < S;
-    const int qc = q < S ? q : S - 1;
-    const int nkt = (S + KBLK - 1) / KBLK;
-
-    BWD_STAMP(0, 0);
-    h8 qh[8], ql[8], doh[8], dol[8];
-    load_row_frags(qh, ql, base + (size_t)qc * ld + qoff, hi);
-    load_row_frags(doh, dol, d_o + ((size_t)b * S + qc) * ldo + qoff, hi);
-    const float mx = row_stats[((size_t)bh * S + qc) * 2] * 1.4426950408889634f;   // log2 units
-    const float inv = row_stats[((size_t)bh * S + qc) * 2 + 1];
-    const float dsum = rowdot[(size_t)bh * S + qc];
-    const float scale2 = scale * 1.4426950408889634f;
-    const TrOff troff = make_troff(lane);
-
-    f32x16 dq0[4], dq1[4];
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { dq0[d][r] = 0.f; dq1[d][r] = 0.f; }
-
-    stage_tile(lds, base, ld, koff, 0, S, wave, lane);
-    stage_tile(lds + TILE, base, ld, voff, 0, S, wave, lane);
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
-    BWD_STAMP(0, 1);
-    for (int t = 0; t < nkt; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nkt) {
-            stage_tile(lds + (cur ^ 1) * STAGE, base, ld, koff, (t + 1) * KBLK, S, wave, lane);
-            stage_tile(lds + (cur ^ 1) * STAGE + TILE, base, ld, voff, (t + 1) * KBLK, S, wave, lane);
-        }
-        if (active) {
-            const char* kt = lds + cur * STAGE;
-            const char* vt = kt + TILE;
-            const f32x16 st = tile_dot_h3(kt, qh, ql, l31, hi);     // Sᵀ (unscaled): lane = query, regs = keys
-            if (t == 1) BWD_STAMP(0, 12);
-            const f32x16 dpt = tile_dot_h3(vt, doh, dol, l31, hi);  // dPᵀ
-            if (t == 1) BWD_STAMP(0, 13);
-            float ds[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = t * KBLK + mfma32_row(r, lane);
-                const float p = (key < S && qok) ? __builtin_amdgcn_exp2f(st[r] * scale2 - mx) * inv : 0.f;
-                ds[r] = p * (dpt[r] - dsum) * scale;
-            }
-            if (t == 1) BWD_STAMP(0, 14);
-            acc_unbounded(dq0, dq1, ds, kt, troff);                 // dQᵀ += Kᵀ · dSᵀ
-            if (t == 1) BWD_STAMP(0, 15);
-        }
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        __syncthreads();
-        BWD_STAMP(0, 2 + t);
-    }
-    if (qok) {
-#pragma unroll
-        for (int d = 0; d < 4; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dq0[d][r] += dq1[d][r] * kLoInv;
-        store_split_head(d_qkv + ((size_t)b * S + q) * ld + qoff + 4 * hi, dq0);
-    }
-    BWD_STAMP(0, 10);
-#ifdef CMDI_PROBES
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-    BWD_STAMP(0, 11);
-}
-
-// ---- dK / dV: wave = 32 keys, loop over query tiles ------------------------------------------------------
-// Two instantiations (the fused form needs ~650 registers per lane and spills): WHICH = 0 computes dK (needs
-// K, V fragments and the two-accumulator dK: 512 registers, one wave per SIMD), WHICH = 1 computes dV (K fragments
-// only, one accumulator: fits 248 registers, so two blocks share a CU).
-template <int WHICH>
-__global__ __launch_bounds__(64 * BW, WHICH == 1 ? 2 : 1) void attn_bwd_kv_h3_kernel(const _Float16* __restrict__ qkv,
-                                                                    const _Float16* __restrict__ d_o,
-                                                                    const float* __restrict__ row_stats,
-                                                                    const float* __restrict__ rowdot,
-                                                                    _Float16* __restrict__ d_qkv, int S, int H,
-                                                                    float scale) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];  // [2][Q tile | dO tile | m, inv, D (3 x 32 f32)]
-    constexpr int BSTAGE = STAGE + 512;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, hi = lane >> 5;
-    int bh, half;
-    bwd_block(blockIdx.x, gridDim.x >> 1, bh, half);
-    if (half * BW * 32 >= S) return;   // short sequences: the second half block has no rows (whole block, before any barrier)
-    const int b = bh / H, h = bh % H;
-    const int d_model = H * DH;
-    const size_t ld = 6 * (size_t)d_model, ldo = 2 * (size_t)d_model;
-    const int qoff = 2 * h * DH, koff = 2 * (d_model + h * DH), voff = 2 * (2 * d_model + h * DH);
-    const _Float16* base = qkv + (size_t)b * S * ld;
-    const _Float16* dobase = d_o + (size_t)b * S * ldo;
-    const int k0 = (half * BW + wave) * 32;
-    const bool active = k0 < S;
-    const int key = k0 + l31;
-    const bool kok = active && key < S;
-    const int kc = key < S ? key : S - 1;
-    const int nqt = (S + KBLK - 1) / KBLK;
-    const float scale2 = scale * 1.4426950408889634f;
-    const TrOff troff = make_troff(lane);
-
-    BWD_STAMP(1 + WHICH, 0);
-    h8 kh[8], kl[8], vh[8], vl[8];
-    load_row_frags(kh, kl, base + (size_t)kc * ld + koff, hi);
-    if constexpr (WHICH == 0) load_row_frags(vh, vl, base + (size_t)kc * ld + voff, hi);
-
-    f32x16 acc0[4], acc1[4];   // dK: hi / cross accumulators; dV: acc0 only
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[d][r] = 0.f; acc1[d][r] = 0.f; }
-
-    auto stage_q = [&](int t, int buf) {
-        char* st = lds + buf * BSTAGE;
-        if constexpr (WHICH == 0) stage_tile(st, base, ld, qoff, t * KBLK, S, wave, lane);
-        else {   // dV only needs Q for the scores; dO is what gets transposed
-            stage_tile(st, base, ld, qoff, t * KBLK, S, wave, lane);
-        }
-        stage_tile(st + TILE, dobase, ldo, qoff, t * KBLK, S, wave, lane);
-        if (tid < 32) {
-            float* sp = reinterpret_cast<float*>(st + STAGE);
-            const int qq = t * KBLK + tid;
-            const bool ok = qq < S;
-            sp[tid] = ok ? row_stats[((size_t)bh * S + qq) * 2] * 1.4426950408889634f : 0.f;
-            sp[32 + tid] = ok ? row_stats[((size_t)bh * S + qq) * 2 + 1] : 0.f;   // 0 masks q >= S
-            sp[64 + tid] = ok ? rowdot[(size_t)bh * S + qq] : 0.f;
-        }
-    };
-    stage_q(0, 0);
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
-    BWD_STAMP(1 + WHICH, 1);
-    for (int t = 0; t < nqt; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nqt) stage_q(t + 1, cur ^ 1);
-        if (active) {
-            const char* qt = lds + cur * BSTAGE;
-            const char* dot = qt + TILE;
-            const float* sp = reinterpret_cast<const float*>(qt + STAGE);
-            const f32x16 s = tile_dot_h3<WHICH == 0>(qt, kh, kl, l31, hi);     // S (unscaled): lane = key, regs = queries
-            if (t == 1) BWD_STAMP(1 + WHICH, 12);
-            float p[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int qi = mfma32_row(r, lane);
-                p[r] = kok ? __builtin_amdgcn_exp2f(s[r] * scale2 - sp[qi]) * sp[32 + qi] : 0.f;
-            }
-            if constexpr (WHICH == 1) {
-                acc_prob(acc0, p, dot, troff);                     // dVᵀ += dOᵀ · P
-            } else {
-                const f32x16 dp = tile_dot_h3(dot, vh, vl, l31, hi);   // dP
-                if (t == 1) BWD_STAMP(1 + WHICH, 13);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) p[r] = p[r] * (dp[r] - sp[64 + mfma32_row(r, lane)]) * scale;
-                if (t == 1) BWD_STAMP(1 + WHICH, 14);
-                acc_unbounded(acc0, acc1, p, qt, troff);           // dKᵀ += Qᵀ · dS
-            }
-            if (t == 1) BWD_STAMP(1 + WHICH, 15);
-        }
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        __syncthreads();
-        BWD_STAMP(1 + WHICH, 2 + t);
-    }
-    if (kok) {
-        if constexpr (WHICH == 0) {
-#pragma unroll
-            for (int d = 0; d < 4; ++d)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc0[d][r] += acc1[d][r] * kLoInv;
-        }
-        _Float16* row = d_qkv + ((size_t)b * S + key) * ld + 4 * hi;
-        store_split_head(row + (WHICH == 0 ? koff : voff), acc0);
-    }
-    BWD_STAMP(1 + WHICH, 10);
-#ifdef CMDI_PROBES
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-    BWD_STAMP(1 + WHICH, 11);
-}
-
-// D[(b*H + h)*S + q] = sum over the head's 128 dims of dO·O (fp32); one wave per token row, d_model = H*128
-__global__ __launch_bounds__(256) void rowdot_heads_kernel(const float* __restrict__ d_o, const float* __restrict__ o,
-                                                           float* __restrict__ out, int rows, int S, int H) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const int d_model = H * DH;
-    const int b = row / S, q = row - b * S;
-    for (int c0 = 0; c0 < d_model; c0 += 512) {   // 64 lanes x 8 columns per pass = 4 heads
-        const int c = c0 + lane * 8;
-        float acc = 0.f;
-        if (c < d_model) {
-            const float4 a0 = *reinterpret_cast<const float4*>(d_o + (size_t)row * d_model + c);
-            const float4 a1 = *reinterpret_cast<const float4*>(d_o + (size_t)row * d_model + c + 4);
-            const float4 b0 = *reinterpret_cast<const float4*>(o + (size_t)row * d_model + c);
-            const float4 b1 = *reinterpret_cast<const float4*>(o + (size_t)row * d_model + c + 4);
-            acc = ((a0.x * b0.x + a0.y * b0.y) + (a0.z * b0.z + a0.w * b0.w)) +
-                  ((a1.x * b1.x + a1.y * b1.y) + (a1.z * b1.z + a1.w * b1.w));
-        }
-#pragma unroll
-        for (int o2 = 8; o2 > 0; o2 >>= 1) acc += __shfl_xor(acc, o2, 64);   // 16 lanes = one head
-        const int hh = c / DH;
-        if ((lane & 15) == 0 && c < d_model) out[((size_t)b * H + hh) * S + q] = acc;
-    }
-}
-
-// d_qkv_split [M, 6d] (split rows) from: qkv_split (forward stash), d_out_split [M, 2d] + d_out fp32 + o_fwd fp32
-// (for D), row_stats; d_rowdot is a [n_seq*H*S] scratch
-hipError_t launch_attention_bwd_h3(const _Float16* qkv_split, const float* o_fwd, const float* row_stats,
-                                   const float* d_out, const _Float16* d_out_split, _Float16* d_qkv_split,
-                                   float* d_rowdot, int n_seq, int S, int H, hipStream_t stream) {
-    if (S < 1 || S > 224) return hipErrorInvalidValue;
-    const float scale = 1.0f / sqrtf((float)DH);
-    constexpr size_t lds_q = 2ull * STAGE, lds_kv = 2ull * (STAGE + 512);
-    static bool attr_done_dev[kMaxDevices] = {};
-    bool& attr_done = attr_done_dev[device_slot()];
-    if (!attr_done) {
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_q_h3_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kv_h3_kernel<0>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
-        hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kv_h3_kernel<1>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
-        if (e1 != hipSuccess) return e1;
-        if (e2 != hipSuccess) return e2;
-        if (e3 != hipSuccess) return e3;
-        attr_done = true;
-    }
-    const int rows = n_seq * S;
-    hipLaunchKernelGGL(rowdot_heads_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, d_out, o_fwd, d_rowdot,
-                       rows, S, H);
-    static_assert(32 * BW * 2 >= 224, "two row halves cover S <= 224");
-    const dim3 grid(2 * n_seq * H), block(64 * BW);
-    hipLaunchKernelGGL(attn_bwd_q_h3_kernel, grid, block, lds_q, stream, qkv_split, d_out_split, row_stats,
-                       d_rowdot, d_qkv_split, S, H, scale);
-    hipLaunchKernelGGL(attn_bwd_kv_h3_kernel<0>, grid, block, lds_kv, stream, qkv_split, d_out_split, row_stats,
-                       d_rowdot, d_qkv_split, S, H, scale);
-    hipLaunchKernelGGL(attn_bwd_kv_h3_kernel<1>, grid, block, lds_kv, stream, qkv_split, d_out_split, row_stats,
-                       d_rowdot, d_qkv_split, S, H, scale);
-    return hipGetLastError();
-}
-
-#ifdef CMDI_PROBES
-hipError_t read_bwd_stamps(void* host_dst) {
-    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_bwd_stamps), sizeof(long long) * 3 * 1024 * 24);
-}
-#endif
-
 template <int NW, int NS, int STAG = 0>
 static hipError_t launch_attention_h3_cfg(const _Float16* qkv_split, float* out, _Float16* out_split, int* range_flag,
                                           float* row_stats, int n_seq, int S, int H, int dbg, long head_rows,

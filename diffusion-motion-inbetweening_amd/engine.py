@@ -457,7 +457,8 @@ def attention_vjp_h3(qkv: torch.Tensor, dout: torch.Tensor, n_seq: int, seq_len:
     assert qkv.shape == (M, 3 * d) and dout.shape == (M, d) and dout.dtype == torch.float32 and dout.is_contiguous()
     qs = split_f16(qkv)
     dqs = torch.zeros((M, 6 * d), dtype=torch.float16, device=qkv.device)
-    work = torch.empty(2 * M * d + 3 * n_seq * n_heads * seq_len, dtype=torch.float32, device=qkv.device)
+    work = torch.empty(2 * M * d + n_seq * n_heads * (2 * seq_len + 96 * ((seq_len + 31) // 32)), dtype=torch.float32,
+                       device=qkv.device)
     with torch.cuda.device(qkv.device):
         N.check(lib.cmdi_attention_vjp_h3(N.ptr(qs), N.ptr(dout), N.ptr(dqs), N.ptr(work), n_seq, seq_len, n_heads,
                                           N.current_stream(qkv.device)))

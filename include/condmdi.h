@@ -307,7 +307,8 @@ int cmdi_attention_fwd_h3(const void* d_qkv_split, float* d_out, int32_t n_seq, 
 /* Input-VJP of the self-attention core alone on the f16 matrix pipe (test / bench hook; in the engine it runs inside
  * cmdi_mdm_vjp and replaces torch.autograd through torch MultiheadAttention at diffusion/gaussian_diffusion.py:411-416):
  * d_dqkv_split [n_seq*S, 6*H*128] split rows = (d out / d qkv)^T · d_dout, with d_dout fp32 [n_seq*S, H*128].  The forward
- * pass is re-run first for its row statistics.  d_work: n_seq*S*H*128*2 + n_seq*H*S*3 floats of scratch (16-B aligned). */
+ * pass is re-run first for its row statistics.  d_work: n_seq*S*H*128*2 + n_seq*H*(2*S + 96*ceil(S/32)) floats of scratch
+ * (16-B aligned). */
 int cmdi_attention_vjp_h3(const void* d_qkv_split, const float* d_dout, void* d_dqkv_split, float* d_work,
                           int32_t n_seq, int32_t seq_len, int32_t n_heads, cmdi_stream stream);
 /* Philox4x32-10 raw block (host, for known-answer tests): out[4] = philox(counter[4], key[2]). */

@@ -23,7 +23,7 @@ for n_seq in (64,):
     dout = torch.randn(M, d, device=dev)
     qs = eng.split_f16(qkv)
     dqs = torch.zeros(M, 6 * d, dtype=torch.float16, device=dev)
-    work = torch.empty(2 * M * d + 3 * n_seq * H * S, device=dev)
+    work = torch.empty(2 * M * d + n_seq * H * (2 * S + 96 * ((S + 31) // 32)), device=dev)
     st = N.current_stream(dev)
     call = lambda: N.check(lib.cmdi_attention_vjp_h3(N.ptr(qs), N.ptr(dout), N.ptr(dqs), N.ptr(work), n_seq, S, H, st))
     t_all = timeit(call, iters=20)
@@ -50,6 +50,9 @@ for n_seq in (64,):
                   f"kernel span {(s[:,11].max()-t0)} cycles", flush=True)
             print(f"    inside iteration 1: first product {f(s[:,12]-s[:,2]):.0f}  second {f(s[:,13]-s[:,12]):.0f}  "
                   f"valu {f(s[:,14]-s[:,13]):.0f}  accumulate {f(s[:,15]-s[:,14]):.0f}  wait+barrier {f(s[:,3]-s[:,15]):.0f}", flush=True)
+            if s[:, 16].max() > 0:
+                print(f"    accumulate detail: to first wait {f(s[:,16]-s[:,14]):.0f}  unit0 issue {f(s[:,17]-s[:,16]):.0f}  wait1 {f(s[:,18]-s[:,17]):.0f}  "
+                      f"unit1 issue {f(s[:,19]-s[:,18]):.0f}  wait2+unit2 {f(s[:,20]-s[:,19]):.0f}  wait3+unit3 {f(s[:,15]-s[:,20]):.0f}", flush=True)
             # start-time distribution: how many blocks started in the first wave
             st0 = np.sort(s[:, 0] - t0)
             print(f"    block starts (cycles after the first): median {st0[len(st0)//2]}  90% {st0[int(len(st0)*0.9)]}  max {st0[-1]}", flush=True)
