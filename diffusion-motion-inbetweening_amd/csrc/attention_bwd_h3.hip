@@ -108,15 +108,33 @@ __device__ __forceinline__ void nt_product(f32x16& c0, f32x16& c1, const char* a
                                            const char* brow, int hi) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
+    // Fragment reads in groups of 8 (G k-steps), each group requested BEFORE the previous group's MFMAs are issued: at one
+    // wave per SIMD nothing else hides an LDS round trip, and the compiler's own placement (a k-step's reads right behind
+    // the previous k-step's three MFMAs, then a wait for everything) leaves 96 cycles of cover for a longer latency.
+    constexpr int G = BREG ? 4 : 2, NG = 8 / G;
+    h8 th[8], tl[8], xh[8], xl[8];
+    auto fetch = [&](int g) __attribute__((always_inline)) {
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-        const h8 th = row_frag(arow, fk, ks, hi, 0), tl = row_frag(arow, fk, ks, hi, 1);
-        h8 xh, xl;
-        if constexpr (BREG) { xh = bh[ks]; xl = bl[ks]; }
-        else { xh = row_frag(brow, fk, ks, hi, 0); xl = row_frag(brow, fk, ks, hi, 1); }
-        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(th, xl, c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(th, xh, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl, xh, c1, 0, 0, 0);
+        for (int ks = g * G; ks < (g + 1) * G; ++ks) {
+            th[ks] = row_frag(arow, fk, ks, hi, 0);
+            tl[ks] = row_frag(arow, fk, ks, hi, 1);
+            if constexpr (!BREG) { xh[ks] = row_frag(brow, fk, ks, hi, 0); xl[ks] = row_frag(brow, fk, ks, hi, 1); }
+        }
+    };
+    fetch(0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) fetch(g + 1);
+#pragma unroll
+        for (int ks = g * G; ks < (g + 1) * G; ++ks) {
+            const h8 yh = BREG ? bh[ks] : xh[ks], yl = BREG ? bl[ks] : xl[ks];
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[ks], yl, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[ks], yh, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl[ks], yh, c1, 0, 0, 0);
+        }
+        if (g == 0) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);            // this group's reads (first group only)
+        if (g + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);        // the next group's reads
+        __builtin_amdgcn_sched_group_barrier(0x008, 3 * G, 0);                    // this group's MFMAs
     }
 }
 
@@ -312,7 +330,6 @@ __global__ __launch_bounds__(64 * BW, 1) void attn_bwd_kv_h3_kernel(const _Float
     const int k0 = (half * BW + wave) * 32;
     const bool active = k0 < S;         // wave-uniform
     const int key = k0 + l31;
-    const bool kok = active && key < S;
     const int kc = key < S ? key : S - 1;
     const int nqt = (S + KBLK - 1) / KBLK;
     const float* qst = qstat + (size_t)bh * nqt * 96;
@@ -348,7 +365,7 @@ __global__ __launch_bounds__(64 * BW, 1) void attn_bwd_kv_h3_kernel(const _Float
     const char* const vrow = vres + wave * TILE + l31 * ROWB;
     for (int t = 0; t < nqt; ++t) {
         const int cur = t & 1;
-        if (t + 1 < nqt) stage_q(t + 1, cur ^ 1);
+        if (!active && t + 1 < nqt) stage_q(t + 1, cur ^ 1);     // (a wave without keys still carries its share of the requests)
         if (active) {
             const char* qt = ring + cur * QSTG;
             const char* dot = qt + TILE;
@@ -360,6 +377,9 @@ __global__ __launch_bounds__(64 * BW, 1) void attn_bwd_kv_h3_kernel(const _Float
             f32x16 s0, s1;
             nt_product<true>(s0, s1, qt + l31 * ROWB, fk, kh, kl, nullptr, hi);
             if (t == 1) BWD_STAMP(1, 12);
+            // the next stage's requests go out behind the first product (three more phases to land in): at the top of the
+            // iteration their ~100 address instructions and 9 requests ran with the matrix pipe idle
+            if (t + 1 < nqt) stage_q(t + 1, cur ^ 1);
             // dP = dO_t · Vᵀ (B operand: the lane's V row in LDS); the first transposed reads go out under it
             tr_issue<0, 0>(ua, dot_a, troff);
             f32x16 e0, e1;
@@ -379,14 +399,14 @@ __global__ __launch_bounds__(64 * BW, 1) void attn_bwd_kv_h3_kernel(const _Float
             asm volatile("s_waitcnt lgkmcnt(0)"
                          : "+v"(st4[0][0]), "+v"(st4[0][1]), "+v"(st4[0][2]), "+v"(st4[0][3]), "+v"(st4[1][0]), "+v"(st4[1][1]),
                            "+v"(st4[1][2]), "+v"(st4[1][3]), "+v"(st4[2][0]), "+v"(st4[2][1]), "+v"(st4[2][2]), "+v"(st4[2][3]));
-            const float kmask = kok ? 1.f : 0.f;   // (keys past the sequence are clamped copies of its last row: finite scores)
+            // (no key mask: a lane past the sequence — a clamped copy of its last key — owns accumulator columns nobody stores)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * g + e;
                     const float sv = s0[r] + s1[r] * kLoInv;
-                    const float pv = __builtin_amdgcn_exp2f(sv * scale2 - st4[0][g][e]) * (st4[1][g][e] * kmask);
+                    const float pv = __builtin_amdgcn_exp2f(sv * scale2 - st4[0][g][e]) * st4[1][g][e];
                     p[r] = pv;
                     ds[r] = pv * ((e0[r] + e1[r] * kLoInv) - st4[2][g][e]) * scale;
                 }
@@ -453,7 +473,6 @@ __global__ __launch_bounds__(64 * BW, 1) void attn_bwd_q_h3_kernel(const _Float1
     const int q0 = (half * BW + wave) * 32;
     const bool active = q0 < S;
     const int q = q0 + l31;
-    const bool qok = active && q < S;
     const int qc = q < S ? q : S - 1;
     const int nkt = (S + KBLK - 1) / KBLK;
     BWD_STAMP(0, 0);
@@ -485,7 +504,7 @@ __global__ __launch_bounds__(64 * BW, 1) void attn_bwd_q_h3_kernel(const _Float1
     BWD_STAMP(0, 1);
     for (int t = 0; t < nkt; ++t) {
         const int cur = t & 1;
-        if (t + 1 < nkt) stage_kv(t + 1, cur ^ 1);
+        if (!active && t + 1 < nkt) stage_kv(t + 1, cur ^ 1);
         if (active) {
             const char* kt = lds + cur * KVSTG;
             const char* vt = kt + TILE;
@@ -494,6 +513,7 @@ __global__ __launch_bounds__(64 * BW, 1) void attn_bwd_q_h3_kernel(const _Float1
             f32x16 s0, s1, e0, e1;
             nt_product<true>(s0, s1, kt + l31 * ROWB, fk, qh, ql, nullptr, hi);      // Sᵀ (unscaled): lane = query, regs = keys
             if (t == 1) BWD_STAMP(0, 12);
+            if (t + 1 < nkt) stage_kv(t + 1, cur ^ 1);
             tr_issue<0, 0>(ua, kt_a, troff);
             nt_product<true>(e0, e1, vt + l31 * ROWB, fk, doh, dol, nullptr, hi);    // dPᵀ
             if (t == 1) BWD_STAMP(0, 13);
@@ -503,7 +523,7 @@ __global__ __launch_bounds__(64 * BW, 1) void attn_bwd_q_h3_kernel(const _Float1
                 const int key = t * KBLK + mfma32_row(r, lane);
                 const float sv = s0[r] + s1[r] * kLoInv;
                 const float pr = __builtin_amdgcn_exp2f(sv * scale2 - mx) * inv;
-                const float p = (key < S && qok) ? pr : 0.f;
+                const float p = key < S ? pr : 0.f;    // (a lane past the sequence owns accumulator columns nobody stores)
                 ds[r] = p * ((e0[r] + e1[r] * kLoInv) - dsum) * scale;
             }
             if (t == 1) BWD_STAMP(0, 14);
