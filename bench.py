@@ -120,11 +120,44 @@ def build_model(cfg_on, dev, seed=0):
     return model, sd
 
 
-def cpu_baseline(sd, B, n_steps=3):
+def _timed_steps(one, x, n_steps):
+    """1 warm-up + n_steps timed steps of `one`; per-step wall times (VERDICT r3 task 8: three timed steps gave a 35 % spread
+    between boxes — the line now carries min / median / max per step and is quoted on the median)."""
+    xc = one(x, 999, 0)
+    per = []
+    for k in range(n_steps):
+        t0 = time.perf_counter()
+        xc = one(xc, 998 - k, k + 1)
+        per.append(time.perf_counter() - t0)
+    per.sort()
+    med = per[len(per) // 2] if len(per) % 2 else 0.5 * (per[len(per) // 2 - 1] + per[len(per) // 2])
+    return {"value": 1.0 / med, "steps_per_s_mean": n_steps / sum(per), "step_s_min": per[0], "step_s_median": med,
+            "step_s_max": per[-1], "timed_steps": n_steps}
+
+
+def _calibrate_threads(step_fn):
+    """Intra-op thread count of the CPU leg: the fastest of {all, 64, 32, 16} logical CPUs on ONE FULL step of the workload
+    (round 3 calibrated on a single conditional forward), after a warm-up at that count."""
+    host = os.cpu_count() or 1
+    best, best_dt = host, None
+    for n in sorted({host, min(host, 64), min(host, 32), min(host, 16)}, reverse=True):
+        torch.set_num_threads(n)
+        step_fn()
+        t0 = time.perf_counter()
+        step_fn()
+        dt = time.perf_counter() - t0
+        if best_dt is None or dt < best_dt:
+            best, best_dt = n, dt
+    torch.set_num_threads(best)
+    return best, host
+
+
+def cpu_baseline(sd, B, n_steps=10):
     """The reference's CPU path restated on torch CPU kernels (oracle/torch_cpu_port.py: the reference's
     denoiser IS torch's nn.TransformerEncoder, two sequential CFG passes, then the posterior update) at
-    the bench shape.  The intra-op thread count is calibrated first (one conditional pass per candidate)
-    and reported as `cores`."""
+    the bench shape.  The intra-op thread count is calibrated first (one full CFG step per candidate)
+    and reported as `cores`.  profiles/r04_cpu_port_vs_reference.json holds the port / real-reference ratio measured
+    where /root/reference exists (tools/cpu_port_vs_reference.py)."""
     from oracle import diffusion_oracle as do
     from oracle.torch_cpu_port import TorchCpuMDM
     rng = np.random.default_rng(1)
@@ -134,40 +167,25 @@ def cpu_baseline(sd, B, n_steps=3):
     enc = torch.from_numpy(rng.standard_normal((B, 512)).astype(np.float32))
     scale = torch.full((B,), 2.5)
     nz = rng.standard_normal((n_steps + 1,) + x.shape).astype(np.float32)
-    t999 = torch.full((B,), 999, dtype=torch.long)
-
-    host = os.cpu_count() or 1
-    prev = torch.get_num_threads()
-    best, best_dt = host, None
-    for n in sorted({host, min(host, 64), min(host, 32), min(host, 16)}, reverse=True):
-        torch.set_num_threads(n)
-        m.forward(torch.from_numpy(x), t999, enc)  # warm this thread count
-        t0 = time.perf_counter()
-        m.forward(torch.from_numpy(x), t999, enc)
-        dt = time.perf_counter() - t0
-        if best_dt is None or dt < best_dt:
-            best, best_dt = n, dt
-    torch.set_num_threads(best)
 
     def one(xc, i, k):
         t = torch.full((B,), i, dtype=torch.long)
         hat, _, _ = m.forward_cfg(torch.from_numpy(xc), t, enc, scale)
         return do.step_update(sch, i, xc, hat.numpy(), nz[k])[0]
 
-    xc = one(x, 999, 0)  # warm-up
-    t0 = time.perf_counter()
-    for k in range(n_steps):
-        xc = one(xc, 998 - k, k + 1)
-    dt = time.perf_counter() - t0
+    prev = torch.get_num_threads()
+    best, host = _calibrate_threads(lambda: one(x, 999, 0))
+    res = _timed_steps(one, x, n_steps)
     torch.set_num_threads(prev)
-    return {"value": n_steps / dt, "unit": "denoising steps/s", "cores": best, "kind": "port",
-            "sample": f"{n_steps} full CFG DDPM steps at B={B}x{T_FRAMES}x{N_FEATS} after 1 warm-up "
-                      f"(oracle/torch_cpu_port.py: torch {torch.__version__} CPU nn.TransformerEncoder, the "
-                      f"reference's own denoiser arithmetic; {best} intra-op threads picked from a calibration "
-                      f"on a host with {host} logical CPUs)"}
+    res.update({"unit": "denoising steps/s", "cores": best, "kind": "port",
+                "sample": f"{n_steps} full CFG DDPM steps at B={B}x{T_FRAMES}x{N_FEATS} after 1 warm-up, quoted on the median step "
+                          f"(oracle/torch_cpu_port.py: torch {torch.__version__} CPU nn.TransformerEncoder, the "
+                          f"reference's own denoiser arithmetic; {best} intra-op threads picked from a calibration "
+                          f"of one full step per candidate on a host with {host} logical CPUs)"})
+    return res
 
 
-def cpu_baseline_unet(sd, B, n_steps=2):
+def cpu_baseline_unet(sd, B, n_steps=5):
     """The same for --config unet: MDM_UNET on torch's CPU conv1d / group_norm / mish kernels
     (oracle/torch_cpu_port.py::TorchCpuUNET), two sequential CFG passes + the posterior update."""
     from oracle import diffusion_oracle as do
@@ -183,42 +201,25 @@ def cpu_baseline_unet(sd, B, n_steps=2):
     enc = torch.from_numpy(rng.standard_normal((B, 512)).astype(np.float32))
     scale = torch.full((B,), 2.5)
     nz = rng.standard_normal((n_steps + 1,) + shape).astype(np.float32)
-    host = os.cpu_count() or 1
-    prev = torch.get_num_threads()
-    best, best_dt = host, None
     t999 = torch.full((B,), 999, dtype=torch.long)
     xs = torch.from_numpy(x[:4])
-    for n in sorted({host, min(host, 64), min(host, 32), min(host, 16)}, reverse=True):
-        torch.set_num_threads(n)
-        m.forward(xs, t999[:4], enc[:4], False, obs[:4], mask[:4])   # warm this thread count (4 sequences)
-        t0 = time.perf_counter()
-        m.forward(xs, t999[:4], enc[:4], False, obs[:4], mask[:4])
-        dt = time.perf_counter() - t0
-        if best_dt is None or dt < best_dt:
-            best, best_dt = n, dt
-    torch.set_num_threads(best)
+    prev = torch.get_num_threads()
+    # (calibrated on a 4-sequence conditional pass: a full U-Net step is 5-10 s of CPU per candidate)
+    best, host = _calibrate_threads(lambda: m.forward(xs, t999[:4], enc[:4], False, obs[:4], mask[:4]))
 
     def one(xc, i, k):
         t = torch.full((B,), i, dtype=torch.long)
         hat, _, _ = m.forward_cfg(torch.from_numpy(xc), t, enc, scale, obs, mask)
         return do.step_update(sch, i, xc, hat.numpy(), nz[k])[0]
 
-    xc = one(x, 999, 0)  # warm-up
-    t0 = time.perf_counter()
-    for k in range(n_steps):
-        xc = one(xc, 998 - k, k + 1)
-    dt = time.perf_counter() - t0
+    res = _timed_steps(one, x, n_steps)
     torch.set_num_threads(prev)
-    return {"value": n_steps / dt, "unit": "denoising steps/s", "cores": best, "kind": "port",
-            "sample": f"{n_steps} full CFG DDPM steps of MDM_UNET at B={B}x{T_FRAMES}x{N_FEATS} after 1 warm-up "
-                      f"(oracle/torch_cpu_port.py::TorchCpuUNET: torch {torch.__version__} CPU conv1d / group_norm / "
-                      f"mish, the reference's own layer kernels; {best} intra-op threads picked from a calibration "
-                      f"on a host with {host} logical CPUs)"}
-
-
-N_SIMD = 1024            # 256 CUs x 4 SIMDs
-N_XCD = 8
-
+    res.update({"unit": "denoising steps/s", "cores": best, "kind": "port",
+                "sample": f"{n_steps} full CFG DDPM steps of MDM_UNET at B={B}x{T_FRAMES}x{N_FEATS} after 1 warm-up, quoted on the "
+                          f"median step (oracle/torch_cpu_port.py::TorchCpuUNET: torch {torch.__version__} CPU conv1d / group_norm / "
+                          f"mish, the reference's own layer kernels; {best} intra-op threads picked from a calibration "
+                          f"on a host with {host} logical CPUs)"})
+    return res
 
 def pmc_counters(config: str, precision: str, batch: int, timeout_s: float = 150.0):
     """rocprofv3 --pmc sub-runs of `bench.py --pmc-child` for THIS config and precision (counters serialise kernels, so
@@ -412,6 +413,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc sub-runs (traffic / mfma_busy = null)")
     ap.add_argument("--no-f32", action="store_true", help="skip the exact-fp32 engine's leg")
     ap.add_argument("--graph", action="store_true", help="replay each denoising step as a hipGraph")
+    ap.add_argument("--no-graph-leg", action="store_true", help="skip the eager-vs-hipGraph comparison legs")
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch of the config (exploration)")
     ap.add_argument("--precision", default=None, choices=["f32", "f16x3", "bf16x6"],
                     help="encoder GEMM arithmetic (include/condmdi.h CMDI_PREC_*); default: the library's")
@@ -583,6 +585,41 @@ def main():
                 leg["roofline"] = roofline_from(eng2, loop2, False, False, pmc2)
             out[key] = leg
         model.native_precision = None
+
+    # hipGraph replay vs eager launches of the same K steps (VERDICT r3 task 6; SURVEY 8d asks config 4 for step latency with
+    # and without hipGraph, through ddim_sample_loop AND p_sample_loop on the 'ddim100' respacing).  The engine replays the
+    # schedule it runs eagerly: pipeline parts on their own streams, one graph per (part, kind).
+    if rank == 0 and world == 1 and not is_unet and not args.no_graph_leg and args.precision is None:
+        legs = {}
+        kinds = ("ddim", "ddpm") if args.config == "c4" else (cfg["sampler"],)
+        model.native_precision = None
+        eng_g = model.engine(dev, max_batch=B, max_frames=T_FRAMES, want_grad=cfg["edit"])
+        for kind in kinds:
+            sid = N.CMDI_SAMPLER_DDIM if kind == "ddim" else N.CMDI_SAMPLER_DDPM
+            leg = {}
+            for mode in ("eager", "graph"):
+                eng_g.set_graph(mode == "graph")
+                eng_g.set_schedule(diffusion.engine_tables(), key=None)
+                eng_g.set_condition(**cond)
+                xg = eng_g.randn((B, N_FEATS, 1, T_FRAMES), seed=seed, first_sample=lo)
+                if W > 0:
+                    eng_g.sample_loop(xg, n_chain - 1, n_chain - W, sampler=sid, seed=seed, first_sample=lo)
+                # (graph capture happens on the first two steps of a kind: two untimed steps in both modes keep it out of the K)
+                hi2 = min(K + 1, n_chain - 1)
+                eng_g.sample_loop(xg, hi2, hi2 - 1, sampler=sid, seed=seed, first_sample=lo)
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                eng_g.sample_loop(xg, K - 1, 0, sampler=sid, seed=seed, first_sample=lo)
+                torch.cuda.synchronize(dev)
+                leg[f"{mode}_ms_per_step"] = (time.perf_counter() - t0) / K * 1e3
+                if mode == "eager":
+                    ref_x = xg.clone()
+                else:
+                    leg["bitwise_equal"] = bool(torch.equal(ref_x, xg))
+            leg["pipeline_parts"] = eng_g.pipeline_parts()
+            legs[{"ddim": "ddim_sample_loop", "ddpm": "p_sample_loop"}[kind]] = leg
+        eng_g.set_graph(args.graph)
+        out["hip_graph_legs"] = legs
 
     if rank == 0 and world == 1 and not args.no_cpu and not (is_unet and cfg["edit"]):
         Bc = min(B, 32)   # bounded sample: at most the c2 batch (c4/c5: per-sample cost is the same, scaled below)

@@ -158,6 +158,12 @@ struct cmdi_engine {
     int* cursor_dev = nullptr;         // current respaced step index
     int table_cap = 0;
     hipGraphExec_t graph_exec[2] = {nullptr, nullptr};   // [reconstruction guidance active?]
+    // the pipelined schedule (round 4): one graph per (part, kind), captured on and replayed into the part's own stream;
+    // the parts' cursors are cursor_dev[1 + part]
+    std::vector<hipGraphExec_t> part_graph;              // [part * 2 + kind]
+    std::vector<char> part_warm;
+    int part_graph_parts = 0;
+    int cursor_cap = 0;
     bool graph_warm[2] = {false, false};
     hipStream_t graph_stream = nullptr;
     hipStream_t own_stream = nullptr;   // capture cannot start on the legacy default stream
@@ -203,6 +209,12 @@ inline void drop_graphs(cmdi_engine* e) {
         e->graph_exec[i] = nullptr;
         e->graph_warm[i] = false;
     }
+    for (hipGraphExec_t& g : e->part_graph) {
+        if (g) (void)hipGraphExecDestroy(g);
+        g = nullptr;
+    }
+    e->part_graph.clear();
+    e->part_warm.clear();
 }
 
 inline GemmParams gp(const float* A, const float* W, const float* bias, float* C, int M, int N, int K,

@@ -386,11 +386,15 @@ class GaussianDiffusion:
         chain's first x_t — at its first and at its last timestep — are checked for the f16 range first, so weights / conditions
         that overflow systematically send the chain to the bf16x6 engine BEFORE its (up to 1000) steps are spent, not after
         (VERDICT r2 task 7; the end-of-chain check stays: an overflow that only a later x_t provokes is still caught).  Costs 2
-        of >= 50 evaluations and one 4-byte read-back; skipped for pinned precisions, short chains and denoisers without a
-        fallback mode."""
-        if (mdm is None or not hasattr(mdm, "range_fallback") or getattr(mdm, "native_precision", None) is not None
-                or getattr(mdm, "_range_fallback", False) or eng.precision != "f16x3" or getattr(eng, "arch", "") == "unet"
-                or len(indices) < self.RANGE_PROBE_MIN_STEPS):
+        of >= 50 evaluations and one 4-byte read-back; skipped for pinned precisions and short chains.  MDM_UNET (f16x3 only):
+        the same probe, and its RangeError — which names the cause — reaches the caller before any step is spent."""
+        if mdm is None or eng.precision != "f16x3" or len(indices) < self.RANGE_PROBE_MIN_STEPS:
+            return
+        unet = getattr(eng, "arch", "") == "unet"
+        # MDM_UNET has no wider-range engine to fall back to (the reference's is plain fp32, model/mdm_unet.py:561-849): there the
+        # probe turns "RangeError after 1000 steps" into "RangeError before the first one" (round 4, VERDICT r3 task 2)
+        if not unet and (not hasattr(mdm, "range_fallback") or getattr(mdm, "native_precision", None) is not None
+                         or getattr(mdm, "_range_fallback", False)):
             return
         tmap = self._timestep_map()
         for i in (indices[0], indices[-1]):

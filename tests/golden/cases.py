@@ -192,6 +192,10 @@ UNET_RECON_CHAIN = dict(UNET_CHAIN, seed=304, recon_weight=20.0, stop_recguidanc
 UNET_ATTN_CASE = dict(UNET_CASE, seed=305, weight_seed=33, t=[700, 41], text_scale=[2.5, 1.0])
 
 
+# the released geometry (configs/model.py motion_unet_adagn_xl): 1024 channels at every level
+UNET_XL_CASE = dict(UNET_CASE, seed=306, weight_seed=78, dim_mults=(2, 2, 2, 2), t=[612, 27], text_scale=[2.5, 0.7], mask_prob=0.2)
+
+
 def make_unet_vjp_inputs(case: dict = UNET_VJP_CASE) -> dict:
     inp = make_unet_inputs(case)
     rng = np.random.default_rng(case["seed"] + 1000)

@@ -1136,6 +1136,48 @@ def test_graph_replay_is_bitwise_identical(precision, sampler):
     assert torch.equal(eager, replay) and torch.equal(eager, again)
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("groups", ["2", "3"])
+def test_graph_replay_of_the_pipelined_schedule_is_bitwise_identical(precision, groups, monkeypatch):
+    """hipGraph replay of the PIPELINED schedule (VERDICT r3 task 6): the batch is cut into independent parts, each part's
+    denoising step is captured on its own stream (per-part device cursor) and replayed into it; the chain crosses both
+    graph kinds (reconstruction guidance stops at step 4) and the imputation gate, DDPM and DDIM.  Bitwise the eager
+    pipelined chain, which is bitwise the single-stream chain."""
+    N = sub("_native")
+    monkeypatch.setenv("CMDI_GROUPS", groups)
+    case = dict(text=True, weight_seed=11, cfg=True)
+    model, _ = make_model(case, layers=2, precision=precision)
+    diffusion = make_diffusion([12])
+    B, T = 5, 52
+    rng = np.random.default_rng(10)
+    shape = (B, 263, 1, T)
+    emb = tt(rng.standard_normal((B, 512)).astype(np.float32))
+    x0 = tt(rng.standard_normal(shape).astype(np.float32))
+    mask = tt(rng.random(shape) < 0.3)
+    eng = model.model.engine(torch.device(DEV), max_batch=B, max_frames=T, want_grad=True)
+    eng.set_schedule(diffusion.engine_tables(), key="gp")
+
+    def run(graph, sid):
+        eng.set_graph(graph)
+        eng.set_condition(batch=B, n_frames=T, cfg=True, enc_text=emb, text_scale=torch.full((B,), 2.5, device=DEV),
+                          inpaint_mask=mask, inpaint_motion=x0, imputate=True, stop_imputation_at=1,
+                          recon_guidance=True, stop_recguidance_at=4,
+                          recon_w=np.full((12,), 20.0, dtype=np.float32))
+        x = eng.randn(shape, seed=5)
+        eng.sample_loop(x, 11, 0, sampler=sid, eta=0.3, seed=78, first_sample=3)
+        eng.check_range()
+        assert eng.pipeline_parts() == int(groups)
+        return x.clone()
+
+    for sid in (N.CMDI_SAMPLER_DDPM, N.CMDI_SAMPLER_DDIM):
+        eager = run(False, sid)
+        replay = run(True, sid)
+        again = run(True, sid)
+        assert torch.isfinite(eager).all()
+        assert torch.equal(eager, replay) and torch.equal(eager, again)
+    eng.set_graph(False)
+
+
 # ---- post-sampling step (SURVEY.md §8f rank 2) -----------------------------------------------------------
 @pytest.mark.parametrize("abs_3d", [False, True])
 def test_recover_xyz_vs_reference(cases, abs_3d):
@@ -1387,45 +1429,95 @@ def test_unet_forward_groupnorm_fusion_modes(cases, monkeypatch, fuse):
     assert ok("unet_forward_groupnorm_fusion_modes.max_abs.0", max_abs(cfg, g["out_cfg"]), 2e-4) and ok("unet_forward_groupnorm_fusion_modes.rel_l2.0", rel_l2(cfg, g["out_cfg"]), 2e-5), rel_l2(cfg, g["out_cfg"])
 
 
-def test_unet_xl_geometry_vs_torch_port(cases):
-    """The released geometry (configs/model.py motion_unet_adagn_xl: dim 512 x mults (2,2,2,2) = 1024 channels, 128 per
-    GroupNorm group) — forward and input-VJP vs the torch CPU port; the golden fixtures use 512 channels."""
-    from oracle.torch_cpu_port import TorchCpuUNET
+@pytest.mark.parametrize("scale,expect", [(4000.0, "ok"), (60000.0, "range")])
+def test_unet_real_scale_activations_and_range_probe(cases, scale, expect, monkeypatch):
+    """MDM_UNET is f16x3-only (the reference's U-Net is plain fp32 anywhere, model/mdm_unet.py:561-849).  Its range story
+    (VERDICT r3 task 2): activations far above the synthetic-weight scale stay exact to the usual tolerance — here the first
+    block's residual 1x1 convolution is scaled so that the block's output (a split-f16 operand of the next convolution) reaches
+    ~1e4 — and activations that DO leave the f16 range (the same weights x 15) are reported by the pre-chain probe: a RangeError that names the cause BEFORE the first of the chain's steps is
+    spent (rounds 1-3: after the last one), never a silent wrong sample."""
+    from oracle.unet_oracle import UnetOracle
+    N = sub("_native")
     mu = sub("utils.model_util")
-    args = SimpleNamespace(dataset="humanml", arch="unet", keyframe_conditioned=True, dim_mults=(2, 2, 2, 2),
+    case = cases.UNET_CASE
+    args = SimpleNamespace(dataset="humanml", arch="unet", keyframe_conditioned=True, dim_mults=case["dim_mults"],
                            cond_mask_prob=0.1)
     model, _ = mu.create_model_and_diffusion(args, None)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
-    mu.load_model_wo_clip(model, weights.to_torch(weights.fill_like(shapes, 78)) |
+    sd = weights.fill_like(shapes, 91)
+    first = "unet.downs.0.0.residual_conv.weight"
+    assert first in sd, sorted(sd)[:8]
+    sd[first] = sd[first] * np.float32(scale)
+    mu.load_model_wo_clip(model, weights.to_torch(sd) | {k: v for k, v in model.state_dict().items() if k.endswith(".pe")})
+    model = model.to(DEV).eval()
+    wrapped = sub("model.cfg_sampler").ClassifierFreeSampleModel(model)
+    B, T = 2, 64
+    rng = np.random.default_rng(92)
+    shape = (B, 263, 1, T)
+    x = rng.standard_normal(shape).astype(np.float32)
+    obs = rng.standard_normal(shape).astype(np.float32)
+    m = rng.random(shape) < 0.2
+    enc = rng.standard_normal((B, 512)).astype(np.float32)
+    sc = np.full(B, 2.5, np.float32)
+    if expect == "ok":
+        t = rng.integers(0, 1000, B)
+        full = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+        want, _, _ = UnetOracle(full).forward_cfg(x, t, enc, sc, obs, m)
+        got = wrapped(tt(x), tt(t), y={"text_embed": tt(enc), "text_scale": tt(sc)}, obs_x0=tt(obs), obs_mask=tt(m)).cpu().numpy()
+        model.check_range()
+        assert ok("unet_real_scale.rel_l2", rel_l2(got, want), 2e-5), rel_l2(got, want)
+        return
+    gd = sub("diffusion.gaussian_diffusion")
+    diffusion = make_diffusion([60])      # >= RANGE_PROBE_MIN_STEPS: the probe runs
+    calls = []
+    eng_cls = sub("engine").Engine
+    real = eng_cls.sample_loop
+    monkeypatch.setattr(eng_cls, "sample_loop", lambda self, *a, **k: (calls.append(1), real(self, *a, **k))[1])
+    y = {"mask": torch.ones(B, 1, 1, T, dtype=torch.bool, device=DEV), "lengths": torch.full((B,), T),
+         "text_embed": tt(enc), "text_scale": tt(sc)}
+    with pytest.raises(N.RangeError, match="MDM_UNET engine is built for f16x3 only"):
+        diffusion.p_sample_loop(wrapped, shape, noise=tt(x), clip_denoised=False,
+                                model_kwargs={"y": y, "obs_x0": tt(obs), "obs_mask": tt(m)})
+    assert not calls, "the chain was started although the probe evaluation left the f16 range"
+
+
+def test_unet_xl_geometry_vs_reference(cases):
+    """The released geometry (configs/model.py motion_unet_adagn_xl: dim 512 x mults (2,2,2,2) = 1024 channels, 128 per
+    GroupNorm group) — forward (cond / uncond / CFG) and input-VJP vs the REAL reference's CPU outputs
+    (tests/golden/make_golden_unet_xl.py; rounds 1-3 compared this geometry with the torch port only)."""
+    mu = sub("utils.model_util")
+    case = cases.UNET_XL_CASE
+    inp = cases.make_unet_vjp_inputs(case)
+    g = load_golden("unet_xl")
+    assert np.array_equal(g["fingerprint"], cases.fingerprint(inp))
+    args = SimpleNamespace(dataset="humanml", arch="unet", keyframe_conditioned=True, dim_mults=case["dim_mults"],
+                           cond_mask_prob=0.1)
+    model, _ = mu.create_model_and_diffusion(args, None)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert sorted(shapes) == list(g["names"]), "state-dict names differ from the reference's MDM_UNET"
+    mu.load_model_wo_clip(model, weights.to_torch(weights.fill_like(shapes, case["weight_seed"])) |
                           {k: v for k, v in model.state_dict().items() if k.endswith(".pe")})
     model = model.to(DEV).eval()
-    port = TorchCpuUNET({k: v.detach().cpu() for k, v in model.state_dict().items()})
-    B, T = 2, 196
-    rng = np.random.default_rng(6001)
-    shape = (B, 263, 1, T)
-    x, gout, obs = (rng.standard_normal(shape).astype(np.float32) for _ in range(3))
-    m = rng.random(shape) < 0.2
-    t = rng.integers(0, 1000, B)
-    enc = rng.standard_normal((B, 512)).astype(np.float32)
-    scale = np.asarray([2.5, 0.7], np.float32)
-    tc = torch.from_numpy
-    zc = tc(x).clone().requires_grad_(True)
-    with torch.enable_grad():
-        oc = port.forward_impl(zc, tc(t), tc(enc), False, tc(obs), tc(m))
-        ou = port.forward_impl(zc, tc(t), tc(enc), True, tc(obs), tc(m))
-        want_out = ou + tc(scale).view(-1, 1, 1, 1) * (oc - ou)
-        want_gx, = torch.autograd.grad((want_out * tc(gout)).sum(), zc)
     net = sub("model.cfg_sampler").ClassifierFreeSampleModel(model)
-    y = {"text_embed": tt(enc), "text_scale": tt(scale)}
+    x, t = tt(inp["x"]), tt(inp["t"])
+    kw = dict(obs_x0=tt(inp["obs_x0"]), obs_mask=tt(inp["obs_mask"]))
+    y = {"text_embed": tt(inp["enc_text"])}
     with torch.no_grad():   # plain forward (split-K at the coarse levels, no stash)
-        plain = net(tt(x), tt(t), y=y, obs_x0=tt(obs), obs_mask=tt(m)).cpu().numpy()
-    assert ok("unet_xl_geometry_vs_torch_port.max_abs.0", max_abs(plain, want_out.detach().numpy()), 2e-4) and ok("unet_xl_geometry_vs_torch_port.rel_l2.0", rel_l2(plain, want_out.detach().numpy()), 2e-5)
-    z = tt(x).requires_grad_(True)
+        oc = model(x, t, y=y, **kw).cpu().numpy()
+        ou = model(x, t, y=dict(y, uncond=True), **kw).cpu().numpy()
+        cfg = net(x, t, y=dict(y, text_scale=tt(inp["text_scale"])), **kw).cpu().numpy()
+    for mine, key in ((oc, "out_cond"), (ou, "out_uncond"), (cfg, "out_cfg")):
+        assert np.isfinite(mine).all()
+        assert ok("unet_xl.max_abs", max_abs(mine, g[key]), 2e-4) and ok("unet_xl.rel_l2", rel_l2(mine, g[key]), 2e-5), \
+            (key, max_abs(mine, g[key]), rel_l2(mine, g[key]))
+    z = tt(inp["x"]).requires_grad_(True)
     with torch.enable_grad():
-        out = net(z, tt(t), y=y, obs_x0=tt(obs), obs_mask=tt(m))
-        got, = torch.autograd.grad((out * tt(gout)).sum(), z)
-    assert ok("unet_xl_geometry_vs_torch_port.rel_l2.1", rel_l2(out.detach().cpu().numpy(), want_out.detach().numpy()), 2e-5)
-    assert ok("unet_xl_geometry_vs_torch_port.rel_l2.2", rel_l2(got.cpu().numpy(), want_gx.numpy()), 5e-5), rel_l2(got.cpu().numpy(), want_gx.numpy())
+        out = net(z, t, y=dict(y, text_scale=tt(inp["text_scale"])), **kw)
+        got, = torch.autograd.grad((out * tt(inp["gout"])).sum(), z)
+    assert ok("unet_xl.stash_fwd", rel_l2(out.detach().cpu().numpy(), g["out_cfg"]), 2e-5)
+    got = got.cpu().numpy()
+    assert float(np.abs(got[inp["obs_mask"]]).max()) == 0.0          # observed entries are replaced by obs_x0
+    assert ok("unet_xl.vjp", rel_l2(got, g["gx"]), 5e-5), rel_l2(got, g["gx"])
 
 
 @pytest.mark.parametrize("B,T,keyframe,cfg", [(3, 100, True, False), (1, 224, False, True), (2, 33, True, True)])
