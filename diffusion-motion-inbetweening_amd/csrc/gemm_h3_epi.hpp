@@ -73,7 +73,9 @@ __device__ __forceinline__ void h3p_load_rows(const H3Params& p, int m_blk, int 
 // arithmetic copied from gemm_h3's interior path line by line (same bits).
 // LOWREG (gemm_h3's 128-register kernels): the transposed rows are read from LDS one row pass at a time and the accumulator
 // pair is combined while it is written out — 24 fewer live registers; the other form reads both passes before the first store.
-template <int EPI, bool EDGE, bool NO_STORE = false, bool LOWREG = false>
+// CONV (H3_PLAIN of the persistent kernel): the row goes to m * c_row_mul + c_row_add and only if its position inside the
+// tp-row frame of its sequence lies in [t_lo, t_hi) — gemm_h3's convolution rule.
+template <int EPI, bool EDGE, bool NO_STORE = false, bool LOWREG = false, bool CONV = false>
 __device__ __forceinline__ void h3p_epi_block(const H3Params& p, const f32x16& acc, const f32x16& acc_lo, int m_blk, int n_blk,
                                               const float2* rs, float* wl, int lane, const H3PCols& cols, const H3PRows& rows,
                                               bool& overflow) {
@@ -102,8 +104,15 @@ __device__ __forceinline__ void h3p_epi_block(const H3Params& p, const f32x16& a
             tt[it][1] = *reinterpret_cast<const float4*>(wl + (it * 16 + rl) * 32 + cl + 4);
             rst[it] = rs ? rs[it * 16 + rl] : make_float2(0.f, 1.f);
         }
-        const int m = m_blk + it * 16 + rl;
-        const bool live = (!EDGE || m < M) && !(NO_STORE && rs != nullptr && rst[0].x != 12345.678f);
+        int m = m_blk + it * 16 + rl;
+        bool live = (!EDGE || m < M) && !(NO_STORE && rs != nullptr && rst[0].x != 12345.678f);
+        if constexpr (CONV) {
+            if (p.c_row_mul) m = m * p.c_row_mul + p.c_row_add;
+            if (p.tp) {
+                const int pos = m % p.tp;
+                live = live && pos >= p.t_lo && pos < p.t_hi;
+            }
+        }
         const float2 rs2 = rst[it];
         float v[8];
 #pragma unroll

@@ -4,18 +4,28 @@
 
 namespace cmdi {
 
+static bool is_conv(const H3Params& p) { return p.cpt || p.a_ld || p.a_row_mul || p.c_row_mul || p.tp; }
+
 bool gemm_h3p_supports(int epi, const H3Params& p) {
     if (epi != H3_PLAIN && epi != H3_PLAIN_SPLIT && epi != H3_GELU_SPLIT && epi != H3_GELUGRAD_SPLIT && epi != H3_RESID) return false;
-    if (p.cpt || p.a_ld || p.a_row_mul || p.c_row_mul || p.tp || p.ksplit > 1 || p.cs_head_major || p.m_fast) return false;
+    if (p.ksplit > 1 || p.cs_head_major || p.m_fast) return false;
     if (p.M <= 0 || p.N % H3PTile::BN != 0 || p.K % 32 != 0 || p.K < 64) return false;
-    if ((size_t)p.M * 4 * (size_t)p.K >= (1ull << 31) || (size_t)p.N * 4 * (size_t)p.K >= (1ull << 31)) return false;   // 32-bit request offsets
+    if (is_conv(p)) {   // convolution rows (U-Net): the plain fp32 epilogue only; K = taps * cpt * 32
+        if (epi != H3_PLAIN || p.ln_part || p.ln_c1 || p.aux) return false;
+        if (p.cpt < 1 || p.taps < 1 || p.K != p.taps * p.cpt * 32 || (p.a_ld && p.a_ld < 2 * p.cpt * 32)) return false;
+        const size_t a_row = 2 * (p.a_ld ? (size_t)p.a_ld : 2 * (size_t)p.K) * (size_t)(p.a_row_mul ? p.a_row_mul : 1);
+        if ((size_t)p.M * a_row + (size_t)p.taps * a_row >= (1ull << 31)) return false;
+    } else if ((size_t)p.M * 4 * (size_t)p.K >= (1ull << 31)) {
+        return false;
+    }
+    if ((size_t)p.N * 4 * (size_t)p.K >= (1ull << 31)) return false;   // 32-bit request offsets
     if (epi == H3_RESID && p.ln_c1) return false;        // (a folded-LayerNorm A operand together with a residual: not used, not built)
     return true;
 }
 
-template <int EPI, int ABL = 0>
+template <int EPI, int ABL = 0, bool CONV = false>
 static hipError_t launch_h3p(const H3Params& p, hipStream_t stream) {
-    auto kern = gemm_h3p_kernel<EPI, ABL>;
+    auto kern = gemm_h3p_kernel<EPI, ABL, CONV>;
     static bool attr_done_dev[kMaxDevices] = {};   // benign race: the attribute call is idempotent
     bool& attr_done = attr_done_dev[device_slot()];
     static int blocks_dev[kMaxDevices] = {};
@@ -52,7 +62,7 @@ hipError_t launch_gemm_h3p(int epi, const H3Params& p, hipStream_t s, int ablati
 #endif
     if (ablation) return hipErrorInvalidValue;
     switch (epi) {
-        case H3_PLAIN: return launch_h3p<H3_PLAIN>(p, s);
+        case H3_PLAIN: return is_conv(p) ? launch_h3p<H3_PLAIN, 0, true>(p, s) : launch_h3p<H3_PLAIN>(p, s);
         case H3_PLAIN_SPLIT: return launch_h3p<H3_PLAIN_SPLIT>(p, s);
         case H3_GELU_SPLIT: return launch_h3p<H3_GELU_SPLIT>(p, s);
         case H3_GELUGRAD_SPLIT: return launch_h3p<H3_GELUGRAD_SPLIT>(p, s);

@@ -57,7 +57,10 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // ABL (probes library only, tools/h3p_ablate.py): 1 = no requests inside the loop, 2 = fragments from registers instead of LDS,
 // 4 = no epilogue, 8 = cycle stamps (tools/h3p_timeline.py).  Compile-time: a runtime switch costs the loop 15-20 %.
-template <int EPI, int ABL = 0>
+// CONV (H3_PLAIN only, round 4): the A operand is a 1-D convolution's tap-shifted row matrix (H3Params a_ld / a_row_mul / cpt:
+// K step kt reads chunk kt % cpt of the row `kt / cpt` frames further on — only the SCALAR offset of the A requests changes)
+// and the output rows follow c_row_mul / c_row_add / tp / t_lo / t_hi (halo rows of a framed sequence are not written).
+template <int EPI, int ABL = 0, bool CONV = false>
 __global__ __launch_bounds__(H3PTile::NT, 2) void gemm_h3p_kernel(const H3Params p) {
     using TC = H3PTile;
     constexpr bool NO_DMA = (ABL & 1) != 0, NO_READ = (ABL & 2) != 0, NO_EPI = (ABL & 4) != 0, STAMPS = (ABL & 8) != 0;
@@ -107,6 +110,9 @@ __global__ __launch_bounds__(H3PTile::NT, 2) void gemm_h3p_kernel(const H3Params
     // one request count for every K step — clamped to the matrix.)  Sources are 32-bit byte offsets from p.A / p.W.
     const int prow = lane >> 3, pslot = lane & 7;
     const unsigned ldk_b = 4u * (unsigned)p.K;                 // bytes per split row
+    const unsigned lda_b = CONV && p.a_ld ? 2u * (unsigned)p.a_ld : ldk_b;                       // bytes per A row
+    const unsigned a_rstep = CONV && p.a_row_mul ? lda_b * (unsigned)p.a_row_mul : lda_b;        // ... per output row
+    const int cpt = CONV && p.cpt ? p.cpt : 0x40000000;
     unsigned src_off[6];
     auto set_src = [&](int m0, int n0) {
 #pragma unroll
@@ -116,7 +122,7 @@ __global__ __launch_bounds__(H3PTile::NT, 2) void gemm_h3p_kernel(const H3Params
             if (r < TC::BM) {
                 int grow = m0 + r;
                 grow = grow < M ? grow : M - 1;
-                src_off[q] = (unsigned)grow * ldk_b + sw;
+                src_off[q] = (unsigned)grow * a_rstep + sw;
             } else {
                 int c = n0 + r - TC::BM;
                 c = c < p.N ? c : p.N - 1;
@@ -129,13 +135,15 @@ __global__ __launch_bounds__(H3PTile::NT, 2) void gemm_h3p_kernel(const H3Params
     // one request per piece, no vector arithmetic (a flat global_load_lds needs a 64-bit address per lane and piece)
     const auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.A), 0, 0x7fffffff, 0x00020000);
     const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(p.W), 0, 0x7fffffff, 0x00020000);
+    int iss_aoff = 0, iss_tap = 0, iss_chunk = 0;           // CONV: scalar offset of the A requests of the next K step to request
     auto issue_range = [&](auto q0_c, auto q1_c, int kt, int s) {
         constexpr int Q0 = decltype(q0_c)::value, Q1 = decltype(q1_c)::value;
+        const int a_soff = CONV ? __builtin_amdgcn_readfirstlane(iss_aoff) : kt * 128;
 #pragma unroll
         for (int q = Q0; q < Q1; ++q) {
             const int r0 = wave * 48 + q * 8;                 // wave-uniform: the piece lies entirely in A or entirely in W
             auto dst = (__attribute__((address_space(3))) void*)(lds + s * STAGE + r0 * 128);
-            if (r0 < TC::BM) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, dst, 16, (int)src_off[q], kt * 128, 0, 0);
+            if (r0 < TC::BM) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, dst, 16, (int)src_off[q], a_soff, 0, 0);
             else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, dst, 16, (int)src_off[q], kt * 128, 0, 0);
         }
     };
@@ -188,6 +196,12 @@ __global__ __launch_bounds__(H3PTile::NT, 2) void gemm_h3p_kernel(const H3Params
     auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };   // block-uniform bookkeeping stays on the scalar unit
     auto advance_issue = [&]() {
         iss_kt = uni(iss_kt + 1);
+        if constexpr (CONV) {     // tap = kt / cpt, chunk = kt % cpt, kept incrementally on the scalar unit
+            iss_chunk = uni(iss_chunk + 1);
+            if (iss_chunk == cpt) { iss_chunk = 0; iss_tap = uni(iss_tap + 1); }
+            if (iss_kt == nk) { iss_chunk = 0; iss_tap = 0; }
+            iss_aoff = uni((int)((unsigned)iss_tap * lda_b) + iss_chunk * 128);
+        }
         if (iss_kt == nk) {
             iss_kt = 0;
             iss_item = uni(iss_item + P);
@@ -423,7 +437,7 @@ __global__ __launch_bounds__(H3PTile::NT, 2) void gemm_h3p_kernel(const H3Params
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                h3p_epi_block<EPI, EDGE, NO_STORE>(p, acc0[i][j], acc0[i][j], m0 + wm * 64 + i * 32, n0 + j * 128 + wn * 32,
+                h3p_epi_block<EPI, EDGE, NO_STORE, false, CONV>(p, acc0[i][j], acc0[i][j], m0 + wm * 64 + i * 32, n0 + j * 128 + wn * 32,
                                          rs ? rs + wm * 64 + i * 32 : nullptr, wl, lane, cols[j], rows[i][j], overflow);
     };
 

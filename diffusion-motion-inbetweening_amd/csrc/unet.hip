@@ -453,6 +453,7 @@ struct UnetModel {
     // level 1 (128x128 tiles, two blocks per CU) 8.83 -> 8.70 ms/step; level 0 needs 256-row tiles (one block per CU,
     // nothing to overlap the longer epilogue with) and gains nothing, so only level 1 is on
     int fuse_gn = 2;
+    int persist = 1;      // long-K convolutions on the persistent GEMM (conv_rows)
     int m_fast = 0;      // CMDI_UNET_MFAST: tile order of the convolution GEMMs (gemm_params.hpp)
     int big_tile = 0;    // CMDI_UNET_TILE: gemm_h3 tile id for the long-K convolutions that are not split
     float *tw_all = nullptr, *tb_all = nullptr;   // the 16 time_mlp.1 Linears stacked: ONE GEMM per evaluation
@@ -609,6 +610,7 @@ UnetModel* unet_new(int n_feats, int added, int dim, const int mults[4], int max
 #endif
     // both GroupNorm schedules (separate kernels / fused epilogue) are complete and parity-tested
     if (const char* v = std::getenv("CMDI_UNET_FUSE_GN")) u->fuse_gn = std::atoi(v);
+    if (const char* v = std::getenv("CMDI_UNET_PERSIST")) u->persist = std::atoi(v);
     u->C[0] = n_feats + added;
     for (int i = 0; i < 4; ++i) u->C[i + 1] = dim * mults[i];
     u->Cin0p = (u->C[0] + 31) / 32 * 32;
@@ -827,6 +829,12 @@ int conv_rows(UnetModel* u, const Conv& c, const _Float16* ws, const _Float16* a
     }
     if (nsl_out) *nsl_out = p.ksplit > 1 ? p.ksplit : 1;
     if (!tile && u->big_tile && p.K >= 2048) tile = u->big_tile;
+    // Long-K convolutions with at least one 128 x 256 tile per CU run on the persistent kernel (gemm_h3p.hpp: same bits; its
+    // un-overlapped epilogue is <= 10 % of a tile at K >= 1536, and its request stream runs across tile boundaries): levels 0
+    // and 1 at B = 32.  CMDI_UNET_PERSIST=0 keeps the tiled kernel.
+    if (!tile && kind == H3_PLAIN && u->persist && p.ksplit <= 1 && p.K >= 1536 && p.N % 256 == 0 &&
+        (long)((p.M + 127) / 128) * (p.N / 256) >= 256 && gemm_h3p_supports(kind, p))
+        tile = 50;
     UCHK(launch_gemm_h3(kind, p, tile, s));
     return 0;
 }

@@ -1253,6 +1253,41 @@ def test_conv_rows_h3_vs_torch(kind):
     assert ok("conv_rows_h3_vs_torch.rel_l2.0", rel_l2(got.numpy(), want.numpy()), 2e-6), rel_l2(got.numpy(), want.numpy())
 
 
+@pytest.mark.parametrize("kind", ["k5", "down", "up", "k1"])
+def test_conv_rows_persistent_is_bitwise_the_tiled_kernel(kind):
+    """Round 4: the U-Net's long-K convolutions run on the persistent GEMM (gemm_h3p.hpp with tap-shifted A requests and the
+    convolution's output-row rule).  Same products in the same order: its fp32 output must equal the tiled kernel's bit for
+    bit — every addressing mode (k=5, stride 2, transposed, 1x1), a row count that leaves edge tiles and a half-tile
+    remainder, halo rows untouched (the output buffer is pre-filled with a sentinel)."""
+    eng, N = sub("engine"), sub("_native")
+    lib = N.load()
+    g = torch.Generator().manual_seed(200 + len(kind))
+    B, cin, cout = 37, 64, 512
+    T_in, h_in = 56, 4
+    taps, pad, a_mul, c_mul, c_add = dict(k5=(5, 2, 1, 0, 0), k1=(1, 0, 1, 0, 0), down=(3, 1, 2, 0, 0), up=(2, 1, 1, 2, 0))[kind]
+    T_out, h_out = (T_in // 2, h_in // 2) if kind == "down" else ((T_in * 2, h_in * 2) if kind == "up" else (T_in, h_in))
+    tp_in, tp_out = T_in + 2 * h_in, T_out + 2 * h_out
+    guard = 8
+    rows = torch.zeros(guard + B * tp_in + guard, cin)
+    rows[guard:guard + B * tp_in] = torch.randn(B * tp_in, cin, generator=g)
+    a_s = eng.split_f16(rows.to(DEV))
+    w_s = eng.split_f16((torch.randn(cout, taps * cin, generator=g) * 0.1).to(DEV))
+    bias = torch.randn(cout, generator=g).to(DEV)
+    m_gemm = B * tp_in if kind == "up" else B * tp_out
+    outs = []
+    for tile in (0, 50):
+        out = torch.full((B * tp_out, cout), -7.25, device=DEV)
+        with torch.cuda.device(DEV):
+            N.check(lib.cmdi_conv_rows_h3(a_s.data_ptr() + guard * (2 * cin) * 2, 2 * cin, N.ptr(w_s), N.ptr(bias), 0, N.ptr(out), 0,
+                                          m_gemm, cout, cin, taps, pad, a_mul, c_mul, c_add, tp_out, h_out, h_out + T_out, tile,
+                                          N.current_stream(torch.device(DEV))))
+        outs.append(out.cpu())
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+    v = outs[1].view(B, tp_out, cout)
+    assert float((v[:, :h_out] + 7.25).abs().max()) == 0.0 and float((v[:, h_out + T_out:] + 7.25).abs().max()) == 0.0
+    assert float((v[:, h_out:h_out + T_out:2 if kind == "up" else 1] + 7.25).abs().min()) > 0.0   # frames were written
+
+
 # ---- MDM_UNET denoiser (SURVEY.md §8f rank 1) -------------------------------------------------------------
 def make_unet(cases):
     mu = sub("utils.model_util")

@@ -1,6 +1,6 @@
 # round-end evidence from ONE box: bench lines of every config + single-stream kernel statistics (c2, c3, c4, unet)
 # usage (on the GPU box): bash tools/refresh_profiles.sh [tag]   -> gpurun_out/<tag>/
-tag=${1:-r3}
+tag=${1:-r4}
 mkdir -p gpurun_out/$tag
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 ( time python bench.py --gpus 1 --steps 20 --warmup 5 ) > gpurun_out/$tag/bench_c2_driver_cmd.json 2> gpurun_out/$tag/bench_c2_driver_cmd.err
