@@ -184,6 +184,12 @@ int cmdi_conv_rows_h3(const void* d_a_split, int32_t a_ld, const void* d_w_split
     p.a_ld = a_ld; p.a_row_mul = a_row_mul; p.taps = taps; p.cpt = cin / 32;
     p.c_row_mul = c_row_mul; p.c_row_add = c_row_add; p.tp = tp; p.t_lo = t_lo; p.t_hi = t_hi;
     const int kind = d_c_split ? H3_PLAIN_SPLIT : (d_resid ? H3_RESID : H3_PLAIN);
+    if (tile == 51) {   // the persistent kernel over frames only (H3Params.rc_tv): m must be whole framed sequences
+        if (tp < 1 || m % tp != 0 || t_hi <= t_lo) return fail(CMDI_E_INVALID, "tile 51 needs m % tp == 0");
+        p.rc_tv = t_hi - t_lo;
+        p.M = m / tp * p.rc_tv;
+        tile = 50;
+    }
     hipError_t err = launch_gemm_h3(kind, p, tile, static_cast<hipStream_t>(stream));
     if (err != hipSuccess) return fail(CMDI_E_HIP, std::string("launch_gemm_h3: ") + hipGetErrorString(err));
     return CMDI_OK;

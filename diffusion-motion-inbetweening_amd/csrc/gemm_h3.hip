@@ -137,6 +137,7 @@ hipError_t launch_gemm_h3(int epi, const H3Params& p, int tile, hipStream_t s) {
         (p.ln_c1 && (!p.ln_part || p.K != 512)))
         return hipErrorInvalidValue;
     if (tile == 50) return launch_gemm_h3p(epi, p, s, 0);
+    if (p.rc_tv) return hipErrorInvalidValue;      // logical-row GEMMs exist on the persistent kernel only
     if (tile == 0 && gemm_h3_persistent_for(p.M) && gemm_h3p_supports(epi, p)) return launch_gemm_h3p(epi, p, s, 0);
     if (tile >= 1000) return launch_gemm_h3p(epi, p, s, tile - 1000);   // structure variants / ablations (probes library only)
     if (tile == 0) {

@@ -107,8 +107,11 @@ __device__ __forceinline__ void h3p_epi_block(const H3Params& p, const f32x16& a
         int m = m_blk + it * 16 + rl;
         bool live = (!EDGE || m < M) && !(NO_STORE && rs != nullptr && rst[0].x != 12345.678f);
         if constexpr (CONV) {
-            if (p.c_row_mul) m = m * p.c_row_mul + p.c_row_add;
-            if (p.tp) {
+            if (p.rc_tv) {      // logical row -> physical row of the framed layout (always a frame: nothing to mask)
+                const int sq = m / p.rc_tv;
+                m = sq * p.tp + p.t_lo + (m - sq * p.rc_tv);
+            } else if (p.c_row_mul) m = m * p.c_row_mul + p.c_row_add;
+            if (p.tp && !p.rc_tv) {
                 const int pos = m % p.tp;
                 live = live && pos >= p.t_lo && pos < p.t_hi;
             }

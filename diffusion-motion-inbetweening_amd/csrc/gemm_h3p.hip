@@ -13,8 +13,12 @@ bool gemm_h3p_supports(int epi, const H3Params& p) {
     if (is_conv(p)) {   // convolution rows (U-Net): the plain fp32 epilogue only; K = taps * cpt * 32
         if (epi != H3_PLAIN || p.ln_part || p.ln_c1 || p.aux) return false;
         if (p.cpt < 1 || p.taps < 1 || p.K != p.taps * p.cpt * 32 || (p.a_ld && p.a_ld < 2 * p.cpt * 32)) return false;
+        if (p.rc_tv && (p.rc_tv < 1 || p.tp < 1 || p.a_row_mul > 1 || p.c_row_mul || p.t_lo < 0 || p.t_lo + p.rc_tv > p.tp ||
+                        p.M % p.rc_tv != 0))
+            return false;
         const size_t a_row = 2 * (p.a_ld ? (size_t)p.a_ld : 2 * (size_t)p.K) * (size_t)(p.a_row_mul ? p.a_row_mul : 1);
-        if ((size_t)p.M * a_row + (size_t)p.taps * a_row >= (1ull << 31)) return false;
+        const size_t phys_rows = p.rc_tv ? (size_t)(p.M / p.rc_tv) * p.tp : (size_t)p.M;
+        if (phys_rows * a_row + (size_t)p.taps * a_row >= (1ull << 31)) return false;
     } else if ((size_t)p.M * 4 * (size_t)p.K >= (1ull << 31)) {
         return false;
     }

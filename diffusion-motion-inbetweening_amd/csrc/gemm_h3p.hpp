@@ -122,6 +122,9 @@ __global__ __launch_bounds__(H3PTile::NT, 2) void gemm_h3p_kernel(const H3Params
             if (r < TC::BM) {
                 int grow = m0 + r;
                 grow = grow < M ? grow : M - 1;
+                if constexpr (CONV) {
+                    if (p.rc_tv) { const int sq = grow / p.rc_tv; grow = sq * p.tp + p.t_lo + (grow - sq * p.rc_tv); }   // logical -> physical row
+                }
                 src_off[q] = (unsigned)grow * a_rstep + sw;
             } else {
                 int c = n0 + r - TC::BM;

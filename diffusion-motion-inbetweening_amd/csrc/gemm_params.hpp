@@ -91,6 +91,10 @@ struct H3Params {
     // if that row's position inside its tp-row sequence frame lies in [t_lo, t_hi) (halo rows stay zero).
     int a_ld, a_row_mul, taps, cpt;
     int c_row_mul, c_row_add, tp, t_lo, t_hi;
+    int rc_tv;          // > 0 (persistent kernel, convolutions with a_row_mul <= 1 and no c_row_mul): GEMM row g is only a
+                        // LOGICAL row — frame g % rc_tv of sequence g / rc_tv, i.e. physical row (g / rc_tv) * tp + t_lo +
+                        // g % rc_tv of both the A rows and the output; M counts rc_tv rows per sequence, so the halo rows of
+                        // the framed layout (12.5 % of a 256-row frame) are neither multiplied nor masked
     int cs_ld;          // halves per row of the split output (0 = 2N); Cs may point at a column block of a wider matrix
     int cs_head_major;  // H3_PLAIN_SPLIT: write the output head-major — column block n / 128 (= q|k|v x head) is its own
                         // [M][128] split matrix (512 contiguous bytes per token): what attention_h3 streams per (sequence, head)

@@ -453,7 +453,7 @@ struct UnetModel {
     // level 1 (128x128 tiles, two blocks per CU) 8.83 -> 8.70 ms/step; level 0 needs 256-row tiles (one block per CU,
     // nothing to overlap the longer epilogue with) and gains nothing, so only level 1 is on
     int fuse_gn = 2;
-    int persist = 1;      // long-K convolutions on the persistent GEMM (conv_rows)
+    int persist = 2;      // CMDI_UNET_PERSIST: 1 = long-K convolutions on the persistent GEMM (conv_rows), 2 = ... over frames only
     int m_fast = 0;      // CMDI_UNET_MFAST: tile order of the convolution GEMMs (gemm_params.hpp)
     int big_tile = 0;    // CMDI_UNET_TILE: gemm_h3 tile id for the long-K convolutions that are not split
     float *tw_all = nullptr, *tb_all = nullptr;   // the 16 time_mlp.1 Linears stacked: ONE GEMM per evaluation
@@ -833,8 +833,17 @@ int conv_rows(UnetModel* u, const Conv& c, const _Float16* ws, const _Float16* a
     // un-overlapped epilogue is <= 10 % of a tile at K >= 1536, and its request stream runs across tile boundaries): levels 0
     // and 1 at B = 32.  CMDI_UNET_PERSIST=0 keeps the tiled kernel.
     if (!tile && kind == H3_PLAIN && u->persist && p.ksplit <= 1 && p.K >= 1536 && p.N % 256 == 0 &&
-        (long)((p.M + 127) / 128) * (p.N / 256) >= 256 && gemm_h3p_supports(kind, p))
+        (long)((p.M + 127) / 128) * (p.N / 256) >= 224 && gemm_h3p_supports(kind, p)) {
         tile = 50;
+        // frames only: the GEMM walks the Tv valid frames of every sequence instead of all Tp framed rows (the halo rows'
+        // products were computed and thrown away: 12.5 % of the work); same products for the rows that are computed
+        if (u->persist >= 2 && a_mul <= 1 && !c_mul && m_rows % lo.Tp == 0) {
+            H3Params q = p;
+            q.rc_tv = lo.Tv;
+            q.M = m_rows / lo.Tp * lo.Tv;
+            if (gemm_h3p_supports(kind, q)) p = q;
+        }
+    }
     UCHK(launch_gemm_h3(kind, p, tile, s));
     return 0;
 }
