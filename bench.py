@@ -337,7 +337,8 @@ def roofline_from(eng, run_loop, split, is_unet, pmc):
         # product, so its ceiling is the dense f16 peak / 3
         peak = F16_MFMA_PEAK_TFLOPS / 3.0
         what = ("unet.downs.0.1.blocks.1 Conv1d k=5 as a tap-shifted GEMM" if is_unet else "self_attn.in_proj")
-        rl.update(kernel=f"gemm_h3_kernel ({what}, M={m} N={n} K={k}, 3x v_mfma_f32_32x32x16_f16 per fp32-equivalent "
+        kname = "gemm_h3p_kernel (persistent, frames only: " if is_unet else "gemm_h3_kernel ("
+        rl.update(kernel=f"{kname}{what}, M={m} N={n} K={k}, 3x v_mfma_f32_32x32x16_f16 per fp32-equivalent "
                          "product" + ("" if is_unet else ", split-rows output") + ")",
                   peak=peak, frac=ach / peak, executed_f16_tflops=3.0 * ach, f16_dense_peak=F16_MFMA_PEAK_TFLOPS,
                   vs_fp32_mfma_peak=ach / FP32_MFMA_PEAK_TFLOPS)
