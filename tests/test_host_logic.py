@@ -327,3 +327,32 @@ def test_const_noise_is_refused_like_the_reference_refuses_it():
         for fn in (ref.gd.GaussianDiffusion.p_sample, ref.gd.GaussianDiffusion.ddim_sample_loop):
             src = inspect.getsource(fn)
             assert re.search(r"if const_noise[^\n]*:\s*\n\s*raise NotImplementedError\(\)", src), fn
+
+
+def test_attention_backward_isa_audit(tmp_path):
+    """The attention backward kernels (csrc/attention_bwd_h3.hip) issue their transposed / statistics LDS reads as inline asm,
+    which hipcc neither counts nor protects: under register pressure it may copy or spill a destination register before the
+    data has landed (round 4: a variant of these kernels that spilled produced NaN gradients exactly this way).  Compile
+    the file to gfx950 ISA and check (tools/audit_asm_loads.py) that nothing touches such a register between its load and
+    the hand-written wait, and that neither backward kernel uses scratch memory (one wave per SIMD, <= 512 registers)."""
+    import shutil
+    import subprocess
+    import sys
+    from pathlib import Path
+    from conftest import PKG
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(hipcc).exists():
+        pytest.skip("hipcc not available")
+    src = REPO / PKG / "csrc" / "attention_bwd_h3.hip"
+    out = tmp_path / "attention_bwd_h3.s"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-gpu-rdc", "-I", str(src.parent), "-S",
+                        "--cuda-device-only", "-o", str(out), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = out.read_text()
+    scratch = [int(v) for v in re.findall(r"; ScratchSize: (\d+)", text)]
+    regs = [int(v) for v in re.findall(r"; TotalNumVgprs: (\d+)", text)]
+    assert len(scratch) == 3 and all(v == 0 for v in scratch), scratch       # qstat, dK+dV, dQ
+    assert max(regs) <= 512, regs
+    a = subprocess.run([sys.executable, str(REPO / "tools" / "audit_asm_loads.py"), str(out)], capture_output=True, text=True)
+    assert a.returncode == 0, a.stdout[-2000:]
+    assert re.search(r"(\d+) hand-issued LDS loads, 0 violations", a.stdout) and int(re.search(r"(\d+) hand-issued", a.stdout).group(1)) >= 64
