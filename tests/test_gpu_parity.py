@@ -160,6 +160,32 @@ def test_gemm_h3_persistent_is_bitwise_the_tiled_kernel(shape):
     assert ok("gemm_h3_persistent_is_bitwise_the_tiled_kernel.rel_l2.0", rel_l2(eng.gemm_h3(a_s, w_s, b, tile=50).cpu().numpy(), ref64.cpu().numpy()), 2e-6)
 
 
+def test_persistent_gemm_keep_path_is_bitwise_the_tiled_schedule(cases, tmp_path):
+    """at M >= 32,768 rows (B = 256) the stashing forward pass of a reconstruction-guidance step runs its folded-
+    LayerNorm GEMMs (ln_part, ln_c1, ln_rg, out_part, ln_stats, aux under a folded A operand, C + Cs together) on the
+    PERSISTENT kernel, which no golden reaches at that size.  Here the same schedule is forced on the small goldens:
+    CMDI_H3_PERSIST=1 (read once per process, hence the subprocesses) sends every supported GEMM to gemm_h3p.  Forward with
+    stash, input-VJP and a reconstruction-guidance chain must equal the tiled schedule BIT FOR BIT, and meet the
+    reference's golden values."""
+    import os
+    import subprocess
+    import sys
+    helper = str(__import__("pathlib").Path(__file__).resolve().parent / "helpers" / "persist_probe.py")
+    outs = {}
+    for mode in ("0", "1"):
+        path = tmp_path / f"persist{mode}.npz"
+        env = dict(os.environ, CMDI_H3_PERSIST=mode)
+        r = subprocess.run([sys.executable, helper, str(path)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[mode] = np.load(path)
+    for key in ("vjp_out", "vjp_gx", "chain_final"):
+        assert np.array_equal(outs["0"][key], outs["1"][key]), key
+    g = load_golden("vjp_text_cfg")
+    assert ok("persistent_keep_path.fwd", rel_l2(outs["1"]["vjp_out"], g["out"]), 2e-5)
+    assert ok("persistent_keep_path.vjp", rel_l2(outs["1"]["vjp_gx"], g["gx"]), 5e-5)
+    assert ok("persistent_keep_path.chain", rel_l2(outs["1"]["chain_final"], load_golden("chain_edit_recon")["final"]), 1e-4)
+
+
 # ---- bf16x6: exact three-plane bf16 operands, six MFMA products (fp32-class, no operand truncation) -----------------
 def test_pack_x6_is_exact():
     """W = p0 + p1 + p2 EXACTLY for every finite binary32 (24 significant bits = three bf16 mantissas), over the whole
