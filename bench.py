@@ -221,6 +221,10 @@ def cpu_baseline_unet(sd, B, n_steps=5):
                           f"on a host with {host} logical CPUs)"})
     return res
 
+N_SIMD = 1024            # 256 CUs x 4 SIMDs
+N_XCD = 8
+
+
 def pmc_counters(config: str, precision: str, batch: int, timeout_s: float = 150.0):
     """rocprofv3 --pmc sub-runs of `bench.py --pmc-child` for THIS config and precision (counters serialise kernels, so
     they never run inside the timed region): per launch of the dominant GEMM (the largest-grid gemm kernel = the

@@ -356,3 +356,35 @@ def test_attention_backward_isa_audit(tmp_path):
     a = subprocess.run([sys.executable, str(REPO / "tools" / "audit_asm_loads.py"), str(out)], capture_output=True, text=True)
     assert a.returncode == 0, a.stdout[-2000:]
     assert re.search(r"(\d+) hand-issued LDS loads, 0 violations", a.stdout) and int(re.search(r"(\d+) hand-issued", a.stdout).group(1)) >= 64
+
+
+def test_no_undefined_names_in_bench_and_package():
+    """A module-level constant deleted by an edit shows up only when its line runs — on the GPU box (round 4: `N_XCD` vanished
+    from bench.py with a neighbouring function and the roofline leg died there).  Static check: every name loaded anywhere in
+    bench.py, __graft_entry__.py, tools/*.py and the package's modules is bound somewhere in its module (or is a builtin)."""
+    import ast
+    import builtins
+    from conftest import PKG
+    files = [REPO / "bench.py", REPO / "__graft_entry__.py"] + sorted((REPO / "tools").glob("*.py")) + \
+        sorted((REPO / PKG).rglob("*.py"))
+    assert len(files) > 20
+    for path in files:
+        tree = ast.parse(path.read_text())
+        bound = set(dir(builtins)) | {"__file__", "__name__", "__doc__"}
+        for node in ast.walk(tree):
+            if isinstance(node, (ast.FunctionDef, ast.ClassDef, ast.AsyncFunctionDef)):
+                bound.add(node.name)
+            elif isinstance(node, ast.Import):
+                bound |= {a.asname or a.name.split(".")[0] for a in node.names}
+            elif isinstance(node, ast.ImportFrom):
+                bound |= {a.asname or a.name for a in node.names}
+            elif isinstance(node, ast.arg):
+                bound.add(node.arg)
+            elif isinstance(node, ast.ExceptHandler) and node.name:
+                bound.add(node.name)
+            elif isinstance(node, ast.Name) and isinstance(node.ctx, (ast.Store, ast.Del)):
+                bound.add(node.id)
+            elif isinstance(node, (ast.Global, ast.Nonlocal)):
+                bound |= set(node.names)
+        used = {n.id for n in ast.walk(tree) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load)}
+        assert not (used - bound), (str(path.relative_to(REPO)), sorted(used - bound))
