@@ -523,6 +523,7 @@ def main():
         return
     x_default = x.clone()   # (the roofline leg below replays the K steps on x in place)
     split = eng.precision == "f16x3"
+    main_prec = eng.precision
 
     # the path's only collective: reassemble the generated sequences (outside the timed steps)
     t1 = time.perf_counter()
@@ -597,8 +598,9 @@ def main():
     if rank == 0 and world == 1 and not is_unet and not args.no_graph_leg and args.precision is None:
         legs = {}
         kinds = ("ddim", "ddpm") if args.config == "c4" else (cfg["sampler"],)
-        model.native_precision = None
+        model.native_precision = main_prec     # (pinned: with None, engine() would hand back the f32 engine of the leg above)
         eng_g = model.engine(dev, max_batch=B, max_frames=T_FRAMES, want_grad=cfg["edit"])
+        assert eng_g.precision == main_prec
         for kind in kinds:
             sid = N.CMDI_SAMPLER_DDIM if kind == "ddim" else N.CMDI_SAMPLER_DDPM
             leg = {}
@@ -624,6 +626,7 @@ def main():
             leg["pipeline_parts"] = eng_g.pipeline_parts()
             legs[{"ddim": "ddim_sample_loop", "ddpm": "p_sample_loop"}[kind]] = leg
         eng_g.set_graph(args.graph)
+        model.native_precision = None
         out["hip_graph_legs"] = legs
 
     if rank == 0 and world == 1 and not args.no_cpu and not (is_unet and cfg["edit"]):
