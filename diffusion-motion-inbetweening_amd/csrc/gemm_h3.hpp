@@ -38,6 +38,12 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #else
 #define CMDI_DBG(p) 0
 #endif
+// Compile-time ablations of the K step (tools/probes/kstep.hip only; 0 everywhere else): 1 = no operand requests inside the
+// loop, 2 = no MFMAs (the fragments are xor-ed into a sink), 4 = no fragment reads (loop-invariant registers), 8 = no
+// end-of-step waits / barrier, 32 = requests behind the products instead of in front of the fragment reads
+#ifndef CMDI_KABL
+#define CMDI_KABL 0
+#endif
 
 constexpr float kLoScale = 2048.0f;          // 2^11
 constexpr float kLoInv = 1.0f / 2048.0f;
@@ -772,13 +778,28 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
     __builtin_amdgcn_s_barrier();
 
     if (CMDI_DBG(p) & 16) t_loop = __builtin_readcyclecounter();
+#if CMDI_KABL
+    h8 kabl_frag;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) kabl_frag[e] = (_Float16)(0.001f * (float)(lane + e));
+    unsigned kabl_sink = 0;
+#endif
     {
     int cur = 0, nxt = NSTAGE - 1;   // stage being multiplied / stage being filled
     for (int kt = kt0; kt < nk; ++kt) {
         const bool more = kt + NSTAGE - 1 < nk;
-        if (more && !(CMDI_DBG(p) & 1)) issue(kt + NSTAGE - 1, nxt);
+        if (!(CMDI_KABL & (1 | 32)) && more && !(CMDI_DBG(p) & 1)) issue(kt + NSTAGE - 1, nxt);
         const char* st = lds + cur * STAGE;
         h8 ah[2][TM], al[2][TM], wh[2][TN], wl[2][TN];
+#if CMDI_KABL & 4
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) { ah[ks][i] = kabl_frag; al[ks][i] = kabl_frag; }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) { wh[ks][j] = kabl_frag; wl[ks][j] = kabl_frag; }
+        }
+#else
 #if CMDI_H3_SETPRIO
         __builtin_amdgcn_s_setprio(CMDI_H3_SETPRIO);
 #endif
@@ -795,6 +816,16 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
                 wl[ks][j] = *reinterpret_cast<const h8*>(st + w_row + j * 4096 + off_lo[ks]);
             }
         }
+#endif
+#if CMDI_KABL & 2
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) kabl_sink ^= __builtin_bit_cast(uint4, ah[ks][i]).x ^ __builtin_bit_cast(uint4, al[ks][i]).w;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) kabl_sink ^= __builtin_bit_cast(uint4, wh[ks][j]).x ^ __builtin_bit_cast(uint4, wl[ks][j]).w;
+        }
+#else
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -822,20 +853,27 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 6 * TM * TN - 2 * (TM + TN), 0);
+#endif
 #if CMDI_H3_SETPRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
+        if ((CMDI_KABL & 32) && more) issue(kt + NSTAGE - 1, nxt);
+#if !(CMDI_KABL & 8)
         // stage kt+1 must have landed (this wave's pieces; the barrier extends it to every wave's);
         // with 3 stages the pieces of stage kt+2, issued above, stay in flight across the barrier
         if (NSTAGE == 3 && more) wait_vmcnt<PW>(); else wait_vmcnt<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+#endif
         cur = cur + 1 == NSTAGE ? 0 : cur + 1;
         nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
     }
     }
 
     if (CMDI_DBG(p) & 16) t_loop_end = __builtin_readcyclecounter();
+#if CMDI_KABL
+    if (kabl_sink == 0x12345678u) acc0[0][0][0] += 1.0f;
+#endif
     h3_epilogue<TC, EPI>(p, acc0, acc1, m0, n0, M, kslice, lds);
     if ((CMDI_DBG(p) & 16) && p.dbg_buf && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
