@@ -36,7 +36,8 @@ constexpr int TILE = KBLK * ROWB;        // 16 KiB per K or V tile
 constexpr int STAGE = 2 * TILE;
 constexpr int NSTG = 4;                  // LDS ring: 3 stages (96 KiB) in flight ahead of the one being used
 constexpr int kAttnStagDefault = 1;      // two wave groups half a stage apart (attention_h3_kernel); probes build: CMDI_ATTN_STAG
-constexpr int kAttnSplitDefault = 0;     // see launch_attention_h3 (measured: 36.7 vs 35.1 us per layer — no gain, so off)
+constexpr int kAttnSplitDefault = -1;    // -1 = by grid size, see launch_attention_h3 (at one block per CU, B = 32: 36.7 vs 35.1 us
+                                         // per layer — no gain; below half a chip of (sequence, head) pairs the split wins)
 
 typedef short s4v __attribute__((ext_vector_type(4)));
 typedef short s8v __attribute__((ext_vector_type(8)));
@@ -415,8 +416,23 @@ hipError_t launch_attention_h3(const _Float16* qkv_split, float* out, _Float16* 
 #else
     constexpr int dbg = 0;
 #endif
-    // schedule: CMDI_ATTN_SPLIT = 1 -> two 4-wave blocks per (sequence, head), two blocks per CU; 0 -> one 8-wave block
-    static const int split = std::getenv("CMDI_ATTN_SPLIT") ? std::atoi(std::getenv("CMDI_ATTN_SPLIT")) : kAttnSplitDefault;
+    // schedule: CMDI_ATTN_SPLIT = 1 -> two 4-wave blocks per (sequence, head), two blocks per CU; 0 -> one 8-wave block;
+    // unset -> by grid size (round 4): while the (sequence, head) pairs fill at most half the CUs (B <= 16 with CFG) the two
+    // halves of a pair's queries run on two CUs, one wave per SIMD instead of two: 23.6 -> 19 us per layer at B = 2,
+    // 25 -> 17 us at B = 10 (0.80 -> 0.76 and 0.99 -> 0.92 ms per step).  A wave computes its 32 queries with the same
+    // instruction sequence in both schedules: same bits (test_attention_split_schedule_is_bitwise_identical).
+    static const int split_env = std::getenv("CMDI_ATTN_SPLIT") ? std::atoi(std::getenv("CMDI_ATTN_SPLIT")) : kAttnSplitDefault;
+    bool split = split_env > 0;
+    if (split_env < 0) {
+        static int cus_dev[kMaxDevices] = {};
+        int& cus = cus_dev[device_slot()];
+        if (!cus) {
+            int dev = 0, n = 256;
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+            cus = n > 0 ? n : 256;
+        }
+        split = 2L * n_seq * H <= cus;
+    }
     if (split && S > 128)
         return launch_attention_h3_cfg<4, 2>(qkv_split, out, out_split, range_flag, row_stats, n_seq, S, H, dbg, head_rows, stream);
 #ifdef CMDI_PROBES

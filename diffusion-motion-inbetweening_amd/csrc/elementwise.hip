@@ -227,23 +227,26 @@ __global__ void token0_kernel(float* __restrict__ tok, const float* __restrict__
 }
 
 // Frame rows for the input projection on the f16 pipe: x [nb][C][T] (T contiguous) -> split rows
-// [nb*T][2*Kp] (Kp = C rounded up to 32, zero padded).  A block transposes 32 frames of one sequence
-// through LDS: reads run along T, writes along the features.
+// [nb*T][2*Kp] (Kp = C rounded up to 32, zero padded).  A block transposes 32 frames x 64 features of one sequence
+// through LDS: reads run along T, writes along the features.  (Round 4: the feature axis is part of the grid — one block
+// per (32 frames, sequence) looped 36 times over its 288 feature rows and took 13-15 us at EVERY batch size.)
+constexpr int POSE_FC = 64;   // features per block = two 32-column chunks of the split row
 __global__ __launch_bounds__(256) void pose_rows_split_kernel(const float* __restrict__ x, _Float16* __restrict__ xs,
                                                              int C, int T, int Kp, int* __restrict__ range_flag) {
-    extern __shared__ float tile[];   // [Kp][33]
-    const int b = blockIdx.y, t0 = blockIdx.x * 32;
+    __shared__ float tile[POSE_FC * 33];
+    const int b = blockIdx.y, t0 = blockIdx.x * 32, c0 = blockIdx.z * POSE_FC;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 frames x 8 feature lanes
+    const int nc = Kp - c0 < POSE_FC ? Kp - c0 : POSE_FC;     // 64, or 32 in the last block of a 288-column row
     const float* xb = x + (size_t)b * C * T;
     bool overflow = false;
-    for (int c = ty; c < Kp; c += 8) {
+    for (int c = ty; c < nc; c += 8) {
         float v = 0.f;
-        if (c < C && t0 + tx < T) v = xb[(size_t)c * T + t0 + tx];
+        if (c0 + c < C && t0 + tx < T) v = xb[(size_t)(c0 + c) * T + t0 + tx];
         overflow |= !(fabsf(v) < 65504.0f);
         tile[c * 33 + tx] = v;
     }
     __syncthreads();
-    const int chunks = Kp >> 3;   // 8 consecutive features per thread-item
+    const int chunks = nc >> 3;   // 8 consecutive features per thread-item
     for (int it = threadIdx.x; it < 32 * chunks; it += 256) {
         const int fr = it / chunks, c = (it - fr * chunks) * 8;
         if (t0 + fr >= T) continue;
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(256) void pose_rows_split_kernel(const float* __res
             split_f16(tile[(c + e) * 33 + fr], h, l);
             oh[e] = h; ol[e] = l;
         }
-        _Float16* dst = xs + ((size_t)b * T + t0 + fr) * (2 * Kp) + split_pos(c);
+        _Float16* dst = xs + ((size_t)b * T + t0 + fr) * (2 * Kp) + split_pos(c0 + c);
         *reinterpret_cast<h8*>(dst) = oh;
         *reinterpret_cast<h8*>(dst + 32) = ol;
     }
@@ -263,7 +266,8 @@ __global__ __launch_bounds__(256) void pose_rows_split_kernel(const float* __res
 
 hipError_t launch_pose_rows_split(const float* x, _Float16* xs, int nb, int C, int T, int Kp, int* range_flag,
                                   hipStream_t stream) {
-    hipLaunchKernelGGL(pose_rows_split_kernel, dim3((T + 31) / 32, nb), dim3(256), (size_t)Kp * 33 * sizeof(float),
+    if (Kp % 32 != 0 || Kp < C) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pose_rows_split_kernel, dim3((T + 31) / 32, nb, (Kp + POSE_FC - 1) / POSE_FC), dim3(256), 0,
                        stream, x, xs, C, T, Kp, range_flag);
     return hipGetLastError();
 }

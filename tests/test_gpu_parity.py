@@ -186,6 +186,30 @@ def test_persistent_gemm_keep_path_is_bitwise_the_tiled_schedule(cases, tmp_path
     assert ok("persistent_keep_path.chain", rel_l2(outs["1"]["chain_final"], load_golden("chain_edit_recon")["final"]), 1e-4)
 
 
+def test_attention_split_schedule_is_bitwise_identical(tmp_path):
+    """Round 4: below half a chip of (sequence, head) pairs the attention core runs as two 4-wave blocks per pair
+    (attention_h3.hip launch_attention_h3).  A sample must not depend on the schedule its batch size selects: forced off,
+    forced on and the default give the same bits, at a small batch, at S = 129 (second block holds one query) and at a
+    batch that fills the chip."""
+    import os
+    import subprocess
+    import sys
+    helper = str(__import__("pathlib").Path(__file__).resolve().parent / "helpers" / "attn_split_probe.py")
+    outs = {}
+    for mode in ("0", "1", None):
+        path = tmp_path / f"split{mode}.npz"
+        env = {k: v for k, v in os.environ.items() if k != "CMDI_ATTN_SPLIT"}
+        if mode is not None:
+            env["CMDI_ATTN_SPLIT"] = mode
+        r = subprocess.run([sys.executable, helper, str(path)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[mode] = np.load(path)
+    for key in ("small", "edge", "big"):
+        assert np.isfinite(outs["0"][key]).all()
+        assert np.array_equal(outs["0"][key], outs["1"][key]), key
+        assert np.array_equal(outs["0"][key], outs[None][key]), key
+
+
 # ---- bf16x6: exact three-plane bf16 operands, six MFMA products (fp32-class, no operand truncation) -----------------
 def test_pack_x6_is_exact():
     """W = p0 + p1 + p2 EXACTLY for every finite binary32 (24 significant bits = three bf16 mantissas), over the whole
