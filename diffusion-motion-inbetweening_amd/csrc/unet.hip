@@ -200,6 +200,100 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     if (overflow && range_flag) atomicOr(range_flag, 1);
 }
 
+// ---- GroupNorm in ONE pass (round 4): one block per (sequence, group) keeps the group's Tv x C/8 values in registers (at
+// most 28 float4 per thread: 224 frames x 128 channels), so the convolution output is read once instead of three times and a
+// GroupNorm is one launch instead of two (25 per evaluation, 12-26 us each for either kernel).  Same thread -> element map,
+// same summation order and the same element formulas as gn_stats_kernel / gn_apply_kernel above, which stay as the fallback
+// for geometries that do not fit (and as the specification).  stats (optional): (mean, rstd) for a stashing forward pass.
+constexpr int GNF_MAXV = 28;
+__global__ __launch_bounds__(256) void gn_fused_kernel(const float* __restrict__ x, float* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ ss, const float* __restrict__ resid,
+                                                       float* __restrict__ yf, _Float16* __restrict__ ys, int ys_ld,
+                                                       int* __restrict__ range_flag, int C, int Tp, int h, int Tv, int ss_ld,
+                                                       int nsl, size_t sl) {
+    __shared__ float red[4];
+    const int seq = blockIdx.x, g = blockIdx.y, cg = C / NG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t row0 = (size_t)seq * Tp + h;
+    const float* base = x + row0 * C + (size_t)g * cg;
+    const int q4 = cg / 4;                    // float4 per row of the group
+    const int total = Tv * q4;
+    float4 v[GNF_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < GNF_MAXV; ++k) {
+        const int i = tid + 256 * k;
+        if (i < total) {
+            const int r = i / q4, c4 = i - r * q4;
+            v[k] = load_slices(base + (size_t)r * C + c4 * 4, nsl, sl);
+            s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+        }
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)(Tv * cg);
+    __syncthreads();
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < GNF_MAXV; ++k) {
+        if (tid + 256 * k < total) {
+            const float a = v[k].x - mean, b = v[k].y - mean, c = v[k].z - mean, d = v[k].w - mean;
+            q += (a * a + b * b) + (c * c + d * d);
+        }
+    }
+    q = wave_sum(q);
+    if (lane == 0) red[wave] = q;
+    __syncthreads();
+    const float var = ((red[0] + red[1]) + (red[2] + red[3])) / (float)(Tv * cg);
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    if (tid == 0 && stats) {
+        stats[((size_t)seq * NG + g) * 2] = mean;
+        stats[((size_t)seq * NG + g) * 2 + 1] = rstd;
+    }
+    bool overflow = false;
+#pragma unroll
+    for (int k = 0; k < GNF_MAXV; ++k) {
+        const int i = tid + 256 * k;
+        if (i >= total) continue;
+        const int r = i / q4, c4 = i - r * q4;
+        const int c = g * cg + c4 * 4;
+        const size_t row = row0 + r;
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+        const float4 be = *reinterpret_cast<const float4*>(beta + c);
+        float y[4] = {(v[k].x - mean) * rstd * ga.x + be.x, (v[k].y - mean) * rstd * ga.y + be.y,
+                      (v[k].z - mean) * rstd * ga.z + be.z, (v[k].w - mean) * rstd * ga.w + be.w};
+        if (ss) {
+            const float4 sc = *reinterpret_cast<const float4*>(ss + (size_t)seq * ss_ld + c);
+            const float4 sh = *reinterpret_cast<const float4*>(ss + (size_t)seq * ss_ld + C + c);
+            y[0] = y[0] * (1.f + sc.x) + sh.x; y[1] = y[1] * (1.f + sc.y) + sh.y;
+            y[2] = y[2] * (1.f + sc.z) + sh.z; y[3] = y[3] * (1.f + sc.w) + sh.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = mish(y[e]);
+        if (resid) {
+            const float4 rr = *reinterpret_cast<const float4*>(resid + row * C + c);
+            y[0] += rr.x; y[1] += rr.y; y[2] += rr.z; y[3] += rr.w;
+        }
+        if (yf) *reinterpret_cast<float4*>(yf + row * C + c) = make_float4(y[0], y[1], y[2], y[3]);
+        if (ys) {
+            h4 oh, ol;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                _Float16 a, l;
+                split_f16(y[e], a, l);
+                oh[e] = a; ol[e] = l;
+                overflow |= !(fabsf(y[e]) < 65504.0f);
+            }
+            _Float16* d = ys + row * ys_ld + split_pos(c);
+            *reinterpret_cast<h4*>(d) = oh;
+            *reinterpret_cast<h4*>(d + 32) = ol;
+        }
+    }
+    if (overflow && range_flag) atomicOr(range_flag, 1);
+}
+
 // ---- input-VJP pieces (reconstruction guidance through the U-Net): everything is linear in the output gradient ----
 __device__ __forceinline__ float mish_grad(float z) { return mish_grad_f(z); }
 
@@ -453,6 +547,7 @@ struct UnetModel {
     // level 1 (128x128 tiles, two blocks per CU) 8.83 -> 8.70 ms/step; level 0 needs 256-row tiles (one block per CU,
     // nothing to overlap the longer epilogue with) and gains nothing, so only level 1 is on
     int fuse_gn = 2;
+    int gn_one_pass = 1;  // CMDI_UNET_GN1: GroupNorm as one register-resident pass (gn_fused_kernel) instead of statistics + apply
     int persist = 2;      // CMDI_UNET_PERSIST: 1 = long-K convolutions on the persistent GEMM (conv_rows), 2 = ... over frames only
     int m_fast = 0;      // CMDI_UNET_MFAST: tile order of the convolution GEMMs (gemm_params.hpp)
     int big_tile = 0;    // CMDI_UNET_TILE: gemm_h3 tile id for the long-K convolutions that are not split
@@ -611,6 +706,7 @@ UnetModel* unet_new(int n_feats, int added, int dim, const int mults[4], int max
     // both GroupNorm schedules (separate kernels / fused epilogue) are complete and parity-tested
     if (const char* v = std::getenv("CMDI_UNET_FUSE_GN")) u->fuse_gn = std::atoi(v);
     if (const char* v = std::getenv("CMDI_UNET_PERSIST")) u->persist = std::atoi(v);
+    if (const char* v = std::getenv("CMDI_UNET_GN1")) u->gn_one_pass = std::atoi(v);
     u->C[0] = n_feats + added;
     for (int i = 0; i < 4; ++i) u->C[i + 1] = dim * mults[i];
     u->Cin0p = (u->C[0] + 31) / 32 * 32;
@@ -853,6 +949,12 @@ int group_norm(UnetModel* u, const float* x, int nsl, const GN& n, const float* 
     const Lvl L = lvl(level);
     const int C = u->C[1];
     const size_t sl = (size_t)nseq * L.Tp * C;   // floats between the split-K slices of x
+    if (u->gn_one_pass && L.Tv * (C / NG / 4) <= 256 * GNF_MAXV) {   // CMDI_UNET_GN1=0: the two kernels below
+        hipLaunchKernelGGL(gn_fused_kernel, dim3(nseq, NG), dim3(256), 0, s, x, stats, n.g, n.b, ss, resid, yf, ys, ys_ld,
+                           u->range_flag, C, L.Tp, L.h, L.Tv, u->ss_ld, nsl, sl);
+        UCHK(hipGetLastError());
+        return 0;
+    }
     if (!stats) stats = u->stats;                // (a stashing forward pass keeps them per GroupNorm)
     hipLaunchKernelGGL(gn_stats_kernel, dim3(nseq, NG), dim3(256), 0, s, x, stats, C, L.Tp, L.h, L.Tv, nsl, sl);
     hipLaunchKernelGGL(gn_apply_kernel, dim3((L.Tv + 3) / 4, nseq), dim3(256), 0, s, x, stats, n.g, n.b, ss, resid, yf,
