@@ -543,10 +543,12 @@ struct UnetModel {
     int ksplit_ok = 1;   // CMDI_UNET_KSPLIT=0: no split-K at the coarse levels
     hipEvent_t probe_ev[2] = {nullptr, nullptr};   // bench: events around ONE convolution GEMM (downs.0.1, blocks.1)
     int probe_mnk[3] = {0, 0, 0};
-    // CMDI_UNET_FUSE_GN: bit l = fuse convolution + GroupNorm at level l (0, 1); 0 = separate kernels.  Measured at B=32:
-    // level 1 (128x128 tiles, two blocks per CU) 8.83 -> 8.70 ms/step; level 0 needs 256-row tiles (one block per CU,
-    // nothing to overlap the longer epilogue with) and gains nothing, so only level 1 is on
-    int fuse_gn = 2;
+    // CMDI_UNET_FUSE_GN: bit l = fuse convolution + GroupNorm at level l (0, 1) into ONE GEMM (H3_CONV_GN); 0 = convolution on
+    // the persistent / tiled GEMM + the one-pass GroupNorm kernel.  Round 2 (two GroupNorm kernels per norm): fusing level 1
+    // (128x128 tiles, two blocks per CU) 8.83 -> 8.70 ms/step; level 0 needs 256-row tiles and gained nothing.  Round 4: with
+    // the convolution over frames only on the persistent kernel and GroupNorm as one pass, no fusion is the fastest
+    // (B=32, same box, alternating: 0: 7.50-7.52, 1: 7.51-7.53, 2: 7.53-7.58, 3: 7.59 ms/step) -> default 0
+    int fuse_gn = 0;
     int gn_one_pass = 1;  // CMDI_UNET_GN1: GroupNorm as one register-resident pass (gn_fused_kernel) instead of statistics + apply
     int persist = 2;      // CMDI_UNET_PERSIST: 1 = long-K convolutions on the persistent GEMM (conv_rows), 2 = ... over frames only
     int m_fast = 0;      // CMDI_UNET_MFAST: tile order of the convolution GEMMs (gemm_params.hpp)

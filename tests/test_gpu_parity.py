@@ -1502,10 +1502,10 @@ def test_unet_attention_vs_oracle_other_shapes(cases, B, T):
     assert ok("unet_attention_vs_oracle_other_shapes.max_abs.0", max_abs(got, want), 2e-4) and ok("unet_attention_vs_oracle_other_shapes.rel_l2.0", rel_l2(got, want), 2e-5), (max_abs(got, want), rel_l2(got, want))
 
 
-@pytest.mark.parametrize("fuse", ["0", "3"])
+@pytest.mark.parametrize("fuse", ["0", "2", "3"])
 def test_unet_forward_groupnorm_fusion_modes(cases, monkeypatch, fuse):
-    """CMDI_UNET_FUSE_GN = 0 (separate GroupNorm kernels everywhere) and 3 (fused epilogue at levels 0 AND 1; the default
-    fuses level 1 only) give the reference's output to the same tolerance."""
+    """CMDI_UNET_FUSE_GN = 0 (no convolution + GroupNorm fusion: the default since round 4), 2 (fused epilogue at level 1: the
+    default of rounds 2-3) and 3 (levels 0 AND 1) give the reference's output to the same tolerance."""
     monkeypatch.setenv("CMDI_UNET_FUSE_GN", fuse)
     inp = cases.make_unet_inputs()
     model, g = make_unet(cases)
