@@ -337,8 +337,11 @@ int run_layers_bwd(cmdi_engine* e, int seq0, int nseq, hipStream_t s) {
         const LayerW& w = e->layers[l];
         const LayerStash& st = e->stash[l];
         if (h3) {
-            // same chain with the four dX GEMMs on the f16 matrix pipe (weights: split transposes)
-            HIPCHK(launch_layernorm_bwd(st.pre2 + r0 * d, st.stats2 + r0 * 2, w.n2_g, dA, dB, dBS, M, d, s));
+            // same chain with the four dX GEMMs on the f16 matrix pipe (weights: split transposes).  Round 4: every gradient
+            // between two kernels travels ONCE — the LayerNorm backward writes only split rows (the GEMM operand), the
+            // residual epilogues add those same rows (Rs), and D = rowsum(dO * O) is taken from the split dO the attention
+            // kernels multiply: three 26-MB fp32 tensors per layer are no longer written
+            HIPCHK(launch_layernorm_bwd(st.pre2 + r0 * d, st.stats2 + r0 * 2, w.n2_g, dA, nullptr, dBS, M, d, s));
             {   // dffn = (dB · W2) * gelu'(aux)
                 H3Params p = hp(dBS, w.l2_wTs, nullptr, dffnS, f, d);
                 p.aux = st.aux + r0 * f;
@@ -346,21 +349,20 @@ int run_layers_bwd(cmdi_engine* e, int seq0, int nseq, hipStream_t s) {
             }
             {   // dH = dffn · W1 + dB
                 H3Params p = hp(dffnS, w.l1_wTs, dH, nullptr, d, f);
-                p.R = dB;
+                p.Rs = dBS;
                 HIPCHK(launch_gemm_h3(H3_RESID, p, e->h3_tile_ffn2, s));
             }
-            HIPCHK(launch_layernorm_bwd(st.pre1 + r0 * d, st.stats1 + r0 * 2, w.n1_g, dH, dB, dBS, M, d, s));
-            {   // d attn = dB · Wo -> dH (fp32, for D = rowsum(dO*O)) and dOS (split, MFMA operand)
+            HIPCHK(launch_layernorm_bwd(st.pre1 + r0 * d, st.stats1 + r0 * 2, w.n1_g, dH, nullptr, dBS, M, d, s));
+            {   // d attn = dB · Wo -> dOS (split: MFMA operand of the attention backward and the dO of its D = rowsum(dO * O))
                 H3Params p = hp(dBS, w.out_wTs, nullptr, dOS, d, d);
-                p.aux = dH;
                 HIPCHK(launch_gemm_h3(H3_PLAIN_SPLIT, p, e->h3_tile_proj, s));
             }
             HIPCHK(launch_attention_bwd_h3(st.qkvS + r0 * 6 * d, st.attn + r0 * d,
-                                           st.row_stats + (size_t)seq0 * e->H * S * 2, dH, dOS, dqkvS,
+                                           st.row_stats + (size_t)seq0 * e->H * S * 2, dOS, dqkvS,
                                            e->drowdot + attention_bwd_scratch_floats(seq0, S, e->H), nseq, S, e->H, s));
             {   // dA = dqkv · Wqkv + dB
                 H3Params p = hp(dqkvS, w.in_wTs, dA, nullptr, d, 3 * d);
-                p.R = dB;
+                p.Rs = dBS;
                 HIPCHK(launch_gemm_h3(H3_RESID, p, e->h3_tile_proj, s));
             }
             continue;

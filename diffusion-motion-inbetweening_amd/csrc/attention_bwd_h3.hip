@@ -272,8 +272,9 @@ __device__ __forceinline__ void bwd_block(int id, int nbh, int& bh, int& half) {
 }  // namespace
 
 // ---- qstat: per (sequence, head, 32-query tile) m·log2(e) [32] | 1/sum [32] | D [32]; one wave per token row -----------
-// D[(b, h), q] = sum over the head's 128 dims of dO·O (fp32).  Rows q in [S, 32·ceil(S/32)) get (1e30, 0, 0): P = 0·0 there.
-__global__ __launch_bounds__(256) void attn_qstat_kernel(const float* __restrict__ d_o, const float* __restrict__ o,
+// D[(b, h), q] = sum over the head's 128 dims of dO·O, dO = hi + lo·2^-11 of the SPLIT rows the two kernels below multiply
+// (round 4: the fp32 copy of dO existed only for this sum).  Rows q in [S, 32·ceil(S/32)) get (1e30, 0, 0): P = 0·0 there.
+__global__ __launch_bounds__(256) void attn_qstat_kernel(const _Float16* __restrict__ d_o, const float* __restrict__ o,
                                                          const float* __restrict__ row_stats, float* __restrict__ qstat,
                                                          int n_seq, int S, int H) {
     const int lane = threadIdx.x & 63;
@@ -287,12 +288,15 @@ __global__ __launch_bounds__(256) void attn_qstat_kernel(const float* __restrict
         const int c = c0 + lane * 8;
         float acc = 0.f;
         if (c < d_model && q < S) {
-            const float4 a0 = *reinterpret_cast<const float4*>(d_o + row * d_model + c);
-            const float4 a1 = *reinterpret_cast<const float4*>(d_o + row * d_model + c + 4);
+            const _Float16* dp = d_o + row * (2 * (size_t)d_model) + split_pos(c);
+            const h8 dh = *reinterpret_cast<const h8*>(dp), dl = *reinterpret_cast<const h8*>(dp + 32);
+            float a[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = __builtin_fmaf((float)dl[e], kLoInv, (float)dh[e]);
             const float4 b0 = *reinterpret_cast<const float4*>(o + row * d_model + c);
             const float4 b1 = *reinterpret_cast<const float4*>(o + row * d_model + c + 4);
-            acc = ((a0.x * b0.x + a0.y * b0.y) + (a0.z * b0.z + a0.w * b0.w)) +
-                  ((a1.x * b1.x + a1.y * b1.y) + (a1.z * b1.z + a1.w * b1.w));
+            acc = ((a[0] * b0.x + a[1] * b0.y) + (a[2] * b0.z + a[3] * b0.w)) +
+                  ((a[4] * b1.x + a[5] * b1.y) + (a[6] * b1.z + a[7] * b1.w));
         }
 #pragma unroll
         for (int o2 = 8; o2 > 0; o2 >>= 1) acc += __shfl_xor(acc, o2, 64);   // 16 lanes = one head
@@ -565,7 +569,7 @@ size_t attention_bwd_scratch_floats(int n_seq, int S, int H) {
 // d_qkv_split [M, 6d] (split rows) from: qkv_split (forward stash), d_out_split [M, 2d] + d_out fp32 + o_fwd fp32
 // (for D), row_stats; d_scratch: attention_bwd_scratch_floats(n_seq, S, H) floats
 hipError_t launch_attention_bwd_h3(const _Float16* qkv_split, const float* o_fwd, const float* row_stats,
-                                   const float* d_out, const _Float16* d_out_split, _Float16* d_qkv_split,
+                                   const _Float16* d_out_split, _Float16* d_qkv_split,
                                    float* d_scratch, int n_seq, int S, int H, hipStream_t stream) {
     if (S < 1 || S > 224) return hipErrorInvalidValue;
     const float scale = 1.0f / sqrtf((float)DH);
@@ -584,7 +588,7 @@ hipError_t launch_attention_bwd_h3(const _Float16* qkv_split, const float* o_fwd
         attr_done = true;
     }
     const int prow = n_seq * ((S + KBLK - 1) / KBLK) * KBLK;
-    hipLaunchKernelGGL(attn_qstat_kernel, dim3((prow + 3) / 4), dim3(256), 0, stream, d_out, o_fwd, row_stats, d_scratch,
+    hipLaunchKernelGGL(attn_qstat_kernel, dim3((prow + 3) / 4), dim3(256), 0, stream, d_out_split, o_fwd, row_stats, d_scratch,
                        n_seq, S, H);
     static_assert(32 * BW * 2 >= 224, "two row halves cover S <= 224");
     const dim3 grid(2 * n_seq * H), block(64 * BW);

@@ -110,7 +110,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
     const float m1 = wave_sum(s1) * (1.0f / D);
     const float m2 = wave_sum(s2) * (1.0f / D);
-    float* dxr = dx + (size_t)row * D;
+    // dx (fp32) is optional (round 4): the split-f16 chain adds the residual gradient from the split rows it multiplies anyway
+    // (H3Params::Rs), so its LayerNorm backward writes one tensor instead of two
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         float4 o;
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         o.y = rstd * (g[i].y - m1 - xh[i].y * m2);
         o.z = rstd * (g[i].z - m1 - xh[i].z * m2);
         o.w = rstd * (g[i].w - m1 - xh[i].w * m2);
-        *reinterpret_cast<float4*>(dxr + i * 256 + lane * 4) = o;
+        if (dx) *reinterpret_cast<float4*>(dx + (size_t)row * D + i * 256 + lane * 4) = o;
         if (dxs) {   // split rows for the f16-pipe dX GEMMs (gradients: no range flag, see api_denoiser.hip)
             const float ov[4] = {o.x, o.y, o.z, o.w};
             h4 oh, ol;

@@ -55,11 +55,11 @@ hipError_t launch_attention_fwd(const float* qkv, float* out, _Float16* out_spli
 hipError_t launch_attention_h3(const _Float16* qkv_split, float* out, _Float16* out_split,
                                int* range_flag, float* row_stats, int n_seq, int S, int H,
                                hipStream_t stream, bool head_major = false);
-// ---- attention_bwd_h3.hip: backward on the f16 pipe: everything in split rows except o_fwd / d_out (fp32, for
+// ---- attention_bwd_h3.hip: backward on the f16 pipe: everything in split rows except o_fwd (fp32, for
 // D = rowsum(dO*O)); d_scratch holds attention_bwd_scratch_floats(n_seq, S, H) floats (per-tile row statistics)
 size_t attention_bwd_scratch_floats(int n_seq, int S, int H);
 hipError_t launch_attention_bwd_h3(const _Float16* qkv_split, const float* o_fwd, const float* row_stats,
-                                   const float* d_out, const _Float16* d_out_split, _Float16* d_qkv_split,
+                                   const _Float16* d_out_split, _Float16* d_qkv_split,
                                    float* d_scratch, int n_seq, int S, int H, hipStream_t stream);
 #ifdef CMDI_PROBES
 hipError_t read_bwd_stamps(void* host_dst);
