@@ -57,20 +57,28 @@ int run_layers(cmdi_engine* e, int seq0, int nseq, bool keep, bool prof, hipStre
         // ---- no LayerNorm pass: P (tokS) is the layer input BEFORE its LayerNorm (layer 0: the tokens themselves) ----
         float* partA = e->partA + r0 * 32;
         float* partB = e->partB + r0 * 32;
+        // keep (round 3): the folded schedule also serves the forward pass that stashes activations for the input-VJP
+        // (reconstruction guidance, torch.autograd through the module): the GEMM epilogues write what the backward reads —
+        // split qkv per layer, the FFN pre-activation — and the GEMM that CONSUMES a LayerNorm's partial statistics writes
+        // its (mean, rstd) out (p.ln_stats).  16 LayerNorm launches per evaluation less than the schedule below, which it
+        // replaces unless CMDI_LN_FOLD_KEEP=0.  Round 4: the stash IS the stream — the attention output and the two
+        // pre-LayerNorm sums of a layer are written ONCE, as the split rows the next GEMM multiplies, straight into the
+        // layer's stash (st->attn / pre1 / pre2 hold [M][2d] halves = the bytes of their fp32 form; e->stash_split tells the
+        // backward); rounds 1-3 wrote an fp32 copy beside every one of them (3 x 26 MB per layer at C3).
+        if (keep) e->stash_split = true;
+        const _Float16* Pin = tokS;                    // layer input BEFORE its LayerNorm
         for (int l = 0; l < e->L; ++l) {
             const LayerW& w = e->layers[l];
             const LayerW* prev = l > 0 ? &e->layers[l - 1] : nullptr;
-            // keep (round 3): the folded schedule also serves the forward pass that stashes activations for the input-VJP
-            // (reconstruction guidance, torch.autograd through the module): the GEMM epilogues write what the backward reads —
-            // split qkv per layer, the fp32 pre-LayerNorm sums, the FFN pre-activation — and the GEMM that CONSUMES a
-            // LayerNorm's partial statistics writes its (mean, rstd) out (p.ln_stats).  16 LayerNorm launches per evaluation
-            // less than the schedule below, which it replaces unless CMDI_LN_FOLD_KEEP=0.
             const LayerStash* st = keep ? &e->stash[l] : nullptr;
             _Float16* qkvL = keep ? st->qkvS + r0 * 6 * d : qkvS;
+            _Float16* attnL = keep ? reinterpret_cast<_Float16*>(st->attn + r0 * d) : attnS;
+            _Float16* pre1L = keep ? reinterpret_cast<_Float16*>(st->pre1 + r0 * d) : bufHS;
+            _Float16* pre2L = keep ? reinterpret_cast<_Float16*>(st->pre2 + r0 * d) : tokS;
             const bool head_major = e->qkv_head_major != 0 && !keep;   // (the attention backward reads token-major rows)
             { int prc = prof_begin(0); if (prc != CMDI_OK) return prc; }
             {   // qkv = in_proj(LN2_prev(P))
-                H3Params p = hp(tokS, prev ? w.in_wsf : w.in_ws, prev ? w.in_c2 : w.in_b, nullptr, qkvL, 3 * d, d);
+                H3Params p = hp(Pin, prev ? w.in_wsf : w.in_ws, prev ? w.in_c2 : w.in_b, nullptr, qkvL, 3 * d, d);
                 if (prev) { p.ln_part = partB; p.ln_c1 = w.in_c1; }
                 if (prev && keep) p.ln_stats = e->stash[l - 1].stats2 + r0 * 2;
                 p.cs_head_major = head_major;
@@ -78,35 +86,38 @@ int run_layers(cmdi_engine* e, int seq0, int nseq, bool keep, bool prof, hipStre
             }
             { int prc = prof_end(0); if (prc != CMDI_OK) return prc; }
             { int prc = prof_begin(1); if (prc != CMDI_OK) return prc; }
-            HIPCHK(launch_attention_h3(qkvL, keep ? st->attn + r0 * d : nullptr, attnS, e->range_flag,
+            HIPCHK(launch_attention_h3(qkvL, nullptr, attnL, e->range_flag,
                                        keep ? st->row_stats + (size_t)seq0 * e->H * S * 2 : nullptr, nseq, S, e->H, s, head_major));
             { int prc = prof_end(1); if (prc != CMDI_OK) return prc; }
-            {   // pre1 = LN2_prev(P) + out_proj(attn)   -> bufHS (+ partial statistics A)
-                H3Params p = hp(attnS, w.out_ws, w.out_b, keep ? st->pre1 + r0 * d : nullptr, bufHS, d, d);
-                p.Rs = tokS;
+            {   // pre1 = LN2_prev(P) + out_proj(attn)   (+ partial statistics A)
+                H3Params p = hp(attnL, w.out_ws, w.out_b, nullptr, pre1L, d, d);
+                p.Rs = Pin;
                 if (prev) { p.ln_part = partB; p.ln_rg = prev->n2_g; p.ln_rb = prev->n2_b; }
                 p.out_part = partA;
                 HIPCHK(launch_gemm_h3(H3_RESID, p, e->h3_tile_proj, s));
             }
             {   // ffn = gelu(linear1(LN1(pre1)))
-                H3Params p = hp(bufHS, w.l1_wsf, w.l1_c2, nullptr, ffnS, f, d);
+                H3Params p = hp(pre1L, w.l1_wsf, w.l1_c2, nullptr, ffnS, f, d);
                 p.ln_part = partA; p.ln_c1 = w.l1_c1;
                 if (keep) { p.aux = st->aux + r0 * f; p.ln_stats = st->stats1 + r0 * 2; }
                 HIPCHK(launch_gemm_h3(H3_GELU_SPLIT, p, e->h3_tile_ffn1, s));
             }
-            {   // pre2 = LN1(pre1) + linear2(ffn)   -> tokS (+ partial statistics B): the next layer's P
-                H3Params p = hp(ffnS, w.l2_ws, w.l2_b, keep ? st->pre2 + r0 * d : nullptr, tokS, d, f);
-                p.Rs = bufHS; p.ln_part = partA; p.ln_rg = w.n1_g; p.ln_rb = w.n1_b;
+            {   // pre2 = LN1(pre1) + linear2(ffn)   (+ partial statistics B): the next layer's P
+                H3Params p = hp(ffnS, w.l2_ws, w.l2_b, nullptr, pre2L, d, f);
+                p.Rs = pre1L; p.ln_part = partA; p.ln_rg = w.n1_g; p.ln_rb = w.n1_b;
                 p.out_part = partB;
                 HIPCHK(launch_gemm_h3(H3_RESID, p, e->h3_tile_ffn2, s));
             }
+            Pin = pre2L;
         }
-        // the encoder output is LN2 of the last layer: the one LayerNorm launch that remains (split rows in, in place)
+        // the encoder output is LN2 of the last layer: the one LayerNorm launch that remains (split rows in -> tokS; in
+        // place unless the rows are a stash)
         const LayerW& last = e->layers[e->L - 1];
         HIPCHK(launch_layernorm(nullptr, last.n2_g, last.n2_b, nullptr, tokS, e->range_flag,
-                                keep ? e->stash[e->L - 1].stats2 + r0 * 2 : nullptr, M, d, s, tokS));
+                                keep ? e->stash[e->L - 1].stats2 + r0 * 2 : nullptr, M, d, s, Pin));
         return CMDI_OK;
     }
+    if (keep) e->stash_split = false;   // this schedule stashes fp32 rows
     for (int l = 0; l < e->L; ++l) {
         const LayerW& w = e->layers[l];
         const LayerStash* st = keep ? &e->stash[l] : nullptr;
@@ -341,7 +352,11 @@ int run_layers_bwd(cmdi_engine* e, int seq0, int nseq, hipStream_t s) {
             // between two kernels travels ONCE — the LayerNorm backward writes only split rows (the GEMM operand), the
             // residual epilogues add those same rows (Rs), and D = rowsum(dO * O) is taken from the split dO the attention
             // kernels multiply: three 26-MB fp32 tensors per layer are no longer written
-            HIPCHK(launch_layernorm_bwd(st.pre2 + r0 * d, st.stats2 + r0 * 2, w.n2_g, dA, nullptr, dBS, M, d, s));
+            const bool ss = e->stash_split;   // the stash holds split rows (folded forward schedule) or fp32 rows
+            const _Float16* pre2S = ss ? reinterpret_cast<const _Float16*>(st.pre2 + r0 * d) : nullptr;
+            const _Float16* pre1S = ss ? reinterpret_cast<const _Float16*>(st.pre1 + r0 * d) : nullptr;
+            const _Float16* attnS_ = ss ? reinterpret_cast<const _Float16*>(st.attn + r0 * d) : nullptr;
+            HIPCHK(launch_layernorm_bwd(ss ? nullptr : st.pre2 + r0 * d, st.stats2 + r0 * 2, w.n2_g, dA, nullptr, dBS, M, d, s, pre2S));
             {   // dffn = (dB · W2) * gelu'(aux)
                 H3Params p = hp(dBS, w.l2_wTs, nullptr, dffnS, f, d);
                 p.aux = st.aux + r0 * f;
@@ -352,12 +367,12 @@ int run_layers_bwd(cmdi_engine* e, int seq0, int nseq, hipStream_t s) {
                 p.Rs = dBS;
                 HIPCHK(launch_gemm_h3(H3_RESID, p, e->h3_tile_ffn2, s));
             }
-            HIPCHK(launch_layernorm_bwd(st.pre1 + r0 * d, st.stats1 + r0 * 2, w.n1_g, dH, nullptr, dBS, M, d, s));
+            HIPCHK(launch_layernorm_bwd(ss ? nullptr : st.pre1 + r0 * d, st.stats1 + r0 * 2, w.n1_g, dH, nullptr, dBS, M, d, s, pre1S));
             {   // d attn = dB · Wo -> dOS (split: MFMA operand of the attention backward and the dO of its D = rowsum(dO * O))
                 H3Params p = hp(dBS, w.out_wTs, nullptr, dOS, d, d);
                 HIPCHK(launch_gemm_h3(H3_PLAIN_SPLIT, p, e->h3_tile_proj, s));
             }
-            HIPCHK(launch_attention_bwd_h3(st.qkvS + r0 * 6 * d, st.attn + r0 * d,
+            HIPCHK(launch_attention_bwd_h3(st.qkvS + r0 * 6 * d, ss ? nullptr : st.attn + r0 * d, attnS_,
                                            st.row_stats + (size_t)seq0 * e->H * S * 2, dOS, dqkvS,
                                            e->drowdot + attention_bwd_scratch_floats(seq0, S, e->H), nseq, S, e->H, s));
             {   // dA = dqkv · Wqkv + dB

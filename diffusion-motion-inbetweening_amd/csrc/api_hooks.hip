@@ -242,7 +242,7 @@ int cmdi_attention_vjp_h3(const void* d_qkv_split, const float* d_dout, void* d_
     const _Float16* qs = static_cast<const _Float16*>(d_qkv_split);
     HIPCHK(launch_attention_h3(qs, o_fwd, nullptr, nullptr, row_stats, n_seq, seq_len, n_heads, s));
     HIPCHK(launch_split_f16(d_dout, dout_s, (int64_t)M, (int)d, (int)d, nullptr, s));
-    HIPCHK(launch_attention_bwd_h3(qs, o_fwd, row_stats, dout_s, static_cast<_Float16*>(d_dqkv_split), rowdot,
+    HIPCHK(launch_attention_bwd_h3(qs, o_fwd, nullptr, row_stats, dout_s, static_cast<_Float16*>(d_dqkv_split), rowdot,
                                    n_seq, seq_len, n_heads, s));
     return CMDI_OK;
 }

@@ -275,6 +275,7 @@ __device__ __forceinline__ void bwd_block(int id, int nbh, int& bh, int& half) {
 // D[(b, h), q] = sum over the head's 128 dims of dO·O, dO = hi + lo·2^-11 of the SPLIT rows the two kernels below multiply
 // (round 4: the fp32 copy of dO existed only for this sum).  Rows q in [S, 32·ceil(S/32)) get (1e30, 0, 0): P = 0·0 there.
 __global__ __launch_bounds__(256) void attn_qstat_kernel(const _Float16* __restrict__ d_o, const float* __restrict__ o,
+                                                         const _Float16* __restrict__ o_s,
                                                          const float* __restrict__ row_stats, float* __restrict__ qstat,
                                                          int n_seq, int S, int H) {
     const int lane = threadIdx.x & 63;
@@ -293,8 +294,18 @@ __global__ __launch_bounds__(256) void attn_qstat_kernel(const _Float16* __restr
             float a[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) a[e] = __builtin_fmaf((float)dl[e], kLoInv, (float)dh[e]);
-            const float4 b0 = *reinterpret_cast<const float4*>(o + row * d_model + c);
-            const float4 b1 = *reinterpret_cast<const float4*>(o + row * d_model + c + 4);
+            float4 b0, b1;
+            if (o_s) {   // O as the split rows the forward pass wrote for out_proj (stash of the folded schedule)
+                const _Float16* op = o_s + row * (2 * (size_t)d_model) + split_pos(c);
+                const h8 oh = *reinterpret_cast<const h8*>(op), ol = *reinterpret_cast<const h8*>(op + 32);
+                b0 = make_float4(__builtin_fmaf((float)ol[0], kLoInv, (float)oh[0]), __builtin_fmaf((float)ol[1], kLoInv, (float)oh[1]),
+                                 __builtin_fmaf((float)ol[2], kLoInv, (float)oh[2]), __builtin_fmaf((float)ol[3], kLoInv, (float)oh[3]));
+                b1 = make_float4(__builtin_fmaf((float)ol[4], kLoInv, (float)oh[4]), __builtin_fmaf((float)ol[5], kLoInv, (float)oh[5]),
+                                 __builtin_fmaf((float)ol[6], kLoInv, (float)oh[6]), __builtin_fmaf((float)ol[7], kLoInv, (float)oh[7]));
+            } else {
+                b0 = *reinterpret_cast<const float4*>(o + row * d_model + c);
+                b1 = *reinterpret_cast<const float4*>(o + row * d_model + c + 4);
+            }
             acc = ((a[0] * b0.x + a[1] * b0.y) + (a[2] * b0.z + a[3] * b0.w)) +
                   ((a[4] * b1.x + a[5] * b1.y) + (a[6] * b1.z + a[7] * b1.w));
         }
@@ -568,10 +579,10 @@ size_t attention_bwd_scratch_floats(int n_seq, int S, int H) {
 
 // d_qkv_split [M, 6d] (split rows) from: qkv_split (forward stash), d_out_split [M, 2d] + d_out fp32 + o_fwd fp32
 // (for D), row_stats; d_scratch: attention_bwd_scratch_floats(n_seq, S, H) floats
-hipError_t launch_attention_bwd_h3(const _Float16* qkv_split, const float* o_fwd, const float* row_stats,
-                                   const _Float16* d_out_split, _Float16* d_qkv_split,
+hipError_t launch_attention_bwd_h3(const _Float16* qkv_split, const float* o_fwd, const _Float16* o_fwd_split,
+                                   const float* row_stats, const _Float16* d_out_split, _Float16* d_qkv_split,
                                    float* d_scratch, int n_seq, int S, int H, hipStream_t stream) {
-    if (S < 1 || S > 224) return hipErrorInvalidValue;
+    if (S < 1 || S > 224 || (!o_fwd == !o_fwd_split)) return hipErrorInvalidValue;
     const float scale = 1.0f / sqrtf((float)DH);
     constexpr size_t lds_q = 2ull * KVSTG > (size_t)BW * 32 * RSTR ? 2ull * KVSTG : (size_t)BW * 32 * RSTR;
     constexpr size_t lds_kv = (size_t)BW * TILE + 2ull * QSTG;
@@ -588,8 +599,8 @@ hipError_t launch_attention_bwd_h3(const _Float16* qkv_split, const float* o_fwd
         attr_done = true;
     }
     const int prow = n_seq * ((S + KBLK - 1) / KBLK) * KBLK;
-    hipLaunchKernelGGL(attn_qstat_kernel, dim3((prow + 3) / 4), dim3(256), 0, stream, d_out_split, o_fwd, row_stats, d_scratch,
-                       n_seq, S, H);
+    hipLaunchKernelGGL(attn_qstat_kernel, dim3((prow + 3) / 4), dim3(256), 0, stream, d_out_split, o_fwd, o_fwd_split, row_stats,
+                       d_scratch, n_seq, S, H);
     static_assert(32 * BW * 2 >= 224, "two row halves cover S <= 224");
     const dim3 grid(2 * n_seq * H), block(64 * BW);
     hipLaunchKernelGGL(attn_bwd_kv_h3_kernel, grid, block, lds_kv, stream, qkv_split, d_out_split, d_scratch, d_qkv_split,

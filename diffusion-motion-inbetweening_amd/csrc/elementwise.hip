@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ dy,
                                                             float* __restrict__ dx,
-                                                            _Float16* __restrict__ dxs, int rows) {
+                                                            _Float16* __restrict__ dxs, int rows,
+                                                            const _Float16* __restrict__ xs_in) {
     constexpr int D = NV * 256;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -99,7 +100,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const float4 xv = *reinterpret_cast<const float4*>(xr + i * 256 + lane * 4);
+        float4 xv;
+        if (xs_in) {   // x as the split rows the forward pass multiplied (a stash of the folded schedule)
+            const _Float16* sp = xs_in + (size_t)row * (2 * D) + split_pos(i * 256 + lane * 4);
+            const h4 a = *reinterpret_cast<const h4*>(sp), b = *reinterpret_cast<const h4*>(sp + 32);
+            xv = make_float4((float)a[0] + (float)b[0] * kLoInv, (float)a[1] + (float)b[1] * kLoInv,
+                             (float)a[2] + (float)b[2] * kLoInv, (float)a[3] + (float)b[3] * kLoInv);
+        } else {
+            xv = *reinterpret_cast<const float4*>(xr + i * 256 + lane * 4);
+        }
         const float4 dv = *reinterpret_cast<const float4*>(dyr + i * 256 + lane * 4);
         const float4 gm = *reinterpret_cast<const float4*>(gamma + i * 256 + lane * 4);
         xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd,
@@ -183,13 +192,13 @@ hipError_t launch_fold_ln(const float* W, const float* gamma, const float* beta,
 
 hipError_t launch_layernorm_bwd(const float* x, const float* stats, const float* gamma,
                                 const float* dy, float* dx, _Float16* dx_split, int rows, int d,
-                                hipStream_t stream) {
+                                hipStream_t stream, const _Float16* x_split) {
     const dim3 grid((rows + 3) / 4), block(256);
     switch (d) {
-        case 256: hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, block, 0, stream, x, stats, gamma, dy, dx, dx_split, rows); break;
-        case 512: hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, block, 0, stream, x, stats, gamma, dy, dx, dx_split, rows); break;
-        case 768: hipLaunchKernelGGL(layernorm_bwd_kernel<3>, grid, block, 0, stream, x, stats, gamma, dy, dx, dx_split, rows); break;
-        case 1024: hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, block, 0, stream, x, stats, gamma, dy, dx, dx_split, rows); break;
+        case 256: hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, block, 0, stream, x, stats, gamma, dy, dx, dx_split, rows, x_split); break;
+        case 512: hipLaunchKernelGGL(layernorm_bwd_kernel<2>, grid, block, 0, stream, x, stats, gamma, dy, dx, dx_split, rows, x_split); break;
+        case 768: hipLaunchKernelGGL(layernorm_bwd_kernel<3>, grid, block, 0, stream, x, stats, gamma, dy, dx, dx_split, rows, x_split); break;
+        case 1024: hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, block, 0, stream, x, stats, gamma, dy, dx, dx_split, rows, x_split); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

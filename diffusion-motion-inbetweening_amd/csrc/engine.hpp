@@ -105,6 +105,7 @@ struct cmdi_engine {
           *ffn = nullptr, *out_raw = nullptr;
     std::vector<cmdi::host::LayerStash> stash;
     bool stash_valid = false;
+    bool stash_split = false;   // the layer stash (attn / pre1 / pre2) holds split rows [M][2d] halves instead of fp32 rows (run_layers)
     float *dA = nullptr, *dB = nullptr, *dH = nullptr, *dqkv = nullptr, *dffn = nullptr,
           *drowdot = nullptr, *gout = nullptr, *gx = nullptr;
     // precision of the encoder-layer GEMMs: CMDI_PREC_F32 (exact fp32 MFMA) or CMDI_PREC_F16X3

@@ -55,10 +55,12 @@ hipError_t launch_attention_fwd(const float* qkv, float* out, _Float16* out_spli
 hipError_t launch_attention_h3(const _Float16* qkv_split, float* out, _Float16* out_split,
                                int* range_flag, float* row_stats, int n_seq, int S, int H,
                                hipStream_t stream, bool head_major = false);
-// ---- attention_bwd_h3.hip: backward on the f16 pipe: everything in split rows except o_fwd (fp32, for
-// D = rowsum(dO*O)); d_scratch holds attention_bwd_scratch_floats(n_seq, S, H) floats (per-tile row statistics)
+// ---- attention_bwd_h3.hip: backward on the f16 pipe: everything in split rows; the forward output O (for
+// D = rowsum(dO*O)) as fp32 rows (o_fwd) or as split rows (o_fwd_split: the stash of the folded forward schedule), one of
+// the two; d_scratch holds attention_bwd_scratch_floats(n_seq, S, H) floats (per-tile row statistics)
 size_t attention_bwd_scratch_floats(int n_seq, int S, int H);
-hipError_t launch_attention_bwd_h3(const _Float16* qkv_split, const float* o_fwd, const float* row_stats,
+hipError_t launch_attention_bwd_h3(const _Float16* qkv_split, const float* o_fwd, const _Float16* o_fwd_split,
+                                   const float* row_stats,
                                    const _Float16* d_out_split, _Float16* d_qkv_split,
                                    float* d_scratch, int n_seq, int S, int H, hipStream_t stream);
 #ifdef CMDI_PROBES
@@ -81,9 +83,10 @@ hipError_t launch_layernorm(const float* x, const float* gamma, const float* bet
 hipError_t launch_fold_ln(const float* W, const float* gamma, const float* beta, const float* bias, float* Wf, float* c1,
                           float* c2, int N, int K, hipStream_t stream);
 // dx = LN backward of dy (optionally + extra residual gradient dres added to the result)
+// (dx optional when dx_split is given; x_split: x as split rows instead of the fp32 x)
 hipError_t launch_layernorm_bwd(const float* x, const float* stats, const float* gamma,
-                                const float* dy, float* dx, _Float16* dx_split /* optional */,
-                                int rows, int d, hipStream_t stream);
+                                const float* dy, float* dx /* optional */, _Float16* dx_split /* optional */,
+                                int rows, int d, hipStream_t stream, const _Float16* x_split = nullptr);
 // tok[b*S + 0][:] = time_table[t_b] + text_term[b] + pe[0]
 // tmap_dev / cursor (graph replay): t = tmap_dev[*cursor] for every sequence
 hipError_t launch_token0(float* tok, const float* time_table, const float* text_term,
