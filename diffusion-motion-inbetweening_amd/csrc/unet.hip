@@ -202,28 +202,33 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
 
 // ---- GroupNorm in ONE pass (round 4): one block per (sequence, group) keeps the group's Tv x C/8 values in registers (at
 // most 28 float4 per thread: 224 frames x 128 channels), so the convolution output is read once instead of three times and a
-// GroupNorm is one launch instead of two (25 per evaluation, 12-26 us each for either kernel).  Same thread -> element map,
-// same summation order and the same element formulas as gn_stats_kernel / gn_apply_kernel above, which stay as the fallback
-// for geometries that do not fit (and as the specification).  stats (optional): (mean, rstd) for a stashing forward pass.
-constexpr int GNF_MAXV = 28;
-__global__ __launch_bounds__(256) void gn_fused_kernel(const float* __restrict__ x, float* __restrict__ stats,
+// GroupNorm is one launch instead of two (25 per evaluation, 12-26 us each for either kernel).  With NT = 256: the same
+// thread -> element map, summation order and element formulas as gn_stats_kernel / gn_apply_kernel above — the same bits; they
+// stay as the fallback for geometries that do not fit (and as the specification).  NT = 1,024 (the default): 7 float4 per
+// thread, 16 waves per block instead of 4 hide the load -> reduce -> reduce -> Mish -> store chain (level 0: 60 -> 45 us);
+// the sums then run in another order (1e-7-level differences, pinned by the same reference tolerances).
+// stats (optional): (mean, rstd) for a stashing forward pass.
+constexpr int GNF_MAXV = 28;   // float4 per thread at 256 threads
+template <int NT>
+__global__ __launch_bounds__(NT) void gn_fused_kernel(const float* __restrict__ x, float* __restrict__ stats,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ ss, const float* __restrict__ resid,
                                                        float* __restrict__ yf, _Float16* __restrict__ ys, int ys_ld,
                                                        int* __restrict__ range_flag, int C, int Tp, int h, int Tv, int ss_ld,
                                                        int nsl, size_t sl) {
-    __shared__ float red[4];
+    __shared__ float red[NT / 64];
+    constexpr int MAXV = GNF_MAXV * 256 / NT;
     const int seq = blockIdx.x, g = blockIdx.y, cg = C / NG;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t row0 = (size_t)seq * Tp + h;
     const float* base = x + row0 * C + (size_t)g * cg;
     const int q4 = cg / 4;                    // float4 per row of the group
     const int total = Tv * q4;
-    float4 v[GNF_MAXV];
+    float4 v[MAXV];
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < GNF_MAXV; ++k) {
-        const int i = tid + 256 * k;
+    for (int k = 0; k < MAXV; ++k) {
+        const int i = tid + NT * k;
         if (i < total) {
             const int r = i / q4, c4 = i - r * q4;
             v[k] = load_slices(base + (size_t)r * C + c4 * 4, nsl, sl);
@@ -233,12 +238,15 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const float* __restrict__
     s = wave_sum(s);
     if (lane == 0) red[wave] = s;
     __syncthreads();
-    const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)(Tv * cg);
+    float rs = 0.f;
+#pragma unroll
+    for (int w = 0; w < NT / 64; w += 4) rs += (red[w] + red[w + 1]) + (red[w + 2] + red[w + 3]);
+    const float mean = rs / (float)(Tv * cg);
     __syncthreads();
     float q = 0.f;
 #pragma unroll
-    for (int k = 0; k < GNF_MAXV; ++k) {
-        if (tid + 256 * k < total) {
+    for (int k = 0; k < MAXV; ++k) {
+        if (tid + NT * k < total) {
             const float a = v[k].x - mean, b = v[k].y - mean, c = v[k].z - mean, d = v[k].w - mean;
             q += (a * a + b * b) + (c * c + d * d);
         }
@@ -246,7 +254,10 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const float* __restrict__
     q = wave_sum(q);
     if (lane == 0) red[wave] = q;
     __syncthreads();
-    const float var = ((red[0] + red[1]) + (red[2] + red[3])) / (float)(Tv * cg);
+    float rq = 0.f;
+#pragma unroll
+    for (int w = 0; w < NT / 64; w += 4) rq += (red[w] + red[w + 1]) + (red[w + 2] + red[w + 3]);
+    const float var = rq / (float)(Tv * cg);
     const float rstd = 1.0f / sqrtf(var + 1e-5f);
     if (tid == 0 && stats) {
         stats[((size_t)seq * NG + g) * 2] = mean;
@@ -254,8 +265,8 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const float* __restrict__
     }
     bool overflow = false;
 #pragma unroll
-    for (int k = 0; k < GNF_MAXV; ++k) {
-        const int i = tid + 256 * k;
+    for (int k = 0; k < MAXV; ++k) {
+        const int i = tid + NT * k;
         if (i >= total) continue;
         const int r = i / q4, c4 = i - r * q4;
         const int c = g * cg + c4 * 4;
@@ -549,7 +560,8 @@ struct UnetModel {
     // the convolution over frames only on the persistent kernel and GroupNorm as one pass, no fusion is the fastest
     // (B=32, same box, alternating: 0: 7.50-7.52, 1: 7.51-7.53, 2: 7.53-7.58, 3: 7.59 ms/step) -> default 0
     int fuse_gn = 0;
-    int gn_one_pass = 1;  // CMDI_UNET_GN1: GroupNorm as one register-resident pass (gn_fused_kernel) instead of statistics + apply
+    int gn_one_pass = 2;  // CMDI_UNET_GN1: GroupNorm as one register-resident pass (gn_fused_kernel) instead of statistics + apply:
+                          // 1 = 256 threads per (sequence, group) (bitwise the two kernels), 2 = 1,024 threads (7.76 -> 7.57 ms/step)
     int persist = 2;      // CMDI_UNET_PERSIST: 1 = long-K convolutions on the persistent GEMM (conv_rows), 2 = ... over frames only
     int m_fast = 0;      // CMDI_UNET_MFAST: tile order of the convolution GEMMs (gemm_params.hpp)
     int big_tile = 0;    // CMDI_UNET_TILE: gemm_h3 tile id for the long-K convolutions that are not split
@@ -952,8 +964,12 @@ int group_norm(UnetModel* u, const float* x, int nsl, const GN& n, const float* 
     const int C = u->C[1];
     const size_t sl = (size_t)nseq * L.Tp * C;   // floats between the split-K slices of x
     if (u->gn_one_pass && L.Tv * (C / NG / 4) <= 256 * GNF_MAXV) {   // CMDI_UNET_GN1=0: the two kernels below
-        hipLaunchKernelGGL(gn_fused_kernel, dim3(nseq, NG), dim3(256), 0, s, x, stats, n.g, n.b, ss, resid, yf, ys, ys_ld,
-                           u->range_flag, C, L.Tp, L.h, L.Tv, u->ss_ld, nsl, sl);
+        if (u->gn_one_pass >= 2)   // 1,024 threads: 7 float4 per thread (another summation order than the 256-thread form)
+            hipLaunchKernelGGL(gn_fused_kernel<1024>, dim3(nseq, NG), dim3(1024), 0, s, x, stats, n.g, n.b, ss, resid, yf, ys, ys_ld,
+                               u->range_flag, C, L.Tp, L.h, L.Tv, u->ss_ld, nsl, sl);
+        else
+            hipLaunchKernelGGL(gn_fused_kernel<256>, dim3(nseq, NG), dim3(256), 0, s, x, stats, n.g, n.b, ss, resid, yf, ys, ys_ld,
+                               u->range_flag, C, L.Tp, L.h, L.Tv, u->ss_ld, nsl, sl);
         UCHK(hipGetLastError());
         return 0;
     }

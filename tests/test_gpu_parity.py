@@ -1516,21 +1516,23 @@ def test_unet_forward_groupnorm_fusion_modes(cases, monkeypatch, fuse):
 
 
 def test_unet_groupnorm_one_pass_is_the_two_kernel_groupnorm(cases, monkeypatch):
-    """Round 4: GroupNorm as ONE register-resident pass (unet.hip gn_fused_kernel, the default) against the statistics + apply
-    kernels it replaces (CMDI_UNET_GN1=0): same element map, same summation order, same formulas -> the same bits, in the
-    forward pass and through the input-VJP (whose backward reads the statistics the forward pass stashed)."""
+    """Round 4: GroupNorm as ONE register-resident pass (unet.hip gn_fused_kernel) against the statistics + apply kernels it
+    replaces (CMDI_UNET_GN1=0).  With 256 threads per (sequence, group) (=1): same element map, same summation order, same
+    formulas -> the same bits.  With 1,024 threads (=2, the default) the sums run in another order: equal to 1e-6 of the
+    output scale, and to the reference within the usual bound."""
     inp = cases.make_unet_inputs()
     outs = {}
-    for mode in ("0", "1"):
+    for mode in ("0", "1", "2"):
         monkeypatch.setenv("CMDI_UNET_GN1", mode)
         monkeypatch.setenv("CMDI_UNET_FUSE_GN", "0")     # every GroupNorm through the kernels under test
         model, g = make_unet(cases)
         wrapped = sub("model.cfg_sampler").ClassifierFreeSampleModel(model)
         outs[mode] = wrapped(tt(inp["x"]), tt(inp["t"]), y={"text_embed": tt(inp["enc_text"]), "text_scale": tt(inp["text_scale"])},
                              obs_x0=tt(inp["obs_x0"]), obs_mask=tt(inp["obs_mask"])).cpu().numpy()
-    assert np.isfinite(outs["1"]).all()
+    assert np.isfinite(outs["2"]).all()
     assert np.array_equal(outs["0"], outs["1"]), float(np.abs(outs["0"] - outs["1"]).max())
-    assert ok("unet_groupnorm_one_pass.rel_l2", rel_l2(outs["1"], g["out_cfg"]), 2e-5)
+    assert ok("unet_groupnorm_one_pass.order", rel_l2(outs["2"], outs["0"]), 2e-6)
+    assert ok("unet_groupnorm_one_pass.rel_l2", rel_l2(outs["2"], g["out_cfg"]), 2e-5)
 
 
 @pytest.mark.parametrize("scale,expect", [(4000.0, "ok"), (60000.0, "range")])
