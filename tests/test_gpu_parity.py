@@ -490,6 +490,25 @@ def test_forward_layernorm_schedules(cases, monkeypatch, fold):
     assert ok("forward_layernorm_schedules.max_abs.0", max_abs(out, g["out_cfg"]), 2e-4) and ok("forward_layernorm_schedules.rel_l2.0", rel_l2(out, g["out_cfg"]), 2e-5), (max_abs(out, g["out_cfg"]), rel_l2(out, g["out_cfg"]))
 
 
+@pytest.mark.parametrize("fold_keep", ["0", "1"])
+def test_vjp_stash_formats(cases, monkeypatch, fold_keep):
+    """The input-VJP over both stash formats of the f16x3 forward pass (round 4): split rows written once by the folded
+    schedule (default, the stash is the stream) and the fp32 rows of the schedule with separate LayerNorm kernels
+    (CMDI_LN_FOLD_KEEP=0).  Same golden, same bound."""
+    monkeypatch.setenv("CMDI_LN_FOLD_KEEP", fold_keep)
+    case = cases.CASES["vjp_text_cfg"]
+    inp = cases.make_inputs(case)
+    model, _ = make_model(case, precision="f16x3")
+    B, _, _, T = inp["x"].shape
+    eng = model.model.engine(torch.device(DEV), max_batch=B, max_frames=T, want_grad=True)
+    eng.set_condition(batch=B, n_frames=T, cfg=True, enc_text=tt(inp["enc_text"]), text_scale=tt(inp["text_scale"]))
+    g = load_golden("vjp_text_cfg")
+    out = eng.mdm_forward(tt(inp["x"]), tt(inp["t"])).cpu().numpy()
+    assert ok("vjp_stash_formats.fwd", rel_l2(out, g["out"]), 2e-5)
+    gx = eng.mdm_vjp(tt(inp["gout"])).cpu().numpy()
+    assert ok("vjp_stash_formats.vjp", rel_l2(gx, g["gx"]), 5e-5), rel_l2(gx, g["gx"])
+
+
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_vjp_vs_reference_autograd(cases, precision):
     case = cases.CASES["vjp_text_cfg"]
