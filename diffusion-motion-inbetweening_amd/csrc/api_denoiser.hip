@@ -7,6 +7,11 @@ using namespace cmdi::host;
 namespace cmdi {
 namespace host {
 
+// the input-VJP's boundary GEMMs run on the f16 pipe (split rows in, power-of-two gradient scale) when the forward's do
+static inline bool vjp_boundary_h3(const cmdi_engine* e) {
+    return e->precision == CMDI_PREC_F16X3 && e->io_h3 && e->gS && e->w_inT_s && !e->unet;
+}
+
 // ---- encoder layers over sequences [seq0, seq0 + nseq) on stream s -----------------------------
 int run_layers(cmdi_engine* e, int seq0, int nseq, bool keep, bool prof, hipStream_t s) {
     const int S = e->T + 1, d = e->d, f = e->f;
@@ -320,6 +325,47 @@ int mdm_forward(cmdi_engine* e, const float* x, const int64_t* t_dev, int64_t t_
     return CMDI_OK;
 }
 
+// ---- the two boundary GEMMs of the input-VJP (round 4: on the f16 pipe when the I/O projections are) ------------------------
+// d tok[b*S+1+t][k] = scale * sum_c gout[b][c][t] W_out[c][k] for the sequences [slot0, slot0 + nslot); token-0 rows of dA
+// must already be zero.  f16x3: the output gradient becomes scaled split frame rows (pose_rows_split), one H3_TOKENS GEMM
+// writes the fp32 token rows the LayerNorm backward reads (rounds 1-3: an fp32-MFMA GEMM with a transposing A load, 63 us).
+int vjp_output_projection(cmdi_engine* e, const float* gout, float* dA, int slot0, int nslot, const unsigned* gs, hipStream_t s) {
+    const int T = e->T, S = T + 1, d = e->d, C = e->C;
+    if (vjp_boundary_h3(e)) {
+        _Float16* gs_rows = e->gS + (size_t)slot0 * T * 2 * e->Cpad;
+        HIPCHK(launch_pose_rows_split(gout, gs_rows, nslot, C, T, e->Cpad, nullptr, s, gs));
+        H3Params p{};
+        p.A = gs_rows; p.W = e->w_outT_s; p.C = dA;
+        p.M = nslot * T; p.N = d; p.K = e->Cpad; p.ldc = d;
+        p.tok_T = T; p.tok_S = S;
+        HIPCHK(launch_gemm_h3(H3_TOKENS, p, 0, s));
+        return CMDI_OK;
+    }
+    GemmParams p = gp(gout, e->w_outT_pad, nullptr, dA, nslot * T, d, e->Cpad, 0, e->Cpad, d);
+    p.T = T; p.S = S; p.Cf = C;
+    p.gs_bits = gs;
+    HIPCHK(launch_gemm(GK_OUTPROJ_BWD, p, 0, s));
+    return CMDI_OK;
+}
+// gx[b][c][t] = (1 / scale) * sum_n dA[b*S+1+t][n] W_in[n][c].  f16x3: layer 0's last GEMM left dA as split rows (dOS) and the
+// forward's output-projection kernel (H3_MOTION, weight rows as the A operand: stores run along T) takes W_in^T instead.
+int vjp_input_projection(cmdi_engine* e, const float* dA, float* gx, int slot0, int nslot, const unsigned* gs, hipStream_t s) {
+    const int T = e->T, S = T + 1, d = e->d, C = e->C;
+    if (vjp_boundary_h3(e)) {
+        H3Params p{};
+        p.A = e->w_inT_s; p.W = e->dOS + (size_t)slot0 * S * 2 * d; p.C = gx;
+        p.M = C; p.N = nslot * S; p.K = d; p.ldc = 0;
+        p.tok_T = T; p.tok_S = S; p.gs_bits = gs;
+        HIPCHK(launch_gemm_h3(H3_MOTION, p, 0, s));
+        return CMDI_OK;
+    }
+    GemmParams p = gp(e->w_inT, dA, nullptr, gx, C, nslot * T, d, d, d, 0);
+    p.T = T; p.S = S; p.Cf = C;
+    p.gs_bits = gs;
+    HIPCHK(launch_gemm(GK_OUTPROJ, p, 0, s));
+    return CMDI_OK;
+}
+
 // ---- dX backward of the encoder layers over sequences [seq0, seq0 + nseq) -----------------------
 int run_layers_bwd(cmdi_engine* e, int seq0, int nseq, hipStream_t s) {
     const int S = e->T + 1, d = e->d, f = e->f;
@@ -375,8 +421,9 @@ int run_layers_bwd(cmdi_engine* e, int seq0, int nseq, hipStream_t s) {
             HIPCHK(launch_attention_bwd_h3(st.qkvS + r0 * 6 * d, ss ? nullptr : st.attn + r0 * d, attnS_,
                                            st.row_stats + (size_t)seq0 * e->H * S * 2, dOS, dqkvS,
                                            e->drowdot + attention_bwd_scratch_floats(seq0, S, e->H), nseq, S, e->H, s));
-            {   // dA = dqkv · Wqkv + dB
-                H3Params p = hp(dqkvS, w.in_wTs, dA, nullptr, d, 3 * d);
+            {   // dA = dqkv · Wqkv + dB   (layer 0 with the boundary GEMM on the f16 pipe: as split rows, its W operand)
+                const bool to_split = l == 0 && vjp_boundary_h3(e);
+                H3Params p = hp(dqkvS, w.in_wTs, to_split ? nullptr : dA, to_split ? dOS : nullptr, d, 3 * d);
                 p.Rs = dBS;
                 HIPCHK(launch_gemm_h3(H3_RESID, p, e->h3_tile_proj, s));
             }
@@ -435,23 +482,14 @@ int mdm_backward(cmdi_engine* e, const float* gout, float* gx, hipStream_t s) {
         HIPCHK(hipMemsetAsync(e->gs_bits, 0, sizeof(unsigned), s));
         HIPCHK(launch_absmax_bits(gout, (int64_t)n_seq * C * T, e->gs_bits, s));
     }
-    {
-        GemmParams p = gp(gout, e->w_outT_pad, nullptr, e->dA, n_seq * T, d, e->Cpad, 0, e->Cpad, d);
-        p.T = T; p.S = S; p.Cf = C;
-        p.gs_bits = h3 ? e->gs_bits : nullptr;
-        HIPCHK(launch_gemm(GK_OUTPROJ_BWD, p, 0, s));
-    }
-    int rc = for_groups(e, n_seq, s, [&](int seq0, int nseq, hipStream_t gs) {
+    int rc = vjp_output_projection(e, gout, e->dA, 0, n_seq, h3 ? e->gs_bits : nullptr, s);
+    if (rc != CMDI_OK) return rc;
+    rc = for_groups(e, n_seq, s, [&](int seq0, int nseq, hipStream_t gs) {
         return run_layers_bwd(e, seq0, nseq, gs);
     });
     if (rc != CMDI_OK) return rc;
-    {   // input projection: gx[b][c][t] = sum_n dA[b*S+1+t][n] W_in[n][c]
-        GemmParams p = gp(e->w_inT, e->dA, nullptr, gx, C, n_seq * T, d, d, d, 0);
-        p.T = T; p.S = S; p.Cf = C;
-        p.gs_bits = h3 ? e->gs_bits : nullptr;
-        HIPCHK(launch_gemm(GK_OUTPROJ, p, 0, s));
-    }
-    return CMDI_OK;
+    // input projection: gx[b][c][t] = sum_n dA[b*S+1+t][n] W_in[n][c]
+    return vjp_input_projection(e, e->dA, gx, 0, n_seq, h3 ? e->gs_bits : nullptr, s);
 }
 
 }  // namespace host

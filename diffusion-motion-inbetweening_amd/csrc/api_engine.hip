@@ -217,6 +217,8 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
             }
             ALLOC(e->dBS, Mmax * d * 2); ALLOC(e->dffnS, Mmax * f * 2); ALLOC(e->dqkvS, Mmax * 3 * d * 2);
             ALLOC(e->dOS, Mmax * d * 2);
+            ALLOC(e->w_inT_s, (size_t)C * d * 2); ALLOC(e->w_outT_s, (size_t)d * e->Cpad * 2);
+            ALLOC(e->gS, (size_t)nseq * e->Tmax * e->Cpad * 2);
         }
     }
     if (desc->want_grad) {
@@ -369,6 +371,10 @@ int cmdi_finalize_weights(cmdi_handle e, int32_t n_time_rows, cmdi_stream stream
         if (!e->unet) {
             HIPCHK(launch_split_f16(e->w_in_pad, e->w_in_s, d, e->Cpad, e->Cpad, e->range_flag, s));
             HIPCHK(launch_split_f16(e->w_out, e->w_out_s, C, d, d, e->range_flag, s));
+            if (e->desc.want_grad) {   // boundary GEMMs of the input-VJP on the f16 pipe (round 4)
+                HIPCHK(launch_split_f16(e->w_inT, e->w_inT_s, C, d, d, e->range_flag, s));
+                HIPCHK(launch_split_f16(e->w_outT_pad, e->w_outT_s, d, e->Cpad, e->Cpad, e->range_flag, s));
+            }
         }
         for (LayerW& w : e->layers) {
             HIPCHK(launch_split_f16(w.in_w, w.in_ws, 3 * d, d, d, e->range_flag, s));

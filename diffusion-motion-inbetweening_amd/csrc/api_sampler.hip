@@ -215,21 +215,11 @@ static int part_backward(cmdi_engine* e, const Part& pt) {
         HIPCHK(hipMemsetAsync(gs, 0, sizeof(unsigned), s));
         HIPCHK(launch_absmax_bits(gout, (int64_t)pt.nslot * per, gs, s));
     }
-    {
-        GemmParams p = gp(gout, e->w_outT_pad, nullptr, dA, pt.nslot * T, d, e->Cpad, 0, e->Cpad, d);
-        p.T = T; p.S = S; p.Cf = C;
-        p.gs_bits = h3 ? gs : nullptr;
-        HIPCHK(launch_gemm(GK_OUTPROJ_BWD, p, 0, s));
-    }
-    int rc = run_layers_bwd(e, pt.slot0, pt.nslot, s);
+    int rc = vjp_output_projection(e, gout, dA, pt.slot0, pt.nslot, h3 ? gs : nullptr, s);
     if (rc != CMDI_OK) return rc;
-    {
-        GemmParams p = gp(e->w_inT, dA, nullptr, gx, C, pt.nslot * T, d, d, d, 0);
-        p.T = T; p.S = S; p.Cf = C;
-        p.gs_bits = h3 ? gs : nullptr;
-        HIPCHK(launch_gemm(GK_OUTPROJ, p, 0, s));
-    }
-    return CMDI_OK;
+    rc = run_layers_bwd(e, pt.slot0, pt.nslot, s);
+    if (rc != CMDI_OK) return rc;
+    return vjp_input_projection(e, dA, gx, pt.slot0, pt.nslot, h3 ? gs : nullptr, s);
 }
 
 // cursor != null (graph replay): per-step scalars come from the device tables at *cursor, which the step decrements at its end

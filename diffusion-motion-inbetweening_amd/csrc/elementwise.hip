@@ -242,8 +242,10 @@ __global__ void token0_kernel(float* __restrict__ tok, const float* __restrict__
 // per (32 frames, sequence) looped 36 times over its 288 feature rows and took 13-15 us at EVERY batch size.)
 constexpr int POSE_FC = 64;   // features per block = two 32-column chunks of the split row
 __global__ __launch_bounds__(256) void pose_rows_split_kernel(const float* __restrict__ x, _Float16* __restrict__ xs,
-                                                             int C, int T, int Kp, int* __restrict__ range_flag) {
+                                                             int C, int T, int Kp, int* __restrict__ range_flag,
+                                                             const unsigned* __restrict__ gs_bits) {
     __shared__ float tile[POSE_FC * 33];
+    const float gscale = gs_bits ? grad_scale_from_bits(*gs_bits) : 1.0f;   // output gradients: the chain's power-of-two scale
     const int b = blockIdx.y, t0 = blockIdx.x * 32, c0 = blockIdx.z * POSE_FC;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 frames x 8 feature lanes
     const int nc = Kp - c0 < POSE_FC ? Kp - c0 : POSE_FC;     // 64, or 32 in the last block of a 288-column row
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(256) void pose_rows_split_kernel(const float* __res
     bool overflow = false;
     for (int c = ty; c < nc; c += 8) {
         float v = 0.f;
-        if (c0 + c < C && t0 + tx < T) v = xb[(size_t)(c0 + c) * T + t0 + tx];
+        if (c0 + c < C && t0 + tx < T) v = xb[(size_t)(c0 + c) * T + t0 + tx] * gscale;
         overflow |= !(fabsf(v) < 65504.0f);
         tile[c * 33 + tx] = v;
     }
@@ -275,10 +277,10 @@ __global__ __launch_bounds__(256) void pose_rows_split_kernel(const float* __res
 }
 
 hipError_t launch_pose_rows_split(const float* x, _Float16* xs, int nb, int C, int T, int Kp, int* range_flag,
-                                  hipStream_t stream) {
+                                  hipStream_t stream, const unsigned* gs_bits) {
     if (Kp % 32 != 0 || Kp < C) return hipErrorInvalidValue;
     hipLaunchKernelGGL(pose_rows_split_kernel, dim3((T + 31) / 32, nb, (Kp + POSE_FC - 1) / POSE_FC), dim3(256), 0,
-                       stream, x, xs, C, T, Kp, range_flag);
+                       stream, x, xs, C, T, Kp, range_flag, gs_bits);
     return hipGetLastError();
 }
 

@@ -140,6 +140,7 @@ struct cmdi_engine {
     // motion-layout epilogues in gemm_h3.hpp); CMDI_IO_H3=0 keeps them on the fp32 MFMA kernels
     int io_h3 = 0;
     _Float16 *w_in_s = nullptr, *w_out_s = nullptr, *xS = nullptr;
+    _Float16 *w_inT_s = nullptr, *w_outT_s = nullptr, *gS = nullptr;   // input-VJP boundary GEMMs on the f16 pipe: W_in^T [C][2d], W_out^T [d][2 Cpad], scaled output-gradient rows [2B T][2 Cpad]
     int x6_variant = 2;   // K-loop schedule of the bf16x6 GEMM (CMDI_X6_VAR; 2 = rotated barrier, the fastest measured)
     int gemm_tile = 0;
     int tile_inproj = 0, tile_proj = 0, tile_ffn1 = 0, tile_ffn2 = 0;  // per-GEMM overrides (0 = auto)
@@ -241,6 +242,9 @@ inline hipError_t gemm_any(const cmdi_engine* e, GemmKind kind, GemmParams p, co
 // ---- api_denoiser.hip ------------------------------------------------------------------------------
 int run_layers(cmdi_engine* e, int seq0, int nseq, bool keep, bool prof, hipStream_t s);
 int run_layers_bwd(cmdi_engine* e, int seq0, int nseq, hipStream_t s);
+// boundary GEMMs of the input-VJP over the sequences [slot0, slot0 + nslot) (api_denoiser.hip)
+int vjp_output_projection(cmdi_engine* e, const float* gout, float* dA, int slot0, int nslot, const unsigned* gs, hipStream_t s);
+int vjp_input_projection(cmdi_engine* e, const float* dA, float* gx, int slot0, int nslot, const unsigned* gs, hipStream_t s);
 int input_projection_h3(cmdi_engine* e, const float* x, _Float16* xs, _Float16* tok_split, int nb, int dup,
                         hipStream_t s);
 int output_projection_h3(cmdi_engine* e, const _Float16* tok_split, float* out, int nseq, hipStream_t s);

@@ -157,7 +157,7 @@ hipError_t launch_gemm_h3(int epi, const H3Params& p, int tile, hipStream_t s) {
     if (epi == H3_TOKENS || epi == H3_MOTION) {   // the two I/O projections: two tile shapes only
         if (p.tok_T < 1 || p.tok_S != p.tok_T + 1) return hipErrorInvalidValue;
         if (epi == H3_TOKENS) {
-            if (!p.pe || !p.Cs) return hipErrorInvalidValue;
+            if (!p.Cs && !p.C) return hipErrorInvalidValue;
             return tile == 8 ? launch_h3_one<H128x128w8s2, H3_TOKENS>(p, s) : launch_h3_one<H64x128w8s2, H3_TOKENS>(p, s);
         }
         if (!p.C) return hipErrorInvalidValue;

@@ -516,8 +516,12 @@ __device__ __forceinline__ void h3_epilogue(const H3Params& p, f32x16 (&acc0)[TC
                 }
                 if constexpr (EPI == H3_TOKENS) {
                     const int b = m / p.tok_T, fr = m - b * p.tok_T;
-                    const float4 pe4 = *reinterpret_cast<const float4*>(p.pe + (size_t)(1 + fr) * p.N + n);
-                    v[0] += pe4.x; v[1] += pe4.y; v[2] += pe4.z; v[3] += pe4.w;
+                    if (p.pe) {
+                        const float4 pe4 = *reinterpret_cast<const float4*>(p.pe + (size_t)(1 + fr) * p.N + n);
+                        v[0] += pe4.x; v[1] += pe4.y; v[2] += pe4.z; v[3] += pe4.w;
+                    }
+                    if (p.C) *reinterpret_cast<float4*>(p.C + ((size_t)b * p.tok_S + 1 + fr) * p.N + n) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (!p.Cs) continue;
                     h4 oh, ol;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -538,11 +542,12 @@ __device__ __forceinline__ void h3_epilogue(const H3Params& p, f32x16 (&acc0)[TC
                 }
                 if constexpr (EPI == H3_MOTION) {
                     const float bm = p.bias ? p.bias[m] : 0.f;
+                    const float unscale = p.gs_bits ? 1.0f / grad_scale_from_bits(*p.gs_bits) : 1.0f;   // exact: a power of two
                     int b = mo_b, sq = mo_s;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if (n + e < p.N && sq > 0)
-                            p.C[((size_t)b * M + m) * p.tok_T + (sq - 1)] = v[e] + bm;
+                            p.C[((size_t)b * M + m) * p.tok_T + (sq - 1)] = (v[e] + bm) * unscale;
                         if (++sq == p.tok_S) { sq = 0; ++b; }
                     }
                     continue;

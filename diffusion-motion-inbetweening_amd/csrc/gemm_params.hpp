@@ -52,7 +52,8 @@ enum H3Epi {
     H3_RESID_LN = 5,    // x = (v + bias) + R; aux = x (optional); y = LayerNorm(x) -> C (fp32) and Cs (split,
                         // optional); needs a tile that spans the whole row (N == BN)
     H3_TOKENS = 6,      // input projection: GEMM row m = (b, t) -> token row b*S + 1 + t of Cs:
-                        // Cs = split((v + bias[n]) + pe[1 + t][n]), also written for sequence b + tok_dup (CFG)
+                        // Cs = split((v + bias[n]) + pe[1 + t][n]), also written for sequence b + tok_dup (CFG); pe optional; with C:
+                        // the same rows as fp32 (the output projection's backward: dTok rows, no pe, no Cs)
     H3_CONV_GN = 8,     // convolution + GroupNorm [+ AdaGN] + Mish [+ R] in one kernel: the tile owns whole (sequence, group)
                         // blocks (BM == tp rows = one framed sequence, BN = 128 columns = 1 or 2 groups of gn_cg channels);
                         // mean / variance from the accumulators (two block reductions), then as H3_RESID: C, Cs optional
@@ -110,6 +111,8 @@ struct H3Params {
     const float* ln_rg;     // [N] gamma / beta: the residual rows Rs are P and LN(P) is what gets added; null = Rs as is
     const float* ln_rb;
     float* out_part;        // H3_RESID: partial statistics [M][16][2] of the value written (N == 512)
+    const unsigned* gs_bits;  // H3_MOTION: divide the result by the power-of-two gradient scale (common.hpp grad_scale_from_bits): the
+                              // last GEMM of the input-VJP undoes the scale its first one applied; null = 1
     int dbg;            // bench-only ablations: 1 = no in-loop loads, 2 = no epilogue stores, 16 = timestamps
     long long* dbg_buf; // dbg & 16: per block {start, loop start, loop end, end} (s_memtime)
 };

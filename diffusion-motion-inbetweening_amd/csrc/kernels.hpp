@@ -95,8 +95,9 @@ hipError_t launch_token0(float* tok, const float* time_table, const float* text_
                          const int64_t* tmap_dev = nullptr, const int* cursor = nullptr,
                          _Float16* tok_split = nullptr /* write split rows instead of fp32 */, int* range_flag = nullptr);
 // x [nb][C][T] -> split frame rows [nb*T][2*Kp] (Kp = C rounded up to 32, zero padded): A operand of the input projection
+// (gs_bits: multiply by the power-of-two gradient scale first — the output gradient on its way into the input-VJP)
 hipError_t launch_pose_rows_split(const float* x, _Float16* xs, int nb, int C, int T, int Kp, int* range_flag,
-                                  hipStream_t stream);
+                                  hipStream_t stream, const unsigned* gs_bits = nullptr);
 // text_term[b'] rows: conditional rows get proj[b] (already W·c+b), unconditional rows get bias
 hipError_t launch_fill_rows(float* dst, const float* row, int rows, int d, hipStream_t stream);
 hipError_t launch_add2(float* dst, const float* a, const float* b, int64_t n, hipStream_t stream);
