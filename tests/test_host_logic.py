@@ -388,3 +388,35 @@ def test_no_undefined_names_in_bench_and_package():
                 bound |= set(node.names)
         used = {n.id for n in ast.walk(tree) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load)}
         assert not (used - bound), (str(path.relative_to(REPO)), sorted(used - bound))
+
+
+def test_probe_programs_compile_and_leave_the_product_kernel_alone(tmp_path):
+    """tools/probes/kstep.hip instantiates the product's gemm_h3 body under compile-time ablations (-DCMDI_KABL, round 4: the
+    evidence behind 'the encoder GEMMs are frozen').  The hooks must keep compiling, and with CMDI_KABL undefined they must
+    compile to NOTHING: the ablation build differs from the plain one, two plain builds of the kernel do not."""
+    import shutil
+    import subprocess
+    from pathlib import Path
+    from conftest import PKG
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(hipcc).exists():
+        pytest.skip("hipcc not available")
+    csrc = REPO / PKG / "csrc"
+    probe = REPO / "tools" / "probes" / "kstep.hip"
+
+    def isa(name, *defs):
+        out = tmp_path / name
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-DCMDI_PROBES", *defs, "-I", str(csrc), "-S",
+                            "--cuda-device-only", "-o", str(out), str(probe)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        body = [ln for ln in out.read_text().splitlines() if ln.startswith("\t") and not ln.lstrip().startswith((";", "."))]
+        return [ln for ln in body if "__hip_cuid" not in ln]
+
+    plain = isa("plain.s")
+    assert isa("zero.s", "-DCMDI_KABL=0") == plain                  # the hooks are inert unless asked for
+    ablated = isa("abl.s", "-DCMDI_KABL=15")
+    assert ablated != plain and sum("v_mfma" in ln for ln in ablated) < sum("v_mfma" in ln for ln in plain)
+    src = (REPO / "tools" / "probes" / "ingest_rate.hip")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-c", "--cuda-device-only", "-o", str(tmp_path / "ingest.o"), str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
