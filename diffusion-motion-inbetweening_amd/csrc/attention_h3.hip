@@ -422,7 +422,7 @@ hipError_t launch_attention_h3(const _Float16* qkv_split, float* out, _Float16* 
     // 25 -> 17 us at B = 10 (0.80 -> 0.76 and 0.99 -> 0.92 ms per step).  A wave computes its 32 queries with the same
     // instruction sequence in both schedules: same bits (test_attention_split_schedule_is_bitwise_identical).
     static const int split_env = std::getenv("CMDI_ATTN_SPLIT") ? std::atoi(std::getenv("CMDI_ATTN_SPLIT")) : kAttnSplitDefault;
-    bool split = split_env > 0;
+    bool split = split_env > 0, auto_split = false;
     if (split_env < 0) {
         static int cus_dev[kMaxDevices] = {};
         int& cus = cus_dev[device_slot()];
@@ -431,8 +431,12 @@ hipError_t launch_attention_h3(const _Float16* qkv_split, float* out, _Float16* 
             if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
             cus = n > 0 ? n : 256;
         }
-        split = 2L * n_seq * H <= cus;
+        split = auto_split = 2L * n_seq * H <= cus;
     }
+    // (by grid size: every half block has a CU — and its 160 KiB of LDS — to itself, so it keeps the 4-stage K/V ring of the
+    // 8-wave form, three stages in flight instead of one; CMDI_ATTN_SPLIT=1 is the 2-stage form that fits twice per CU)
+    if (auto_split && S > 128)
+        return launch_attention_h3_cfg<4, 4>(qkv_split, out, out_split, range_flag, row_stats, n_seq, S, H, dbg, head_rows, stream);
     if (split && S > 128)
         return launch_attention_h3_cfg<4, 2>(qkv_split, out, out_split, range_flag, row_stats, n_seq, S, H, dbg, head_rows, stream);
 #ifdef CMDI_PROBES
