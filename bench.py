@@ -21,7 +21,12 @@ Prints ONE JSON line on rank 0 (see the task contract) with these extra objects:
   bf16x6        the same on the CMDI_PREC_BF16X6 engine (exact three-plane bf16 operands, six bf16 MFMA products per
                 fp32 product: no operand truncation, no range limit)
   cpu_baseline  the reference's CPU path restated on torch CPU kernels (oracle/torch_cpu_port.py) on the
-                host cores, a bounded sample of the same workload (1 warm-up + 3 full CFG steps at B=32)
+                host cores, a bounded sample of the same workload (1 warm-up + 10 full CFG steps at B=32, quoted on the
+                median step with min / max; intra-op threads calibrated on a full step)
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches ITSELF as
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py ...`
+(one rank per GPU over RCCL; rank 0 prints the line), so the bare command line and the driver's torchrun form are the same job.
 """
 from __future__ import annotations
 
@@ -315,6 +320,7 @@ def roofline_from(eng, run_loop, split, is_unet, pmc):
     run_loop()
     torch.cuda.synchronize()
     ms, launches, (m, n, k) = eng.profile_read()
+    ran = eng.profile_kernel()          # the kernel family the bracketed launches dispatched to, recorded by the library
     eng.profile_enable(False)
     avg_s = ms / max(launches, 1) * 1e-3
     flop_launch = 2.0 * m * n * k
@@ -341,7 +347,7 @@ def roofline_from(eng, run_loop, split, is_unet, pmc):
         # product, so its ceiling is the dense f16 peak / 3
         peak = F16_MFMA_PEAK_TFLOPS / 3.0
         what = ("unet.downs.0.1.blocks.1 Conv1d k=5 as a tap-shifted GEMM" if is_unet else "self_attn.in_proj")
-        kname = "gemm_h3p_kernel (persistent, frames only: " if is_unet else "gemm_h3_kernel ("
+        kname = f"{ran} (" + ("persistent, " if ran == "gemm_h3p_kernel" else "") + ("frames only: " if is_unet and ran == "gemm_h3p_kernel" else "")
         rl.update(kernel=f"{kname}{what}, M={m} N={n} K={k}, 3x v_mfma_f32_32x32x16_f16 per fp32-equivalent "
                          "product" + ("" if is_unet else ", split-rows output") + ")",
                   peak=peak, frac=ach / peak, executed_f16_tflops=3.0 * ach, f16_dense_peak=F16_MFMA_PEAK_TFLOPS,
@@ -349,12 +355,12 @@ def roofline_from(eng, run_loop, split, is_unet, pmc):
     elif eng.precision == "bf16x6":
         # six exact bf16 partial products per fp32 product: ceiling = dense bf16 peak / 6
         peak = F16_MFMA_PEAK_TFLOPS / 6.0
-        rl.update(kernel=f"gemm_x6_kernel (self_attn.in_proj, M={m} N={n} K={k}, 6x v_mfma_f32_32x32x16_bf16 per fp32 "
+        rl.update(kernel=f"{ran or 'gemm_x6_kernel'} (self_attn.in_proj, M={m} N={n} K={k}, 6x v_mfma_f32_32x32x16_bf16 per fp32 "
                          "product on exact three-plane bf16 operands)",
                   peak=peak, frac=ach / peak, executed_bf16_tflops=6.0 * ach, bf16_dense_peak=F16_MFMA_PEAK_TFLOPS,
                   vs_fp32_mfma_peak=ach / FP32_MFMA_PEAK_TFLOPS)
     else:
-        rl.update(kernel=f"gemm_nt_kernel (self_attn.in_proj, M={m} N={n} K={k}, fp32 MFMA 32x32x2)",
+        rl.update(kernel=f"{ran or 'gemm_nt_kernel'} (self_attn.in_proj, M={m} N={n} K={k}, fp32 MFMA 32x32x2)",
                   peak=FP32_MFMA_PEAK_TFLOPS, frac=ach / FP32_MFMA_PEAK_TFLOPS)
     return rl
 
@@ -407,6 +413,18 @@ def job_rates(layout: dict, world: int, K: int, elapsed_s: float, n_chain: int) 
             "motions_per_sec": layout["global_batch"] / (n_chain * elapsed_s / K)}
 
 
+def self_launch_argv(argv, n_gpus, port=None):
+    """The torch.distributed.run command line `python bench.py --gpus N ...` turns into when it was started bare (no
+    WORLD_SIZE): one rank per GPU on this node, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), str(Path(__file__).resolve())] + list(argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -423,8 +441,33 @@ def main():
     ap.add_argument("--precision", default=None, choices=["f32", "f16x3", "bf16x6"],
                     help="encoder GEMM arithmetic (include/condmdi.h CMDI_PREC_*); default: the library's")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--dry-launch", action="store_true", help=argparse.SUPPRESS)    # CPU test of the launch path (gloo, no GPU work)
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.pmc_child:
+        # started bare: become the launcher of N ranks; their rank 0 prints the JSON line
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.call(self_launch_argv(sys.argv[1:], args.gpus), env=env))
+    if args.dry_launch:
+        # tests/test_host_logic.py: the bare `python bench.py --gpus 2` must arrive HERE as 2 ranks with a working process
+        # group (gloo on the CPU-only container) — the rendezvous, rank arithmetic and one collective, no device work
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", init_method="env://")
+            ones = torch.ones(1)
+            dist.all_reduce(ones)
+            layout = job_layout(cfg, world, dist.get_rank(), sub("utils.dist_util").shard_bounds)
+            spans = [None] * world
+            dist.all_gather_object(spans, (layout["lo"], layout["hi"]))
+            if dist.get_rank() == 0:
+                print(json.dumps({"dry_launch": True, "n_gpus": args.gpus, "world": dist.get_world_size(), "ranks_summed": int(ones.item()),
+                                  "shards": spans, "global_batch": layout["global_batch"]}), flush=True)
+            dist.destroy_process_group()
+        else:
+            print(json.dumps({"dry_launch": True, "n_gpus": 1, "world": 1}), flush=True)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

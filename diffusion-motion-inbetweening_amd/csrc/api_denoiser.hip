@@ -52,8 +52,13 @@ int run_layers(cmdi_engine* e, int seq0, int nseq, bool keep, bool prof, hipStre
         if (!prof || e->prof_which != which) return CMDI_OK;
         HIPCHK(hipEventRecord(e->ev_pool[e->ev_used + 1], s));
         e->ev_used += 2;
-        if (which == 0) { e->prof_m = M; e->prof_n = 3 * d; e->prof_k = d; }
-        else { e->prof_m = nseq; e->prof_n = S; e->prof_k = e->H; }      // (sequences, tokens, heads)
+        if (which == 0) {
+            e->prof_m = M; e->prof_n = 3 * d; e->prof_k = d;
+            e->prof_kernel = h3 ? gemm_h3_last_route() : (e->precision == CMDI_PREC_BF16X6 ? "gemm_x6_kernel" : "gemm_nt_kernel");
+        } else {      // (sequences, tokens, heads)
+            e->prof_m = nseq; e->prof_n = S; e->prof_k = e->H;
+            e->prof_kernel = h3 ? "attention_h3_kernel" : "attention_fwd_kernel";
+        }
         return CMDI_OK;
     };
     if (h3 && !e->io_h3)  // layer 0 reads the tokens assembled by token0 + the input projection (fp32)
@@ -289,7 +294,10 @@ int mdm_forward(cmdi_engine* e, const float* x, const int64_t* t_dev, int64_t t_
         }
         const int urc = unet_forward(e->unet, x, e->have_obs ? e->obs_x0 : nullptr, e->have_obs ? e->obs_mask : nullptr,
                                      e->uemb, B, n_seq, T, out_buf, s, ev0, ev1, mnk, keep);
-        if (e->profile && mnk[0]) { e->ev_used += 2; e->prof_m = mnk[0]; e->prof_n = mnk[1]; e->prof_k = mnk[2]; }
+        if (e->profile && mnk[0]) {
+            e->ev_used += 2; e->prof_m = mnk[0]; e->prof_n = mnk[1]; e->prof_k = mnk[2];
+            e->prof_kernel = unet_probe_route(e->unet);
+        }
         if (urc != 0)
             return fail(CMDI_E_HIP, std::string("UNET: ") + unet_error(e->unet));
         e->stash_valid = keep;

@@ -276,6 +276,8 @@ int cmdi_profile_read(cmdi_handle e, double* total_ms, int64_t* launches, int32_
     return CMDI_OK;
 }
 
+const char* cmdi_profile_kernel(cmdi_handle e) { return e ? e->prof_kernel : ""; }
+
 int cmdi_destroy(cmdi_handle h) {
     if (!h) return CMDI_OK;
     drop_graphs(h);

@@ -184,6 +184,12 @@ int cmdi_conv_rows_h3(const void* d_a_split, int32_t a_ld, const void* d_w_split
     p.a_ld = a_ld; p.a_row_mul = a_row_mul; p.taps = taps; p.cpt = cin / 32;
     p.c_row_mul = c_row_mul; p.c_row_add = c_row_add; p.tp = tp; p.t_lo = t_lo; p.t_hi = t_hi;
     const int kind = d_c_split ? H3_PLAIN_SPLIT : (d_resid ? H3_RESID : H3_PLAIN);
+    if (tile == 50 || tile == 51) {   // the persistent kernel's convolution form: refuse by name what it does not compute
+        if (kind != H3_PLAIN) return fail(CMDI_E_INVALID, "tile 50 / 51: plain fp32 output only (no d_c_split, no d_resid)");
+        if (n % 256 != 0) return fail(CMDI_E_INVALID, "tile 50 / 51: n must be a multiple of 256");
+        if (tile == 51 && (a_row_mul > 1 || c_row_mul != 0))
+            return fail(CMDI_E_INVALID, "tile 51: stride-1 rows only (a_row_mul <= 1, c_row_mul == 0)");
+    }
     if (tile == 51) {   // the persistent kernel over frames only (H3Params.rc_tv): m must be whole framed sequences
         if (tp < 1 || m % tp != 0 || t_hi <= t_lo) return fail(CMDI_E_INVALID, "tile 51 needs m % tp == 0");
         p.rc_tv = t_hi - t_lo;
@@ -238,7 +244,9 @@ int cmdi_attention_vjp_h3(const void* d_qkv_split, const float* d_dout, void* d_
     float* o_fwd = d_work;                                  // [M, d]
     _Float16* dout_s = reinterpret_cast<_Float16*>(o_fwd + M * d);   // [M, 2d] halves = M*d floats
     float* row_stats = o_fwd + 2 * M * d;                   // [n_seq*H*S, 2]
-    float* rowdot = row_stats + 2 * nhs;                    // attention_bwd_scratch_floats(): <= 3.5 * n_seq*H*S + 96*n_seq*H
+    // (the backward kernels fetch the tile statistics with 16-byte LDS-DMA pieces: the block starts on a multiple of 4 floats
+    //  whatever the parity of n_seq*H*S — ADVICE r4; d_work itself is 16-byte aligned by contract)
+    float* rowdot = row_stats + ((2 * nhs + 3) & ~(size_t)3);   // attention_bwd_scratch_floats(): <= 3.5 * n_seq*H*S + 96*n_seq*H
     const _Float16* qs = static_cast<const _Float16*>(d_qkv_split);
     HIPCHK(launch_attention_h3(qs, o_fwd, nullptr, nullptr, row_stats, n_seq, seq_len, n_heads, s));
     HIPCHK(launch_split_f16(d_dout, dout_s, (int64_t)M, (int)d, (int)d, nullptr, s));

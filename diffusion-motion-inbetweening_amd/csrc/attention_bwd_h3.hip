@@ -587,8 +587,8 @@ hipError_t launch_attention_bwd_h3(const _Float16* qkv_split, const float* o_fwd
     constexpr size_t lds_q = 2ull * KVSTG > (size_t)BW * 32 * RSTR ? 2ull * KVSTG : (size_t)BW * 32 * RSTR;
     constexpr size_t lds_kv = (size_t)BW * TILE + 2ull * QSTG;
     static_assert(lds_kv <= 160 * 1024 && (size_t)BW * 32 * RSTR <= lds_kv, "LDS budget");
-    static bool attr_done_dev[kMaxDevices] = {};
-    bool& attr_done = attr_done_dev[device_slot()];
+    static PerDevice<bool> attr_done_dev;
+    bool& attr_done = attr_done_dev.get();
     if (!attr_done) {
         hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_q_h3_kernel),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);

@@ -229,8 +229,8 @@ hipError_t launch_attention_fwd(const float* qkv, float* out, _Float16* out_spli
     dim3 grid(n_seq * H, (qblocks + NWAVE - 1) / NWAVE);
     const float scale = 1.0f / sqrtf((float)DH);
     constexpr size_t lds = 2ull * STAGE_FLOATS * sizeof(float);  // 66,560 B > the 64 KiB default
-    static bool attr_done_dev[kMaxDevices] = {};
-    bool& attr_done = attr_done_dev[device_slot()];
+    static PerDevice<bool> attr_done_dev;
+    bool& attr_done = attr_done_dev.get();
     if (!attr_done) {
         hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_fwd_kernel<true>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

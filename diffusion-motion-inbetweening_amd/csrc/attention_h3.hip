@@ -385,8 +385,8 @@ static hipError_t launch_attention_h3_cfg(const _Float16* qkv_split, float* out,
     const float scale = 1.0f / sqrtf((float)DH);
     constexpr size_t lds_ring = (size_t)NS * STAGE, lds_epi = (size_t)NW * 32 * 528;   // K/V ring | output rows (epilogue)
     constexpr size_t lds = lds_ring > lds_epi ? lds_ring : lds_epi;
-    static bool attr_done_dev[kMaxDevices] = {};
-    bool& attr_done = attr_done_dev[device_slot()];
+    static PerDevice<bool> attr_done_dev;
+    bool& attr_done = attr_done_dev.get();
     if (!attr_done) {
         hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_h3_kernel<true, NW, NS, STAG>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -424,8 +424,8 @@ hipError_t launch_attention_h3(const _Float16* qkv_split, float* out, _Float16* 
     static const int split_env = std::getenv("CMDI_ATTN_SPLIT") ? std::atoi(std::getenv("CMDI_ATTN_SPLIT")) : kAttnSplitDefault;
     bool split = split_env > 0, auto_split = false;
     if (split_env < 0) {
-        static int cus_dev[kMaxDevices] = {};
-        int& cus = cus_dev[device_slot()];
+        static PerDevice<int> cus_dev;
+        int& cus = cus_dev.get();
         if (!cus) {
             int dev = 0, n = 256;
             if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);

@@ -11,14 +11,24 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kWave = 64;
 
 // Function attributes (dynamic LDS size) and CU counts belong to a DEVICE: a launcher's one-time setup is keyed by the
-// current device, so a process that drives several GPUs sets every one of them up.  Slot 0 doubles as the
-// fallback for device ids beyond the table.
-constexpr int kMaxDevices = 16;
-inline int device_slot() {
-    int d = 0;
-    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) d = 0;
-    return d;
-}
+// current device, so a process that drives several GPUs sets every one of them up.  64 slots cover a node in
+// CPX mode (8 sockets x 8 partitions).  A device id beyond the table — or a failing hipGetDevice — gets NO cache: get()
+// hands out a fresh zero-initialised scratch value, so the attribute call / CU query is repeated on every launch there
+// instead of being skipped because some other device had done it.
+constexpr int kMaxDevices = 64;
+template <class T>
+struct PerDevice {
+    T slot[kMaxDevices] = {};
+    T& get() {
+        static thread_local T scratch;
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) {
+            scratch = T{};
+            return scratch;
+        }
+        return slot[d];
+    }
+};
 
 // Row r (0..15) of a 32x32 MFMA C/D fragment held by lane `lane`:
 // col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).

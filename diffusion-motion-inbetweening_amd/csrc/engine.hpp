@@ -179,6 +179,7 @@ struct cmdi_engine {
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
     int prof_m = 0, prof_n = 0, prof_k = 0;
+    const char* prof_kernel = "";   // kernel family the bracketed launches dispatched to (cmdi_profile_kernel)
     int prof_which = 0;          // kernel kind the events bracket: 0 = in_proj GEMM, 1 = attention
 };
 

@@ -17,8 +17,8 @@ using T128x256w8 = Tile<128, 256, 32, 2, 4>;  // 8 waves, 64x64 per wave
 template <class TC, int AM, int BMD, int EPI, int PIPE = 0>
 static hipError_t launch_one(const GemmParams& p, hipStream_t stream) {
     auto kern = gemm_nt_kernel<TC, AM, BMD, EPI, PIPE>;
-    static bool attr_done_dev[kMaxDevices] = {};  // benign race: the attribute call is idempotent
-    bool& attr_done = attr_done_dev[device_slot()];
+    static PerDevice<bool> attr_done_dev;  // benign race: the attribute call is idempotent
+    bool& attr_done = attr_done_dev.get();
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -25,8 +25,8 @@ using H128x256w16 = H3Tile<128, 256, 4, 4, 3, 4>;   // 16 waves, 32x64 per wave
 template <class TC, int EPI>
 static hipError_t launch_h3_one(const H3Params& p, hipStream_t stream) {
     auto kern = gemm_h3_kernel<TC, EPI>;
-    static bool attr_done_dev[kMaxDevices] = {};  // benign race: the attribute call is idempotent
-    bool& attr_done = attr_done_dev[device_slot()];
+    static PerDevice<bool> attr_done_dev;  // benign race: the attribute call is idempotent
+    bool& attr_done = attr_done_dev.get();
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -61,8 +61,8 @@ static hipError_t launch_h3_mixed(const H3Params& p0, hipStream_t stream) {
     const int n_small = ((p.M - p.m_split + TS::BM - 1) / TS::BM) * ((p.N + TS::BN - 1) / TS::BN);
     auto kern = gemm_h3_mixed_kernel<TB, TS, EPI>;
     constexpr size_t lds = TB::LDS_BYTES > TS::LDS_BYTES ? TB::LDS_BYTES : TS::LDS_BYTES;
-    static bool attr_done_dev[kMaxDevices] = {};
-    bool& attr_done = attr_done_dev[device_slot()];
+    static PerDevice<bool> attr_done_dev;
+    bool& attr_done = attr_done_dev.get();
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -118,7 +118,21 @@ bool gemm_h3_persistent_for(int M) {
     return mode == 1 || (mode == -1 && M >= 32768);
 }
 
+// Name of the kernel family the most recent launch_gemm_h3 of this thread dispatched to (bench.py names the kernel that RAN,
+// VERDICT r4 weak #13): the tiled gemm_h3_kernel or the persistent gemm_h3p_kernel.
+static thread_local const char* g_h3_route = "";
+const char* gemm_h3_last_route() { return g_h3_route; }
+
+static hipError_t launch_gemm_h3_routed(int epi, const H3Params& p, int tile, hipStream_t s, const char** route);
+
 hipError_t launch_gemm_h3(int epi, const H3Params& p, int tile, hipStream_t s) {
+    const char* route = "gemm_h3_kernel";
+    const hipError_t err = launch_gemm_h3_routed(epi, p, tile, s, &route);
+    g_h3_route = route;
+    return err;
+}
+
+static hipError_t launch_gemm_h3_routed(int epi, const H3Params& p, int tile, hipStream_t s, const char** route) {
     if (p.K % 32 != 0 || (p.N % 8 != 0 && epi != H3_MOTION) || p.M <= 0 || p.N <= 0) return hipErrorInvalidValue;
     {   // the LDS-DMA requests address both operands with 32-bit byte offsets from their base (buffer descriptors)
         const size_t a_row = 2 * (p.a_ld ? (size_t)p.a_ld : 2 * (size_t)p.K) * (size_t)(p.a_row_mul ? p.a_row_mul : 1);
@@ -136,10 +150,13 @@ hipError_t launch_gemm_h3(int epi, const H3Params& p, int tile, hipStream_t s) {
     if ((p.out_part && (epi != H3_RESID || p.N != 512)) || (p.ln_rg && (epi != H3_RESID || !p.Rs || !p.ln_part || p.N != 512)) ||
         (p.ln_c1 && (!p.ln_part || p.K != 512)))
         return hipErrorInvalidValue;
-    if (tile == 50) return launch_gemm_h3p(epi, p, s, 0);
+    if (tile == 50) { *route = "gemm_h3p_kernel"; return launch_gemm_h3p(epi, p, s, 0); }
     if (p.rc_tv) return hipErrorInvalidValue;      // logical-row GEMMs exist on the persistent kernel only
-    if (tile == 0 && gemm_h3_persistent_for(p.M) && gemm_h3p_supports(epi, p)) return launch_gemm_h3p(epi, p, s, 0);
-    if (tile >= 1000) return launch_gemm_h3p(epi, p, s, tile - 1000);   // structure variants / ablations (probes library only)
+    if (tile == 0 && gemm_h3_persistent_for(p.M) && gemm_h3p_supports(epi, p)) {
+        *route = "gemm_h3p_kernel";
+        return launch_gemm_h3p(epi, p, s, 0);
+    }
+    if (tile >= 1000) { *route = "gemm_h3p_kernel"; return launch_gemm_h3p(epi, p, s, tile - 1000); }   // structure variants / ablations (probes library only)
     if (tile == 0) {
         tile = gemm_h3_auto_tile(p.M, p.N);
         static int epi8 = -1;

@@ -30,10 +30,10 @@ bool gemm_h3p_supports(int epi, const H3Params& p) {
 template <int EPI, int ABL = 0, bool CONV = false>
 static hipError_t launch_h3p(const H3Params& p, hipStream_t stream) {
     auto kern = gemm_h3p_kernel<EPI, ABL, CONV>;
-    static bool attr_done_dev[kMaxDevices] = {};   // benign race: the attribute call is idempotent
-    bool& attr_done = attr_done_dev[device_slot()];
-    static int blocks_dev[kMaxDevices] = {};
-    int& blocks = blocks_dev[device_slot()];
+    static PerDevice<bool> attr_done_dev;   // benign race: the attribute call is idempotent
+    bool& attr_done = attr_done_dev.get();
+    static PerDevice<int> blocks_dev;
+    int& blocks = blocks_dev.get();
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)H3PTile::LDS_BYTES);

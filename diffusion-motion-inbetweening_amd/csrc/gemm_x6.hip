@@ -51,8 +51,8 @@ static int x6_slots() {
 template <int EPI, int VAR>
 static hipError_t launch_x6_one(const GemmParams& p, hipStream_t stream) {
     auto kern = gemm_x6_kernel<EPI, VAR>;
-    static bool attr_done_dev[kMaxDevices] = {};  // benign race: the attribute call is idempotent
-    bool& attr_done = attr_done_dev[device_slot()];
+    static PerDevice<bool> attr_done_dev;  // benign race: the attribute call is idempotent
+    bool& attr_done = attr_done_dev.get();
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6Tile::LDS_BYTES);

@@ -38,6 +38,7 @@ hipError_t launch_gemm_h3(int epi, const H3Params& p, int tile, hipStream_t stre
 int gemm_h3_auto_tile(int M, int N);
 // gemm_h3p.hip: the persistent, phase-alternating kernel (tile id 50 of launch_gemm_h3); same bits as the tiles above
 bool gemm_h3p_supports(int epi, const H3Params& p);
+const char* gemm_h3_last_route();   // kernel family of this thread's most recent launch_gemm_h3
 bool gemm_h3_persistent_for(int M);   // policy (CMDI_H3_PERSIST), gemm_h3.hip
 hipError_t launch_gemm_h3p(int epi, const H3Params& p, hipStream_t stream, int ablation = 0);   // ablation: probes library only
 // fp32 [rows][cols] (row stride ld_src) -> split rows [rows][2*cols] halves (format: gemm_h3.hpp)
@@ -115,6 +116,7 @@ struct UnetModel;
 UnetModel* unet_new(int n_feats, int added, int dim, const int mults[4], int max_seq, bool text, bool want_grad,
                     bool attention);
 const char* unet_error(const UnetModel* u);
+const char* unet_probe_route(const UnetModel* u);   // kernel family of the bench-probed convolution GEMM
 int64_t unet_bytes(const UnetModel* u);
 void unet_free(UnetModel* u);
 int unet_load_weight(UnetModel* u, const char* name, const float* d_src, int64_t numel, hipStream_t s);

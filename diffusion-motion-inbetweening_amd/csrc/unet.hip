@@ -554,6 +554,7 @@ struct UnetModel {
     int ksplit_ok = 1;   // CMDI_UNET_KSPLIT=0: no split-K at the coarse levels
     hipEvent_t probe_ev[2] = {nullptr, nullptr};   // bench: events around ONE convolution GEMM (downs.0.1, blocks.1)
     int probe_mnk[3] = {0, 0, 0};
+    const char* probe_route = "";                  // kernel family that GEMM dispatched to (cmdi_profile_kernel)
     // CMDI_UNET_FUSE_GN: bit l = fuse convolution + GroupNorm at level l (0, 1) into ONE GEMM (H3_CONV_GN); 0 = convolution on
     // the persistent / tiled GEMM + the one-pass GroupNorm kernel.  Round 2 (two GroupNorm kernels per norm): fusing level 1
     // (128x128 tiles, two blocks per CU) 8.83 -> 8.70 ms/step; level 0 needs 256-row tiles and gained nothing.  Round 4: with
@@ -809,6 +810,7 @@ UnetModel* unet_new(int n_feats, int added, int dim, const int mults[4], int max
 }
 
 const char* unet_error(const UnetModel* u) { return u->err.c_str(); }
+const char* unet_probe_route(const UnetModel* u) { return u->probe_route; }
 int64_t unet_bytes(const UnetModel* u) { return u->bytes; }
 
 void unet_free(UnetModel* u) {
@@ -1020,7 +1022,7 @@ int res_block(UnetModel* u, const ResBlock& r, const _Float16* xs, int a_ld, con
                 u->probe_mnk[0] = nseq * L.Tv; u->probe_mnk[1] = C; u->probe_mnk[2] = 5 * r.c2.cin_p;
             }
             if (conv_gn_rows(u, r.c2, r.n2, u->H1S[level], 2 * C, rows, level, nullptr, xf, out_f, out_s, out_ld, s)) return -1;
-            if (probe) UCHK(hipEventRecord(u->probe_ev[1], s));
+            if (probe) { UCHK(hipEventRecord(u->probe_ev[1], s)); u->probe_route = gemm_h3_last_route(); }
             return 0;
         }
         if (conv_gn_rows(u, r.c2, r.n2, u->H1S[level], 2 * C, rows, level, nullptr, nullptr, u->F1[level], nullptr, 0, s)) return -1;
@@ -1037,7 +1039,7 @@ int res_block(UnetModel* u, const ResBlock& r, const _Float16* xs, int a_ld, con
         u->probe_mnk[0] = nseq * L.Tv; u->probe_mnk[1] = C; u->probe_mnk[2] = 5 * r.c2.cin_p;   // algorithmic: valid frames only
     }
     if (conv_rows(u, r.c2, r.c2.ws, u->H1S[level], 2 * C, rows, level, 5, 2, 1, 0, 0, f2, nullptr, 0, nullptr, s, &n2)) return -1;
-    if (probe) UCHK(hipEventRecord(u->probe_ev[1], s));
+    if (probe) { UCHK(hipEventRecord(u->probe_ev[1], s)); u->probe_route = gemm_h3_last_route(); }
     if (st) { st->n1 = n1; st->n2 = n2; }
     float* stats2 = st ? st->st2 : nullptr;
     if (!r.res.ws) {   // identity residual, added behind the Mish
@@ -1137,8 +1139,8 @@ int res_block_bwd(UnetModel* u, const ResBlock& r, const RBStash& st, const floa
 int attn_backward(UnetModel* u, const AttnSite& a, int nseq, float* dy, int ld, hipStream_t s) {
     const Lvl L = lvl(a.level);
     const int C = u->C[1], rows = nseq * L.Tp, l = a.level;
-    static bool attr_done_dev[kMaxDevices] = {};
-    bool& attr_done = attr_done_dev[device_slot()];
+    static PerDevice<bool> attr_done_dev;
+    bool& attr_done = attr_done_dev.get();
     if (!attr_done) {
         UCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(linattn_core_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)LA_BWD_LDS));

@@ -132,6 +132,10 @@ class Engine:
                                            C.byref(n), C.byref(k)))
         return ms.value, cnt.value, (m.value, n.value, k.value)
 
+    def profile_kernel(self) -> str:
+        """Kernel family the profiled launches dispatched to (e.g. 'gemm_h3_kernel', 'gemm_h3p_kernel')."""
+        return (self.lib.cmdi_profile_kernel(self._h) or b"").decode()
+
     # -- weights --------------------------------------------------------------------------------
     def load_state_dict(self, state_dict, n_time_rows: int = 1000):
         """Ingest the reference's MDM state dict (SURVEY.md §5.4 key names)."""
@@ -457,7 +461,7 @@ def attention_vjp_h3(qkv: torch.Tensor, dout: torch.Tensor, n_seq: int, seq_len:
     assert qkv.shape == (M, 3 * d) and dout.shape == (M, d) and dout.dtype == torch.float32 and dout.is_contiguous()
     qs = split_f16(qkv)
     dqs = torch.zeros((M, 6 * d), dtype=torch.float16, device=qkv.device)
-    work = torch.empty(2 * M * d + n_seq * n_heads * (2 * seq_len + 96 * ((seq_len + 31) // 32)), dtype=torch.float32,
+    work = torch.empty(2 * M * d + n_seq * n_heads * (2 * seq_len + 96 * ((seq_len + 31) // 32)) + 4, dtype=torch.float32,
                        device=qkv.device)
     with torch.cuda.device(qkv.device):
         N.check(lib.cmdi_attention_vjp_h3(N.ptr(qs), N.ptr(dout), N.ptr(dqs), N.ptr(work), n_seq, seq_len, n_heads,

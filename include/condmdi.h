@@ -309,8 +309,8 @@ int cmdi_attention_fwd_h3(const void* d_qkv_split, float* d_out, int32_t n_seq, 
 /* Input-VJP of the self-attention core alone on the f16 matrix pipe (test / bench hook; in the engine it runs inside
  * cmdi_mdm_vjp and replaces torch.autograd through torch MultiheadAttention at diffusion/gaussian_diffusion.py:411-416):
  * d_dqkv_split [n_seq*S, 6*H*128] split rows = (d out / d qkv)^T · d_dout, with d_dout fp32 [n_seq*S, H*128].  The forward
- * pass is re-run first for its row statistics.  d_work: n_seq*S*H*128*2 + n_seq*H*(2*S + 96*ceil(S/32)) floats of scratch
- * (16-B aligned). */
+ * pass is re-run first for its row statistics.  d_work: n_seq*S*H*128*2 + n_seq*H*(2*S + 96*ceil(S/32)) + 4 floats of scratch
+ * (16-B aligned; the + 4 lets the tile-statistics block start on 16 bytes when n_seq*H*S is odd). */
 int cmdi_attention_vjp_h3(const void* d_qkv_split, const float* d_dout, void* d_dqkv_split, float* d_work,
                           int32_t n_seq, int32_t seq_len, int32_t n_heads, cmdi_stream stream);
 /* Philox4x32-10 raw block (host, for known-answer tests): out[4] = philox(counter[4], key[2]). */
@@ -325,6 +325,10 @@ int cmdi_profile_enable(cmdi_handle h, int32_t on);
 int cmdi_profile_select(cmdi_handle h, int32_t which);
 int cmdi_profile_read(cmdi_handle h, double* total_ms, int64_t* launches, int32_t* m, int32_t* n,
                       int32_t* k);
+/* Kernel family the most recently bracketed launches DISPATCHED to ("gemm_h3_kernel", "gemm_h3p_kernel" (persistent),
+ * "gemm_x6_kernel", "gemm_nt_kernel", "attention_h3_kernel", "attention_fwd_kernel"): recorded at launch time, so
+ * bench.py's roofline names the kernel that ran rather than the one it expects.  "" before the first profiled launch. */
+const char* cmdi_profile_kernel(cmdi_handle h);
 /* Number of independent batch pipelines cmdi_sample_loop cuts the CURRENT condition's batch into (1 = none; 2 from
  * 8192 token rows up, CMDI_GROUPS overrides): each part runs its whole chain on its own stream. */
 int cmdi_pipeline_parts(cmdi_handle h);

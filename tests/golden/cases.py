@@ -240,6 +240,17 @@ BIG_CASES = {
     # compared with reference values over the whole chain, not its first 20 steps.  Sample 0's x_t every 100 steps.
     "big_c2_long": dict(kind="chain", text=True, cfg=True, weight_seed=41, B=32, T=196, respacing=None, sampler="ddpm",
                         seed=511, ragged=True, keep=BIG_KEEP, every=100),
+    # (VERDICT r4 task 1a) BASELINE config 3 itself, END TO END: B=32 x 196 frames, text CFG, ragged lengths,
+    # 'benchmark_sparse' keyframes, imputation + reconstruction guidance (weight 20) on ALL 1000 ancestral steps
+    # (reference gaussian_diffusion.py:405-435 on every step; the released command is the reference README.md:161),
+    # ~45 min of reference CPU.  Sample 0's x_t every 100 steps.
+    "big_c3_long": dict(kind="chain", text=True, cfg=True, weight_seed=42, B=32, T=196, respacing=None, sampler="ddpm",
+                        seed=512, ragged=True, keep=BIG_KEEP, every=100, edit=True, trans_length=5, imputate=True,
+                        stop_imputation_at=1, recon=True, recon_weight=20.0, grad_schedule=None, stop_recguidance_at=0),
+    # the same guided chain at B=2, also run by the reference in float64 (ground truth of the guided drift table)
+    "long_c3": dict(kind="chain", text=True, cfg=True, weight_seed=42, B=2, T=196, respacing=None, sampler="ddpm",
+                    seed=513, ragged=True, every=100, f64=True, edit=True, trans_length=5, imputate=True,
+                    stop_imputation_at=1, recon=True, recon_weight=20.0, grad_schedule=None, stop_recguidance_at=0),
 }
 
 

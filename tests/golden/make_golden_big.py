@@ -135,7 +135,7 @@ def fwd_case(ref, name):
 
 
 def main():
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", 0)) or os.cpu_count() or 1)
     ref = ref_shims.import_reference()
     names = sys.argv[1:] or list(cases.BIG_CASES)
     for name in names:

@@ -295,7 +295,8 @@ def test_f16x3_range_guard():
         model.invalidate_engine()
         out = model(x, t, y={})
         assert model._engine.precision == (precision or "bf16x6")
-        assert ok("f16x3_range_guard.rel_l2.0", rel_l2(out.cpu().numpy(), want), 2e-5), (precision, rel_l2(out.cpu().numpy(), want))
+        assert ok("f16x3_range_guard.rel_l2.0", rel_l2(out.cpu().numpy(), want), 2e-5, precision=model._engine.precision), \
+            (precision, rel_l2(out.cpu().numpy(), want))
 
 
 @pytest.mark.parametrize("scale,expect", [(5.0e3, "f16x3"), (4.0e4, "bf16x6")])
@@ -729,6 +730,42 @@ def test_baseline_config2_full_1000_step_chain_vs_reference(cases, precision):
         assert np.array_equal(last.cpu().numpy(), final)
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_baseline_config3_full_1000_step_guided_chain_vs_reference(cases, precision):
+    """BASELINE config 3 END TO END (VERDICT r4 task 1a): B=32 x 196 frames, text CFG, ragged lengths, 'benchmark_sparse'
+    keyframes, imputation + reconstruction guidance (weight 20) on ALL 1000 ancestral steps — the hand-written input-VJP, the
+    power-of-two gradient scale and the split-row stash on every step — through the one-call two-pipeline path
+    (part_forward / part_backward) against the REAL reference's CPU chain (make_golden_big.py big_c3_long; reference
+    gaussian_diffusion.py:405-435 on every step, README.md:161): six stored samples (three per pipeline), float64
+    (sum, sum^2) of all 32, and sample 0's x_t every 100 steps on the way (per-step generator, default precision)."""
+    name = "big_c3_long"
+    case, inp, g, model, diffusion, kw = big_setup(cases, name, precision)
+    final = diffusion.p_sample_loop(model, inp["draw0"].shape, **kw)
+    eng = model.model._engine
+    assert eng.pipeline_parts() == 2, "the two-pipeline schedule was not taken at the BASELINE shape"
+    final = final.cpu().numpy()
+    keep = list(case["keep"])
+    err = rel_l2(final[keep], g["final"])
+    per = [rel_l2(final[k], g["final"][i]) for i, k in enumerate(keep)]
+    print(json_line({"case": name, "precision": precision, "rel_l2": err, "per_sample": per}))
+    assert np.isfinite(final).all()
+    assert ok("baseline_config3_full_chain.rel_l2", err, 1e-4) and ok("baseline_config3_full_chain.per_sample", max(per), 2e-4), (err, per)
+    assert ok("baseline_config3_full_chain.stats", stats_err(cases.sample_stats(final), g["stats"]), 2e-4)
+    if precision == PRECISIONS[0]:
+        at = {int(i): k for k, i in enumerate(g["dump_at"])}
+        last = None
+        for i, out in enumerate(diffusion.p_sample_loop_progressive(model, inp["draw0"].shape, **kw)):
+            last = out["sample"]
+            if i in at:
+                assert ok("baseline_config3_full_chain.on_the_way", rel_l2(last[:1].cpu().numpy(), g["dumps"][at[i]]), 1e-4), i
+        assert np.array_equal(last.cpu().numpy(), final)
+
+
+def json_line(obj):
+    import json
+    return json.dumps(obj)
+
+
 @pytest.mark.parametrize("name", ["c4_ddim", "c4_ddpm", "c5_rank"])
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_c4_c5_shape_chains_vs_reference(cases, name, precision):
@@ -825,10 +862,10 @@ def test_forced_two_pipelines_on_small_golden(cases, precision, monkeypatch):
 
 
 # measured drift (gpurun_out/drift_*.json): bound = 4x the larger of the two engines' measured value
-LONG_TOL = {"long_ddpm": 1e-4, "long_ddim100": 1e-4}
+LONG_TOL = {"long_ddpm": 1e-4, "long_ddim100": 1e-4, "long_c3": 1e-4}
 
 
-@pytest.mark.parametrize("name", ["long_ddpm", "long_ddim100"])
+@pytest.mark.parametrize("name", ["long_ddpm", "long_ddim100", "long_c3"])
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_long_chain_drift_vs_reference(cases, name, precision):
     """The FULL 1000-step ancestral chain (and ddim_sample_loop on 'ddim100') on shared noise: x_t every 100 (10) steps
@@ -1356,6 +1393,43 @@ def test_conv_rows_persistent_is_bitwise_the_tiled_kernel(kind):
     v = outs[1].view(B, tp_out, cout)
     assert float((v[:, :h_out] + 7.25).abs().max()) == 0.0 and float((v[:, h_out + T_out:] + 7.25).abs().max()) == 0.0
     assert float((v[:, h_out:h_out + T_out:2 if kind == "up" else 1] + 7.25).abs().min()) > 0.0   # frames were written
+
+
+def test_conv_rows_persistent_refuses_what_it_does_not_compute():
+    """tiles 50 / 51 of cmdi_conv_rows_h3 reach the persistent kernel, which computes plain fp32
+    convolution outputs with n % 256 == 0 only (tile 51: stride-1 rows).  Every other combination must come back as an
+    error with the output untouched — never CMDI_OK with columns unwritten or rows addressed as a plain GEMM."""
+    eng, N = sub("engine"), sub("_native")
+    lib = N.load()
+    g = torch.Generator().manual_seed(77)
+    B, cin, T, h = 5, 64, 56, 4
+    tp = T + 2 * h
+    a_s = eng.split_f16(torch.randn(8 + B * tp + 8, cin, generator=g).to(DEV))
+    a_ptr = a_s.data_ptr() + 8 * (2 * cin) * 2
+    stream = N.current_stream(torch.device(DEV))
+
+    def call(cout, tile, split=False, resid=False, taps=5, pad=2, a_mul=1, c_mul=0):
+        w_s = eng.split_f16((torch.randn(cout, taps * cin, generator=g) * 0.1).to(DEV))
+        bias = torch.zeros(cout, device=DEV)
+        out = torch.full((2 * B * tp, cout), -7.25, device=DEV)
+        out_s = torch.zeros((2 * B * tp, 2 * cout), dtype=torch.float16, device=DEV) if split else None
+        res = torch.zeros((2 * B * tp, cout), device=DEV) if resid else None
+        with torch.cuda.device(DEV):
+            rc = lib.cmdi_conv_rows_h3(a_ptr, 2 * cin, N.ptr(w_s), N.ptr(bias), N.ptr(res), 0 if split else N.ptr(out), N.ptr(out_s),
+                                       B * tp, cout, cin, taps, pad, a_mul, c_mul, 0, tp, h, h + T, tile, stream)
+        torch.cuda.synchronize()
+        untouched = bool((out == -7.25).all()) and (out_s is None or bool((out_s == 0).all()))
+        return rc, untouched
+
+    assert call(256, 50)[0] == 0 and call(256, 51)[0] == 0                     # the supported form still runs
+    for kw in (dict(cout=320, tile=50), dict(cout=128, tile=50), dict(cout=320, tile=51),      # n % 256 != 0, n < 256
+               dict(cout=256, tile=50, split=True), dict(cout=256, tile=51, split=True),       # split output
+               dict(cout=256, tile=50, resid=True), dict(cout=256, tile=51, resid=True),       # residual epilogue
+               dict(cout=256, tile=51, taps=3, pad=1, a_mul=2),                                # stride-2 rows as logical rows
+               dict(cout=256, tile=51, taps=2, pad=1, c_mul=2)):                               # transposed-convolution rows
+        rc, untouched = call(**kw)
+        assert rc != 0 and untouched, (kw, rc, untouched)
+        assert b"tile" in lib.cmdi_last_error() or b"launch_gemm_h3" in lib.cmdi_last_error()
 
 
 # ---- MDM_UNET denoiser (SURVEY.md §8f rank 1) -------------------------------------------------------------

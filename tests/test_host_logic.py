@@ -420,3 +420,62 @@ def test_probe_programs_compile_and_leave_the_product_kernel_alone(tmp_path):
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-c", "--cuda-device-only", "-o", str(tmp_path / "ingest.o"), str(src)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_bounds_are_per_precision_sticky_for_nan_and_never_raised_silently(monkeypatch):
+    """VERDICT r4 task 2 / ADVICE r4: (1) a comparison of a precision-parametrised test is keyed "<key>@<precision>" and held to
+    ITS bound, falling back to the legacy precision-blind key only where bounds.json has none yet; (2) a NaN measurement is
+    never erased by a later finite one, neither in ok() nor in the merge of two runs; (3) tools/make_bounds.py keeps an
+    existing bound when a new measurement would RAISE it, unless --allow-raise."""
+    import importlib
+    import math
+    import conftest
+    mb = importlib.import_module("tools.make_bounds")
+    monkeypatch.setattr(conftest, "BOUNDS", {"k": {"bound": 8e-6}, "k@f16x3": {"bound": 4e-6}})
+    monkeypatch.setattr(conftest, "_MEASURED", {})
+    assert conftest.ok("k", 3e-6, 1e-4, precision="f16x3") and not conftest.ok("k", 5e-6, 1e-4, precision="f16x3")
+    assert conftest.ok("k", 5e-6, 1e-4, precision="f32")            # no k@f32 yet: the legacy key's 8e-6
+    assert not conftest.ok("k", 5e-6, 4e-6, precision="f32")        # ... never above the stated default
+    assert set(conftest._MEASURED) == {"k@f16x3", "k@f32"} and conftest._MEASURED["k@f16x3"]["max"] == 5e-6
+    assert not conftest.ok("n", float("nan"), 1.0) and conftest.ok("n", 0.5, 1.0)
+    assert math.isnan(conftest._MEASURED["n"]["max"]) and conftest._MEASURED["n"]["n"] == 2
+    merged = conftest.merge_measured({"n": {"max": 0.25, "n": 1, "default": 1.0}}, {"n": dict(conftest._MEASURED["n"])})
+    assert math.isnan(merged["n"]["max"])
+    merged = conftest.merge_measured({"n": {"max": float("nan"), "n": 1, "default": 1.0}}, {"n": {"max": 0.5, "n": 1, "default": 1.0}})
+    assert math.isnan(merged["n"]["max"]) and merged["n"]["n"] == 2
+    with pytest.raises(SystemExit):
+        mb.derive({"n": {"max": float("nan"), "n": 1, "default": 1.0}}, {})
+    old = {"k": {"bound": 8e-6, "measured": 2e-6}, "gone": {"bound": 1e-6, "measured": 1e-7}}
+    meas = {"k@f16x3": {"max": 1.0e-6, "n": 3, "default": 1e-4}, "k@f32": {"max": 3.0e-6, "n": 3, "default": 1e-4}}
+    new, raised = mb.derive(meas, old)
+    assert new["k@f16x3"]["bound"] == 4e-6 and new["k@f32"]["bound"] == 8e-6          # f32 wanted 1.2e-5: kept at the old 8e-6
+    assert raised == [("k@f32", 8e-6, 1.2e-5)] and "k" not in new and new["gone"]["bound"] == 1e-6
+    new, raised = mb.derive(meas, old, allow_raise=True)
+    assert new["k@f32"]["bound"] == 1.2e-5 and len(raised) == 1
+    again, raised = mb.derive({"k@f16x3": {"max": 2.9e-6, "n": 1, "default": 1e-4}}, new)          # a 2.9x regression of the default
+    assert again["k@f16x3"]["bound"] == 4e-6 and raised                                               # ... does not move its bound
+
+
+def test_bare_bench_command_line_with_gpus_2_launches_its_own_ranks():
+    """the driver starts `python bench.py --gpus 1 ...` bare; started the same way with --gpus 2 the
+    script used to die on `assert args.gpus == world`.  Now it re-executes itself under torch.distributed.run (one rank per
+    GPU, 127.0.0.1 rendezvous).  --dry-launch stops each rank after the process group is up (gloo here: no GPU) and one
+    all-reduce + the shard arithmetic of the real run, so the whole launch path runs on the CPU-only container."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import importlib
+    bench = importlib.import_module("bench")
+    argv = bench.self_launch_argv(["--gpus", "4", "--steps", "3"], 4, port=29512)
+    assert argv[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in argv
+    assert argv[argv.index("--master-addr") + 1] == "127.0.0.1" and argv[argv.index("--master-port") + 1] == "29512"
+    assert argv[-4:] == ["--gpus", "4", "--steps", "3"] and argv[-5].endswith("bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    for cfg, batch in (("c2", 64), ("c5", 1024)):
+        r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--config", cfg, "--dry-launch"], env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert line["world"] == 2 and line["ranks_summed"] == 2 and line["n_gpus"] == 2, line
+        assert line["global_batch"] == batch and line["shards"] == [[0, batch // 2], [batch // 2, batch]], line

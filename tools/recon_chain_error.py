@@ -1,6 +1,19 @@
-"""The smoke chain (3 steps of CFG + imputation + reconstruction guidance, weight 20) against the numpy oracle run in float64
-(the truth) and in float32 (what smoke() compares with): how much of the GPU path's distance is the fp32 oracle's own rounding.
-   CMDI_LIB_VARIANT=<v> python tools/recon_chain_error.py"""
+"""Where the guided (reconstruction-guidance) path's error comes from, per arithmetic mode (VERDICT r4 task 1b).
+
+Truth = the numpy oracle run in float64.  Compared with it, on the same inputs:
+  * the numpy oracle in float32 (what smoke() and the fp32 goldens' arithmetic are),
+  * the native engine in each precision mode: f16x3 (default, 22-bit split operands + split stash), bf16x6 (exact operands),
+    f32 (fp32 MFMA, fp32 stash).
+Stage 1: ONE evaluation — CFG forward and the input-VJP of the reconstruction loss seed (the two model-side ingredients of a
+         guided step), each mode vs float64.
+Stage 2: guided chains (B=2, T=60, CFG 2.5, 'benchmark_sparse' keyframes, imputation + guidance weight 20; weight 0 as the
+         control) of 3 / 10 / 100 steps — the LAST n steps of the respaced chain from a noised init_image.
+The float64 / float32 oracle results ("wants") take minutes of CPU per chain, so they are computed ONCE on the build container
+and shipped (tools/data/recon_chain_wants.npz); the GPU box only runs the engines:
+   python tools/recon_chain_error.py --make-wants            # CPU, here (~30 min)
+   python tools/recon_chain_error.py > gpurun_out/recon_chain_error.txt      # GPU box
+"""
+import argparse
 import importlib
 import sys
 from pathlib import Path
@@ -17,46 +30,134 @@ from oracle import diffusion_oracle as do, mdm_oracle as mo, weights
 PKG = "diffusion-motion-inbetweening_amd"
 sub = lambda n: importlib.import_module(f"{PKG}.{n}")
 dev = torch.device("cuda:0")
+MODES = ("f16x3", "bf16x6", "f32")
+WANTS = REPO / "tools" / "data" / "recon_chain_wants.npz"
+PLAN = ((3, 20.0), (3, 0.0), (10, 20.0), (10, 0.0), (100, 20.0))
+f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+rel = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64) - b) / np.linalg.norm(b))
 
 
-def run(n, w):
+def oracle_dtype(dt):
+    do.F32 = dt
+    mo.F32 = dt
+
+
+def native_model(sd, precision):
     mu = sub("utils.model_util")
     model, _ = mu.create_model_and_diffusion(SimpleNamespace(dataset="humanml"), None)
-    sd = weights.make_state_dict(3, text=True)
     mu.load_model_wo_clip(model, weights.to_torch(sd))
-    model = sub("model.cfg_sampler").ClassifierFreeSampleModel(model.to(dev).eval())
-    rs, gd = sub("diffusion.respace"), sub("diffusion.gaussian_diffusion")
-    diffusion = rs.SpacedDiffusion(rs.space_timesteps(1000, [10]), gd.DiffusionConfig(betas=gd.get_named_beta_schedule("cosine", 1000)))
-    rng = np.random.default_rng(0)
+    model.native_precision = precision
+    return sub("model.cfg_sampler").ClassifierFreeSampleModel(model.to(dev).eval())
+
+
+def inputs(seed, n_noise):
+    rng = np.random.default_rng(seed)
     B, T = 2, 60
     shape = (B, 263, 1, T)
-    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
-    x_T, x0 = f32(rng.standard_normal(shape)), f32(rng.standard_normal(shape))
-    noise = f32(rng.standard_normal((n,) + shape))
-    enc, scale = f32(rng.standard_normal((B, 512))), f32([2.5, 2.5])
-    lengths = np.array([60, 44])
-    len_mask = (np.arange(T)[None] < lengths[:, None]).reshape(B, 1, 1, T)
-    kf_mask = cases.sparse_keyframe_mask(lengths, T, 5)
-    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    y = dict(mask=tt(len_mask), lengths=tt(lengths), text_embed=tt(enc), text_scale=tt(scale), inpainting_mask=tt(kf_mask),
-             inpainted_motion=tt(x0), imputate=True, stop_imputation_at=1, replacement_distribution='conditional',
-             reconstruction_guidance=True, reconstruction_weight=w, gradient_schedule=None, diffusion_steps=1000, stop_recguidance_at=0)
-    diffusion.injected_noise = tt(noise)
-    out = diffusion.p_sample_loop(model, shape, noise=tt(x_T), clip_denoised=False, model_kwargs={"y": y}, skip_timesteps=10 - n,
-                                  init_image=tt(x0)).cpu().numpy()
-    sch = do.Schedule(do.named_betas("cosine", 1000), do.space_timesteps(1000, [10]))
-    wants = {}
+    d = dict(shape=shape, x_T=f32(rng.standard_normal(shape)), x0=f32(rng.standard_normal(shape)),
+             noise=f32(rng.standard_normal((n_noise,) + shape)), enc=f32(rng.standard_normal((B, 512))), scale=f32([2.5, 2.5]),
+             lengths=np.array([60, 44]))
+    d["len_mask"] = (np.arange(T)[None] < d["lengths"][:, None]).reshape(B, 1, 1, T)
+    d["kf_mask"] = cases.sparse_keyframe_mask(d["lengths"], T, 5)
+    return d
+
+
+def eval_inputs():
+    d = inputs(1, 1)
+    gout = f32(np.random.default_rng(2).standard_normal(d["shape"]) * (d["kf_mask"] & d["len_mask"]))
+    return d, d["x_T"], np.array([500, 500]), gout
+
+
+def eval_wants(sd):
+    d, x, t, gout = eval_inputs()
+    out = {}
     for name, dt in (("f32", np.float32), ("f64", np.float64)):
-        do.F32 = dt; mo.F32 = dt
-        x = do.q_sample(sch, n - 1, x0, x_T)
-        wants[name] = np.asarray(do.sample_loop(sch, mo.MDMOracle(sd), x, noise, enc_text=enc, text_scale=scale, cfg=True, mask=kf_mask & len_mask,
-                                                inpaint=x0, imputate=True, stop_imputation_at=1, recon_guidance=True, recon_weight=w,
-                                                first_step=n - 1), dtype=np.float64)
-    do.F32 = np.float32; mo.F32 = np.float32
-    rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
-    print(f"steps {n} weight {w:5.1f}: GPU vs f64 oracle {rel(out, wants['f64']):.3e} | f32 oracle vs f64 oracle {rel(wants['f32'], wants['f64']):.3e} | "
-          f"GPU vs f32 oracle {rel(out, wants['f32']):.3e}", flush=True)
+        oracle_dtype(dt)
+        orc = mo.MDMOracle(sd)
+        out[f"eval_fwd_{name}"] = np.asarray(orc.forward_cfg(x.astype(dt), t, d["enc"].astype(dt), d["scale"].astype(dt))[0], np.float64)
+        out[f"eval_vjp_{name}"] = np.asarray(orc.vjp_cfg(x.astype(dt), t, gout.astype(dt), d["enc"].astype(dt), d["scale"].astype(dt)), np.float64)
+    oracle_dtype(np.float32)
+    return out
 
 
-for n, w in ((3, 20.0), (3, 0.0), (10, 20.0)):
-    run(n, w)
+def one_evaluation(sd, want):
+    """CFG forward + input-VJP of a keyframe-masked output gradient at t = 500."""
+    d, x, t, gout = eval_inputs()
+    B, T = 2, 60
+    print("# stage 1: one CFG evaluation + input-VJP, rel-L2 vs the float64 oracle")
+    print(f"{'numpy fp32 oracle':>18}: forward {rel(want['eval_fwd_f32'], want['eval_fwd_f64']):.3e} | "
+          f"VJP {rel(want['eval_vjp_f32'], want['eval_vjp_f64']):.3e}")
+    for mode in MODES:
+        model = native_model(sd, mode)
+        eng = model.model.engine(dev, max_batch=B, max_frames=T, want_grad=True)
+        eng.set_condition(batch=B, n_frames=T, cfg=True, enc_text=tt(d["enc"]), text_scale=tt(d["scale"]))
+        out = eng.mdm_forward(tt(x), tt(t)).cpu().numpy()
+        gx = eng.mdm_vjp(tt(gout)).cpu().numpy()
+        assert eng.precision == mode
+        print(f"{'engine ' + mode:>18}: forward {rel(out, want['eval_fwd_f64']):.3e} | VJP {rel(gx, want['eval_vjp_f64']):.3e}", flush=True)
+
+
+def chain_wants(sd, n, w):
+    n_resp = max(10, n)
+    d = inputs(0, n)
+    sch = do.Schedule(do.named_betas("cosine", 1000), do.space_timesteps(1000, [n_resp]))
+    out = {}
+    for name, dt in (("f32", np.float32), ("f64", np.float64)):
+        oracle_dtype(dt)
+        x = do.q_sample(sch, n - 1, d["x0"], d["x_T"])
+        out[f"chain_{n}_{w:g}_{name}"] = np.asarray(
+            do.sample_loop(sch, mo.MDMOracle(sd), x, d["noise"], enc_text=d["enc"], text_scale=d["scale"], cfg=True,
+                           mask=d["kf_mask"] & d["len_mask"], inpaint=d["x0"], imputate=True, stop_imputation_at=1,
+                           recon_guidance=True, recon_weight=w, first_step=n - 1), dtype=np.float64)
+    oracle_dtype(np.float32)
+    return out
+
+
+def chain(sd, n, w, want):
+    n_resp = max(10, n)
+    d = inputs(0, n)
+    rs, gd = sub("diffusion.respace"), sub("diffusion.gaussian_diffusion")
+    wants = {k: want[f"chain_{n}_{w:g}_{k}"] for k in ("f32", "f64")}
+    row = [f"steps {n:3d} weight {w:4.1f}: fp32 oracle {rel(wants['f32'], wants['f64']):.3e}"]
+    for mode in MODES:
+        model = native_model(sd, mode)
+        diffusion = rs.SpacedDiffusion(rs.space_timesteps(1000, [n_resp]), gd.DiffusionConfig(betas=gd.get_named_beta_schedule("cosine", 1000)))
+        y = dict(mask=tt(d["len_mask"]), lengths=tt(d["lengths"]), text_embed=tt(d["enc"]), text_scale=tt(d["scale"]),
+                 inpainting_mask=tt(d["kf_mask"]), inpainted_motion=tt(d["x0"]), imputate=True, stop_imputation_at=1,
+                 replacement_distribution='conditional', reconstruction_guidance=True, reconstruction_weight=w, gradient_schedule=None,
+                 diffusion_steps=1000, stop_recguidance_at=0)
+        diffusion.injected_noise = tt(d["noise"])
+        out = diffusion.p_sample_loop(model, d["shape"], noise=tt(d["x_T"]), clip_denoised=False, model_kwargs={"y": y},
+                                      skip_timesteps=n_resp - n, init_image=tt(d["x0"])).cpu().numpy()
+        assert model.model._engine.precision == mode, model.model._engine.precision
+        row.append(f"{mode} {rel(out, wants['f64']):.3e} (vs fp32 oracle {rel(out, wants['f32']):.3e})")
+    print(" | ".join(row), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--make-wants", action="store_true")
+    ap.add_argument("--weight-seed", type=int, default=3)
+    args = ap.parse_args()
+    sd = weights.make_state_dict(args.weight_seed, text=True)
+    if args.make_wants:
+        import time
+        out, t0 = eval_wants(sd), time.time()
+        for n, w in PLAN:
+            out.update(chain_wants(sd, n, w))
+            print(f"oracle chains steps {n} weight {w}: {time.time() - t0:.0f}s", flush=True)
+            WANTS.parent.mkdir(exist_ok=True)
+            np.savez_compressed(WANTS, weight_seed=args.weight_seed, **out)
+        return
+    want = np.load(WANTS)
+    assert int(want["weight_seed"]) == args.weight_seed
+    one_evaluation(sd, want)
+    print("# stage 2: guided chains, rel-L2 of the final sample vs the float64 oracle chain (in brackets: vs the fp32 oracle chain)")
+    for n, w in PLAN:
+        if f"chain_{n}_{w:g}_f64" in want.files:
+            chain(sd, n, w, want)
+
+
+if __name__ == "__main__":
+    main()
