@@ -90,6 +90,9 @@ __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
 #ifndef CMDI_W_AUX
 #define CMDI_W_AUX 0
 #endif
+#ifndef CMDI_CONV_KORDER
+#define CMDI_CONV_KORDER 1   // K order of a convolution's tap-shifted GEMM: 1 = chunk-major (taps of a chunk consecutive), 0 = tap-major
+#endif
 typedef float f4v_ __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void h3_store_f4(float* dst, float4 v) {
 #if CMDI_OUT_SC1
@@ -720,14 +723,27 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
         grow = grow < p.N ? grow : p.N - 1;
         w_voff[q] = (unsigned)(((size_t)grow * ldk + ((pslot ^ ((row >> 1) & 7)) << 3)) * 2);
     }
-    // plain GEMM: chunk kt of the row; convolution: tap kt / cpt = one row further, chunk kt % cpt.  (cpt = "never" for
-    // the plain case keeps the address arithmetic branch-free: the requests then sit in the same scheduling region as
-    // the MFMAs around them)
+    // plain GEMM: chunk kt of the row.  Convolution (round 5, CHUNK-MAJOR K order): K step kt = chunk * taps + tap reads the
+    // 32-channel chunk `kt / taps` of the row `kt % taps` frames further on, so the taps of one chunk are CONSECUTIVE K steps —
+    // the shifted re-reads of the same A lines come back within `taps` steps and hit the L2 (tap-major order, rounds 1-4:
+    // a tap's re-read came cpt = 32 K steps and a 21-MB weight stream later, and every tap fetched A from HBM again —
+    // 682 MB per level-0 launch for 140 MB of distinct bytes).  Weights are packed [Cout][chunk][tap][32] to match
+    // (unet.hip pack_conv_w_kernel).  Branch-free for the plain case (taps = 1): the requests sit in the same scheduling
+    // region as the MFMAs around them.  CMDI_CONV_KORDER=0 (experiment builds): the tap-major order of rounds 1-4.
+#if CMDI_CONV_KORDER
+    const int ktaps = p.cpt && p.taps > 0 ? p.taps : 1;
+#else
     const int cpt = p.cpt ? p.cpt : 0x40000000;
+#endif
     auto issue = [&](int kt, int buf) {
         char* stage = lds + buf * STAGE;
+#if CMDI_CONV_KORDER
+        const int chunk = kt / ktaps, tap = kt - chunk * ktaps;
+        const int a_soff = (int)(((size_t)tap * lda + (size_t)chunk * 64) * 2);
+#else
         const int tap = kt / cpt;
         const int a_soff = (int)(((size_t)tap * lda + (size_t)(kt - tap * cpt) * 64) * 2);
+#endif
 #pragma unroll
         for (int q = 0; q < BM / 8 / NW; ++q)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(stage + (q * NW + wave) * 1024),

@@ -112,7 +112,8 @@ __global__ __launch_bounds__(H3PTile::NT, 2) void gemm_h3p_kernel(const H3Params
     const unsigned ldk_b = 4u * (unsigned)p.K;                 // bytes per split row
     const unsigned lda_b = CONV && p.a_ld ? 2u * (unsigned)p.a_ld : ldk_b;                       // bytes per A row
     const unsigned a_rstep = CONV && p.a_row_mul ? lda_b * (unsigned)p.a_row_mul : lda_b;        // ... per output row
-    const int cpt = CONV && p.cpt ? p.cpt : 0x40000000;
+    [[maybe_unused]] const int cpt = CONV && p.cpt ? p.cpt : 0x40000000;
+    [[maybe_unused]] const int ktaps = CONV && p.cpt && p.taps > 0 ? p.taps : 1;
     unsigned src_off[6];
     auto set_src = [&](int m0, int n0) {
 #pragma unroll
@@ -199,9 +200,15 @@ __global__ __launch_bounds__(H3PTile::NT, 2) void gemm_h3p_kernel(const H3Params
     auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };   // block-uniform bookkeeping stays on the scalar unit
     auto advance_issue = [&]() {
         iss_kt = uni(iss_kt + 1);
-        if constexpr (CONV) {     // tap = kt / cpt, chunk = kt % cpt, kept incrementally on the scalar unit
+        if constexpr (CONV) {     // (tap, chunk) of K step kt, kept incrementally on the scalar unit
+#if CMDI_CONV_KORDER
+            // chunk-major (round 5, as gemm_h3.hpp): kt = chunk * taps + tap — the taps of a chunk are consecutive K steps
+            iss_tap = uni(iss_tap + 1);
+            if (iss_tap == ktaps) { iss_tap = 0; iss_chunk = uni(iss_chunk + 1); }
+#else
             iss_chunk = uni(iss_chunk + 1);
             if (iss_chunk == cpt) { iss_chunk = 0; iss_tap = uni(iss_tap + 1); }
+#endif
             if (iss_kt == nk) { iss_chunk = 0; iss_tap = 0; }
             iss_aoff = uni((int)((unsigned)iss_tap * lda_b) + iss_chunk * 128);
         }

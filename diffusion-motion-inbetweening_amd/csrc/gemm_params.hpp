@@ -87,8 +87,8 @@ struct H3Params {
     int n_big, m_split; // mixed-granularity launch (set by launch_gemm_h3)
     // ---- 1-D convolution as a GEMM over tap-shifted rows (UNET denoiser, unet.hip); all 0 = plain GEMM ----
     // A row of output row m is row (a_row_mul * m) of a [rows, a_ld halves] split matrix whose pointer the
-    // caller has already moved back by the padding; K = taps * cpt * 32 and K step kt reads tap kt / cpt
-    // (one row further per tap), chunk kt % cpt.  The result goes to row m * c_row_mul + c_row_add, and only
+    // caller has already moved back by the padding; K = taps * cpt * 32 and K step kt reads 32-channel chunk kt / taps
+    // of the row kt % taps frames further on (chunk-major, round 5; rounds 1-4: tap kt / cpt, chunk kt % cpt).  The result goes to row m * c_row_mul + c_row_add, and only
     // if that row's position inside its tp-row sequence frame lies in [t_lo, t_hi) (halo rows stay zero).
     int a_ld, a_row_mul, taps, cpt;
     int c_row_mul, c_row_add, tp, t_lo, t_hi;

@@ -464,7 +464,12 @@ __global__ void pack_conv_wT_kernel(const float* __restrict__ w, float* __restri
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (int64_t)Cin_p * K) return;
     const int n = (int)(i / K);
-    const int r = (int)(i - (int64_t)n * K), q = r / Cout_p, c = r - q * Cout_p;
+    const int r = (int)(i - (int64_t)n * K);
+#if CMDI_CONV_KORDER      // chunk-major K (gemm_h3.hpp): K step = (chunk of 32 gradient channels, tap), taps of a chunk consecutive
+    const int kt = r >> 5, ch = kt / taps, q = kt - ch * taps, c = ch * 32 + (r & 31);
+#else
+    const int q = r / Cout_p, c = r - q * Cout_p;
+#endif
     float v = 0.f;
     if (n < Cin && c < Cout) {
         if (mode == 3) v = w[((size_t)c * Cin + n) * k + (k - 1 - q)];
@@ -483,7 +488,8 @@ __global__ void unet_output_kernel(const float* __restrict__ rows, float* __rest
     if (t < T) out[((size_t)seq * J + c) * T + t] = rows[((size_t)seq * Tp + h + t) * N + c];
 }
 
-// conv weight [Cout][Cin][k] -> GEMM weight [Cout][taps * Cin_p] (tap-major K, zero channel padding);
+// conv weight [Cout][Cin][k] -> GEMM weight [Cout][taps * Cin_p], zero channel padding, K in CHUNK-MAJOR order (round 5):
+// column (chunk * taps + tap) * 32 + c32 holds tap `tap` of input channel chunk * 32 + c32 (see gemm_h3.hpp `issue`);
 // transposed-conv weight [Cin][Cout][4] -> the two 2-tap matrices of the even / odd output rows
 __global__ void pack_conv_w_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin, int Cin_p,
                                    int k, int mode) {
@@ -493,7 +499,13 @@ __global__ void pack_conv_w_kernel(const float* __restrict__ w, float* __restric
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (int64_t)Cout * K) return;
     const int n = (int)(i / K);
-    const int r = (int)(i - (int64_t)n * K), tap = r / Cin_p, c = r - tap * Cin_p;
+    const int r = (int)(i - (int64_t)n * K);
+#if CMDI_CONV_KORDER
+    const int taps = mode == 0 ? k : 2;
+    const int kt = r >> 5, ch = kt / taps, tap = kt - ch * taps, c = ch * 32 + (r & 31);
+#else
+    const int tap = r / Cin_p, c = r - tap * Cin_p;
+#endif
     float v = 0.f;
     if (c < Cin) {
         if (mode == 0) v = w[((size_t)n * Cin + c) * k + tap];

@@ -469,6 +469,15 @@ def attention_vjp_h3(qkv: torch.Tensor, dout: torch.Tensor, n_seq: int, seq_len:
     return unsplit_f16(dqs)
 
 
+def conv_weight_k_order(w: torch.Tensor, taps: int) -> torch.Tensor:
+    """[n, taps * cin] tap-major GEMM weights of a convolution (column tap * cin + c) -> the chunk-major K order the
+    convolution GEMMs walk (column (chunk * taps + tap) * 32 + c32, cin % 32 == 0; include/condmdi.h cmdi_conv_rows_h3)."""
+    n, k = w.shape
+    cin = k // taps
+    assert cin * taps == k and cin % 32 == 0
+    return w.reshape(n, taps, cin // 32, 32).permute(0, 2, 1, 3).reshape(n, k).contiguous()
+
+
 def philox4x32_10(counter, key):
     """Host Philox4x32-10 block (known-answer tests)."""
     lib = N.load()

@@ -290,8 +290,10 @@ int cmdi_attention_fwd(const float* d_qkv, float* d_out, int32_t n_seq, int32_t 
 /* 1-D convolution over token rows as a split-f16 GEMM (building block of the UNET denoiser, test hook):
  * activations are rows [.., a_ld halves] in split format, sequences framed by zero halo rows (tp rows per
  * sequence, valid positions [t_lo, t_hi)); output row m * c_row_mul + c_row_add =
- * bias + sum_tap W[:, tap*cin : (tap+1)*cin] · A[a_row_mul * m - pad + tap]; weights [n, 2 * taps * cin]
- * split rows (tap-major K).  Stride-2 convolution: a_row_mul = 2; transposed convolution: c_row_mul = 2.
+ * bias + sum_tap W_tap · A[a_row_mul * m - pad + tap]; weights [n, 2 * taps * cin] split rows with K in CHUNK-MAJOR
+ * order (round 5): K column (chunk * taps + tap) * 32 + c holds tap `tap` of input channel chunk * 32 + c, so the taps of
+ * one 32-channel chunk are consecutive K steps and their shifted re-reads of the same activation lines hit the L2.
+ * Stride-2 convolution: a_row_mul = 2; transposed convolution: c_row_mul = 2.
  * tile: 0 = the library's choice, 50 = the persistent kernel (fp32 output only, n % 256 == 0), 51 = the persistent kernel
  * over the frames [t_lo, t_hi) of every sequence only (m = whole framed sequences; plain convolutions) — same bits all. */
 int cmdi_conv_rows_h3(const void* d_a_split, int32_t a_ld, const void* d_w_split, const float* d_bias,

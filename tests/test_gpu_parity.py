@@ -1346,7 +1346,7 @@ def test_conv_rows_h3_vs_torch(kind):
     out = torch.zeros(B * tp_out, cout, device=DEV)
     m_gemm = B * tp_in if kind == "up" else B * tp_out                       # GEMM rows = output (or input, up) rows
     for wmat, L in zip(wg, launches):
-        w_s = eng.split_f16(wmat.contiguous().to(DEV))
+        w_s = eng.split_f16(eng.conv_weight_k_order(wmat.contiguous(), L["taps"]).to(DEV))   # tap-major -> the GEMM's K order
         a_ptr = a_s.data_ptr() + guard * (2 * cin) * 2
         with torch.cuda.device(DEV):
             N.check(lib.cmdi_conv_rows_h3(a_ptr, 2 * cin, N.ptr(w_s), N.ptr(bias.to(DEV)), 0, N.ptr(out), 0,

@@ -32,6 +32,7 @@ sub = lambda n: importlib.import_module(f"{PKG}.{n}")
 dev = torch.device("cuda:0")
 MODES = ("f16x3", "bf16x6", "f32")
 WANTS = REPO / "tools" / "data" / "recon_chain_wants.npz"
+ENV_TAG = "".join(f" [{k}={v}]" for k, v in sorted(__import__("os").environ.items()) if k in ("CMDI_LN_FOLD_KEEP", "CMDI_LN_FOLD", "CMDI_GROUPS"))
 PLAN = ((3, 20.0), (3, 0.0), (10, 20.0), (10, 0.0), (100, 20.0))
 f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
 tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -81,14 +82,14 @@ def eval_wants(sd):
     return out
 
 
-def one_evaluation(sd, want):
+def one_evaluation(sd, want, modes=MODES):
     """CFG forward + input-VJP of a keyframe-masked output gradient at t = 500."""
     d, x, t, gout = eval_inputs()
     B, T = 2, 60
     print("# stage 1: one CFG evaluation + input-VJP, rel-L2 vs the float64 oracle")
     print(f"{'numpy fp32 oracle':>18}: forward {rel(want['eval_fwd_f32'], want['eval_fwd_f64']):.3e} | "
           f"VJP {rel(want['eval_vjp_f32'], want['eval_vjp_f64']):.3e}")
-    for mode in MODES:
+    for mode in modes:
         model = native_model(sd, mode)
         eng = model.model.engine(dev, max_batch=B, max_frames=T, want_grad=True)
         eng.set_condition(batch=B, n_frames=T, cfg=True, enc_text=tt(d["enc"]), text_scale=tt(d["scale"]))
@@ -96,6 +97,66 @@ def one_evaluation(sd, want):
         gx = eng.mdm_vjp(tt(gout)).cpu().numpy()
         assert eng.precision == mode
         print(f"{'engine ' + mode:>18}: forward {rel(out, want['eval_fwd_f64']):.3e} | VJP {rel(gx, want['eval_vjp_f64']):.3e}", flush=True)
+
+
+def opoint_wants(sd, n=3, w=20.0):
+    """The operating point of the guided chain's LAST step (t = 0) on the float64 chain: state x_1, the model output there,
+    the reconstruction-loss seed and its input-VJP — float64 (truth) and float32 oracle arithmetic at the SAME state and seed."""
+    d = inputs(0, n)
+    sch = do.Schedule(do.named_betas("cosine", 1000), do.space_timesteps(1000, [10]))
+    mask = d["kf_mask"] & d["len_mask"]
+    oracle_dtype(np.float64)
+    orc = mo.MDMOracle(sd)
+    x = do.q_sample(sch, n - 1, d["x0"], d["x_T"])
+    for k, i in enumerate(range(n - 1, 0, -1)):          # every step but the last
+        t = np.full((2,), sch.timestep_map[i], dtype=np.int64)
+        hat = orc.forward_cfg(x, t, d["enc"], d["scale"])[0]
+        seed = do.recon_loss_grad_seed(hat, mask, d["x0"])
+        grad = orc.vjp_cfg(x, t, seed, d["enc"], d["scale"])
+        x, _ = do.step_update(sch, i, x, hat, d["noise"][k], mask=mask, inpaint=d["x0"], impute=True, recon=True, grad=grad,
+                              recon_w=np.float64(w))
+    t0 = np.full((2,), sch.timestep_map[0], dtype=np.int64)
+    x1 = np.asarray(x, np.float32)                        # the state every engine is handed
+    out = {"op_x1": x1, "op_t": t0, "op_k": np.float64(w) * sch.sqrt_ab[0] / 2.0}
+    for name, dt in (("f64", np.float64), ("f32", np.float32)):
+        oracle_dtype(dt)
+        orc = mo.MDMOracle(sd)
+        hat = orc.forward_cfg(x1.astype(dt), t0, d["enc"].astype(dt), d["scale"].astype(dt))[0]
+        if name == "f64":
+            out["op_seed"] = np.asarray(do.recon_loss_grad_seed(hat, mask, d["x0"]), np.float32)   # ONE seed for every mode
+        out[f"op_hat_{name}"] = np.asarray(hat, np.float64)
+        out[f"op_g_{name}"] = np.asarray(orc.vjp_cfg(x1.astype(dt), t0, out["op_seed"].astype(dt), d["enc"].astype(dt),
+                                                     d["scale"].astype(dt)), np.float64)
+    oracle_dtype(np.float32)
+    return out
+
+
+def operating_point(sd, want, modes):
+    """Stage 1b: the two model-side ingredients of the LAST guided step at the chain's own state — and the VJP error where the
+    sampler uses it: the guidance term is g * (1 - mask), i.e. ONLY the entries outside the keyframes, where g is small."""
+    d = inputs(0, 3)
+    B, T = 2, 60
+    m = np.broadcast_to(d["kf_mask"] & d["len_mask"], d["shape"])
+    x1, t0, seed, k = want["op_x1"], want["op_t"], want["op_seed"], float(want["op_k"])
+    g64, h64 = want["op_g_f64"], want["op_hat_f64"]
+    print(f"# stage 1b: last guided step (t = {int(t0[0])}) at the float64 chain's state.  |k g (1-m)| / |x_hat| = "
+          f"{k * np.linalg.norm(g64[~m]) / np.linalg.norm(h64):.3f}; |g| on keyframe entries / elsewhere = "
+          f"{np.sqrt(np.mean(g64[m] ** 2)) / np.sqrt(np.mean(g64[~m] ** 2)):.1f}")
+
+    def row(name, hat, g):
+        tilde = (hat - k * g * (~m)) * (~m) + hat * m
+        tilde64 = (h64 - k * g64 * (~m)) * (~m) + h64 * m
+        print(f"{name:>26}: forward {rel(hat, h64):.3e} | VJP all {rel(g, g64):.3e}  outside keyframes {rel(g[~m], g64[~m]):.3e}  "
+              f"on keyframes {rel(g[m], g64[m]):.3e} | x0 estimate of the step {rel(tilde, tilde64):.3e}", flush=True)
+
+    row("numpy fp32 oracle", want["op_hat_f32"], want["op_g_f32"])
+    for mode in modes:
+        model = native_model(sd, mode)
+        eng = model.model.engine(dev, max_batch=B, max_frames=T, want_grad=True)
+        eng.set_condition(batch=B, n_frames=T, cfg=True, enc_text=tt(d["enc"]), text_scale=tt(d["scale"]))
+        hat = eng.mdm_forward(tt(x1), tt(t0)).cpu().numpy().astype(np.float64)
+        g = eng.mdm_vjp(tt(seed)).cpu().numpy().astype(np.float64)
+        row("engine " + mode + ENV_TAG, hat, g)
 
 
 def chain_wants(sd, n, w):
@@ -114,13 +175,13 @@ def chain_wants(sd, n, w):
     return out
 
 
-def chain(sd, n, w, want):
+def chain(sd, n, w, want, modes=MODES):
     n_resp = max(10, n)
     d = inputs(0, n)
     rs, gd = sub("diffusion.respace"), sub("diffusion.gaussian_diffusion")
     wants = {k: want[f"chain_{n}_{w:g}_{k}"] for k in ("f32", "f64")}
     row = [f"steps {n:3d} weight {w:4.1f}: fp32 oracle {rel(wants['f32'], wants['f64']):.3e}"]
-    for mode in MODES:
+    for mode in modes:
         model = native_model(sd, mode)
         diffusion = rs.SpacedDiffusion(rs.space_timesteps(1000, [n_resp]), gd.DiffusionConfig(betas=gd.get_named_beta_schedule("cosine", 1000)))
         y = dict(mask=tt(d["len_mask"]), lengths=tt(d["lengths"]), text_embed=tt(d["enc"]), text_scale=tt(d["scale"]),
@@ -131,7 +192,7 @@ def chain(sd, n, w, want):
         out = diffusion.p_sample_loop(model, d["shape"], noise=tt(d["x_T"]), clip_denoised=False, model_kwargs={"y": y},
                                       skip_timesteps=n_resp - n, init_image=tt(d["x0"])).cpu().numpy()
         assert model.model._engine.precision == mode, model.model._engine.precision
-        row.append(f"{mode} {rel(out, wants['f64']):.3e} (vs fp32 oracle {rel(out, wants['f32']):.3e})")
+        row.append(f"{mode}{ENV_TAG} {rel(out, wants['f64']):.3e} (vs fp32 oracle {rel(out, wants['f32']):.3e})")
     print(" | ".join(row), flush=True)
 
 
@@ -139,11 +200,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--make-wants", action="store_true")
     ap.add_argument("--weight-seed", type=int, default=3)
+    ap.add_argument("--modes", default=",".join(MODES))
+    ap.add_argument("--stages", default="1,1b,2")
     args = ap.parse_args()
+    modes = tuple(args.modes.split(","))
     sd = weights.make_state_dict(args.weight_seed, text=True)
     if args.make_wants:
         import time
         out, t0 = eval_wants(sd), time.time()
+        out.update(opoint_wants(sd))
         for n, w in PLAN:
             out.update(chain_wants(sd, n, w))
             print(f"oracle chains steps {n} weight {w}: {time.time() - t0:.0f}s", flush=True)
@@ -152,11 +217,16 @@ def main():
         return
     want = np.load(WANTS)
     assert int(want["weight_seed"]) == args.weight_seed
-    one_evaluation(sd, want)
-    print("# stage 2: guided chains, rel-L2 of the final sample vs the float64 oracle chain (in brackets: vs the fp32 oracle chain)")
-    for n, w in PLAN:
-        if f"chain_{n}_{w:g}_f64" in want.files:
-            chain(sd, n, w, want)
+    stages = args.stages.split(",")
+    if "1" in stages:
+        one_evaluation(sd, want, modes)
+    if "1b" in stages:
+        operating_point(sd, want, modes)
+    if "2" in stages:
+        print("# stage 2: guided chains, rel-L2 of the final sample vs the float64 oracle chain (in brackets: vs the fp32 oracle chain)")
+        for n, w in PLAN:
+            if f"chain_{n}_{w:g}_f64" in want.files:
+                chain(sd, n, w, want, modes)
 
 
 if __name__ == "__main__":
