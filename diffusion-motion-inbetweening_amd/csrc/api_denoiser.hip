@@ -96,7 +96,7 @@ int run_layers(cmdi_engine* e, int seq0, int nseq, bool keep, bool prof, hipStre
             }
             { int prc = prof_end(0); if (prc != CMDI_OK) return prc; }
             { int prc = prof_begin(1); if (prc != CMDI_OK) return prc; }
-            HIPCHK(launch_attention_h3(qkvL, nullptr, attnL, e->range_flag,
+            HIPCHK(launch_attention_h3(qkvL, keep && st->attn_f ? st->attn_f + r0 * d : nullptr, attnL, e->range_flag,
                                        keep ? st->row_stats + (size_t)seq0 * e->H * S * 2 : nullptr, nseq, S, e->H, s, head_major));
             { int prc = prof_end(1); if (prc != CMDI_OK) return prc; }
             {   // pre1 = LN2_prev(P) + out_proj(attn)   (+ partial statistics A)
@@ -104,6 +104,7 @@ int run_layers(cmdi_engine* e, int seq0, int nseq, bool keep, bool prof, hipStre
                 p.Rs = Pin;
                 if (prev) { p.ln_part = partB; p.ln_rg = prev->n2_g; p.ln_rb = prev->n2_b; }
                 p.out_part = partA;
+                if (keep && st->pre1_f) p.C = st->pre1_f + r0 * d;
                 HIPCHK(launch_gemm_h3(H3_RESID, p, e->h3_tile_proj, s));
             }
             {   // ffn = gelu(linear1(LN1(pre1)))
@@ -116,6 +117,7 @@ int run_layers(cmdi_engine* e, int seq0, int nseq, bool keep, bool prof, hipStre
                 H3Params p = hp(ffnS, w.l2_ws, w.l2_b, nullptr, pre2L, d, f);
                 p.Rs = pre1L; p.ln_part = partA; p.ln_rg = w.n1_g; p.ln_rb = w.n1_b;
                 p.out_part = partB;
+                if (keep && st->pre2_f) p.C = st->pre2_f + r0 * d;
                 HIPCHK(launch_gemm_h3(H3_RESID, p, e->h3_tile_ffn2, s));
             }
             Pin = pre2L;
@@ -410,7 +412,12 @@ int run_layers_bwd(cmdi_engine* e, int seq0, int nseq, hipStream_t s) {
             const _Float16* pre2S = ss ? reinterpret_cast<const _Float16*>(st.pre2 + r0 * d) : nullptr;
             const _Float16* pre1S = ss ? reinterpret_cast<const _Float16*>(st.pre1 + r0 * d) : nullptr;
             const _Float16* attnS_ = ss ? reinterpret_cast<const _Float16*>(st.attn + r0 * d) : nullptr;
-            HIPCHK(launch_layernorm_bwd(ss ? nullptr : st.pre2 + r0 * d, st.stats2 + r0 * 2, w.n2_g, dA, nullptr, dBS, M, d, s, pre2S));
+            // (stash_f32: fp32 copies of single tensors beside the folded schedule's split rows — which of them the backward
+            //  takes is the engine's accuracy / traffic trade, DESIGN.md section 4 "guided-chain error")
+            const float* pre2F = ss ? (st.pre2_f ? st.pre2_f + r0 * d : nullptr) : st.pre2 + r0 * d;
+            const float* pre1F = ss ? (st.pre1_f ? st.pre1_f + r0 * d : nullptr) : st.pre1 + r0 * d;
+            const float* attnF = ss ? (st.attn_f ? st.attn_f + r0 * d : nullptr) : st.attn + r0 * d;
+            HIPCHK(launch_layernorm_bwd(pre2F, st.stats2 + r0 * 2, w.n2_g, dA, nullptr, dBS, M, d, s, pre2F ? nullptr : pre2S));
             {   // dffn = (dB · W2) * gelu'(aux)
                 H3Params p = hp(dBS, w.l2_wTs, nullptr, dffnS, f, d);
                 p.aux = st.aux + r0 * f;
@@ -421,12 +428,12 @@ int run_layers_bwd(cmdi_engine* e, int seq0, int nseq, hipStream_t s) {
                 p.Rs = dBS;
                 HIPCHK(launch_gemm_h3(H3_RESID, p, e->h3_tile_ffn2, s));
             }
-            HIPCHK(launch_layernorm_bwd(ss ? nullptr : st.pre1 + r0 * d, st.stats1 + r0 * 2, w.n1_g, dH, nullptr, dBS, M, d, s, pre1S));
+            HIPCHK(launch_layernorm_bwd(pre1F, st.stats1 + r0 * 2, w.n1_g, dH, nullptr, dBS, M, d, s, pre1F ? nullptr : pre1S));
             {   // d attn = dB · Wo -> dOS (split: MFMA operand of the attention backward and the dO of its D = rowsum(dO * O))
                 H3Params p = hp(dBS, w.out_wTs, nullptr, dOS, d, d);
                 HIPCHK(launch_gemm_h3(H3_PLAIN_SPLIT, p, e->h3_tile_proj, s));
             }
-            HIPCHK(launch_attention_bwd_h3(st.qkvS + r0 * 6 * d, ss ? nullptr : st.attn + r0 * d, attnS_,
+            HIPCHK(launch_attention_bwd_h3(st.qkvS + r0 * 6 * d, attnF, attnF ? nullptr : attnS_,
                                            st.row_stats + (size_t)seq0 * e->H * S * 2, dOS, dqkvS,
                                            e->drowdot + attention_bwd_scratch_floats(seq0, S, e->H), nseq, S, e->H, s));
             {   // dA = dqkv · Wqkv + dB   (layer 0 with the boundary GEMM on the f16 pipe: as split rows, its W operand)

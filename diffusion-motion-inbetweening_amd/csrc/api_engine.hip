@@ -145,6 +145,7 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
     e->ln_fold = e->io_h3 && desc->d_model == 512 && env_int("CMDI_LN_FOLD", 1);
     e->ln_fold_keep = env_int("CMDI_LN_FOLD_KEEP", 1);
     e->qkv_head_major = env_int("CMDI_QKV_HEAD_MAJOR", 0);
+    e->stash_f32 = env_int("CMDI_STASH_F32", kDefaultStashF32) & 7;
     const int d = e->d, f = e->f, C = e->C;
     const size_t nseq = 2 * (size_t)e->Bmax, Smax = e->Tmax + 1, Mmax = nseq * Smax;
     *out = e;  // so that cmdi_destroy can free a half-built engine
@@ -231,6 +232,11 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
             ALLOC(st.row_stats, nseq * e->H * Smax * 2);
             ALLOC(st.pre1, Mmax * d); ALLOC(st.stats1, Mmax * 2); ALLOC(st.aux, Mmax * f);
             ALLOC(st.pre2, Mmax * d); ALLOC(st.stats2, Mmax * 2);
+            if (e->precision == CMDI_PREC_F16X3 && e->ln_fold && e->ln_fold_keep) {
+                if (e->stash_f32 & 1) ALLOC(st.attn_f, Mmax * d);
+                if (e->stash_f32 & 2) ALLOC(st.pre1_f, Mmax * d);
+                if (e->stash_f32 & 4) ALLOC(st.pre2_f, Mmax * d);
+            }
         }
         ALLOC(e->dA, Mmax * d); ALLOC(e->dB, Mmax * d); ALLOC(e->dH, Mmax * d);
         ALLOC(e->dqkv, Mmax * 3 * d); ALLOC(e->dffn, Mmax * f);

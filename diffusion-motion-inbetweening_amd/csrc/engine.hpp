@@ -40,6 +40,9 @@ namespace host {
 // fp32-MFMA 1.9e-6, the reference's own fp32 CPU chain 1.3e-6 — so the fastest mode is the default; bf16x6 (no operand
 // truncation, no range limit) is what the f16-range guard falls back to.
 constexpr int kDefaultPrecision = CMDI_PREC_F16X3;
+// fp32 copies the folded stashing forward keeps beside its split rows (cmdi_engine::stash_f32, CMDI_STASH_F32 overrides):
+// bits 1 = attention output, 2 = pre1, 4 = pre2.  Round 5: set from the measured attribution of the guided-chain error.
+constexpr int kDefaultStashF32 = 0;
 
 struct LayerW {
     float *in_w = nullptr, *in_b = nullptr, *out_w = nullptr, *out_b = nullptr;
@@ -62,6 +65,8 @@ struct LayerStash {
     float *qkv = nullptr, *attn = nullptr, *row_stats = nullptr;
     _Float16* qkvS = nullptr;   // f16x3: the split qkv replaces the fp32 copy (attention fwd and bwd read it)
     float *pre1 = nullptr, *stats1 = nullptr, *aux = nullptr, *pre2 = nullptr, *stats2 = nullptr;
+    // fp32 copies beside the split rows of the folded schedule's stash (cmdi_engine::stash_f32 bits 1 / 2 / 4), or null
+    float *attn_f = nullptr, *pre1_f = nullptr, *pre2_f = nullptr;
 };
 
 }  // namespace host
@@ -180,6 +185,7 @@ struct cmdi_engine {
     size_t ev_used = 0;
     int prof_m = 0, prof_n = 0, prof_k = 0;
     const char* prof_kernel = "";   // kernel family the bracketed launches dispatched to (cmdi_profile_kernel)
+    int stash_f32 = 0;           // folded stashing forward: fp32 copy of 1 = the attention output, 2 = pre1, 4 = pre2 for the backward
     int prof_which = 0;          // kernel kind the events bracket: 0 = in_proj GEMM, 1 = attention
 };
 

@@ -39,6 +39,15 @@ struct GemmParams {
     const unsigned* gs_bits;  // optional gradient scale (common.hpp grad_scale_from_bits):
                               // EPI_TOKOUT multiplies v by it, EPI_MOTION divides v by it
     const void* Wx;           // bf16x6 path (gemm_x6.hpp): W pre-split into three bf16 planes [N][K/32][3][32], or null
+    // ---- 1-D convolution over tap-shifted fp32 rows (gemm_x6_kernel<.., CONV = true>: the U-Net on exact operands, round 5).
+    // Same meaning as the H3Params fields of these names: A row of GEMM row m is row (a_row_mul * m) of a [rows, lda] fp32
+    // matrix whose pointer the caller has moved back by the padding; K = taps * cin_p in chunk-major order (K step kt = chunk
+    // kt / taps of the row kt % taps frames further on); the result goes to row mo = m * c_row_mul + c_row_add, and only if
+    // that row's position inside its tp-row frame lies in [t_lo, t_hi).  Outputs: C[mo][ldc] and / or C2[mo][ldc2] (both fp32:
+    // the "split rows" of the f16x3 U-Net are plain fp32 rows here); R[mo][r_ld] is added first when given.
+    int taps, a_row_mul, c_row_mul, c_row_add, tp, t_lo, t_hi;
+    float* C2;
+    int ldc2, r_ld;
 };
 
 // ---- split-f16 (fp32-equivalent) GEMM family, gemm_h3.hpp ----------------------------------------

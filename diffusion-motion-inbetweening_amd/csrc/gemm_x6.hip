@@ -82,6 +82,39 @@ static hipError_t launch_x6_var(GemmKind kind, const GemmParams& p, hipStream_t 
     }
 }
 
+// ---- convolution rows on exact operands (the U-Net's bf16x6 mode, round 5) ---------------------------------------------
+bool gemm_x6_conv_supports(GemmKind kind, const GemmParams& p) {
+    if (kind != GK_PLAIN && kind != GK_RESID) return false;
+    if (!p.Wx || !p.A || (!p.C && !p.C2) || p.M <= 0 || p.N <= 0 || p.N % 4 != 0 || p.taps < 1 || p.K % (32 * p.taps) != 0) return false;
+    if (p.lda % 4 != 0 || (p.C && p.ldc % 4 != 0) || (p.C2 && p.ldc2 % 4 != 0) || p.a_row_mul < 0 || p.c_row_mul < 0) return false;
+    if (kind == GK_RESID && (!p.R || (p.r_ld ? p.r_ld : p.ldc) % 4 != 0)) return false;
+    if (p.tp && (p.t_lo < 0 || p.t_hi > p.tp || p.t_lo >= p.t_hi)) return false;
+    return true;
+}
+
+template <int EPI, int VAR>
+static hipError_t launch_x6_conv_one(const GemmParams& p, hipStream_t stream) {
+    auto kern = gemm_x6_kernel<EPI, VAR, true>;
+    static PerDevice<bool> attr_done_dev;
+    bool& attr_done = attr_done_dev.get();
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)X6Tile::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const int tiles = ((p.M + X6Tile::BM - 1) / X6Tile::BM) * ((p.N + X6Tile::BN - 1) / X6Tile::BN);
+    const int grid = tiles < x6_slots() ? tiles : x6_slots();
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(X6Tile::NT), X6Tile::LDS_BYTES, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm_x6_conv(GemmKind kind, const GemmParams& p, hipStream_t s, int variant) {
+    if (!gemm_x6_conv_supports(kind, p)) return hipErrorInvalidValue;
+    if (kind == GK_RESID) return variant == 2 ? launch_x6_conv_one<EPI_RESID, 2>(p, s) : launch_x6_conv_one<EPI_RESID, 0>(p, s);
+    return variant == 2 ? launch_x6_conv_one<EPI_PLAIN, 2>(p, s) : launch_x6_conv_one<EPI_PLAIN, 0>(p, s);
+}
+
 hipError_t launch_gemm_x6(GemmKind kind, const GemmParams& p, hipStream_t s, int variant) {
     if (!gemm_x6_supports(kind, p)) return hipErrorInvalidValue;
     return variant == 2 ? launch_x6_var<2>(kind, p, s) : variant == 1 ? launch_x6_var<1>(kind, p, s) : launch_x6_var<0>(kind, p, s);

@@ -76,7 +76,10 @@ struct X6Tile {
 //        barrier; second half = the products of k-substep 1 + the k-substep-0 reads of step it+1 (from the stage the
 //        barrier just released) + the global loads of step it+2.  The matrix pipe has 12 MFMAs on either side of the
 //        barrier, so neither the LDS latency after it nor the arrival skew before it is exposed.
-template <int EPI, int VAR>
+// CONV (round 5, EPI_PLAIN / EPI_RESID): the A operand is a 1-D convolution's tap-shifted fp32 row matrix and the outputs
+// follow the convolution's row rule (GemmParams taps / a_row_mul / c_row_mul / c_row_add / tp / t_lo / t_hi / C2) — the U-Net's
+// convolutions with EXACT operands (no f16 range limit): only the A address of a K step and the epilogue's row map change.
+template <int EPI, int VAR, bool CONV = false>
 __global__ __launch_bounds__(X6Tile::NT, 2) void gemm_x6_kernel(const GemmParams p) {
     using TC = X6Tile;
     constexpr int BM = TC::BM, BN = TC::BN, BK = TC::BK, TN = TC::TN, ROWB = TC::ROWB, STAGE = TC::STAGE;
@@ -107,7 +110,14 @@ __global__ __launch_bounds__(X6Tile::NT, 2) void gemm_x6_kernel(const GemmParams
     auto load_step = [&](int m0, int n0, int kt) {
         int grow = m0 + a_row;
         grow = grow < p.M ? grow : p.M - 1;                    // clamp: rows past the end land in outputs nobody stores
-        const float* src = p.A + (size_t)grow * p.lda + kt * BK + a_c8 * 8;
+        const float* src;
+        if constexpr (CONV) {     // chunk-major K: the taps of a 32-channel chunk are consecutive K steps (as gemm_h3.hpp)
+            const int taps = p.taps > 0 ? p.taps : 1;
+            const int chunk = kt / taps, tap = kt - chunk * taps;
+            src = p.A + ((size_t)grow * (p.a_row_mul ? p.a_row_mul : 1) + tap) * p.lda + chunk * BK + a_c8 * 8;
+        } else {
+            src = p.A + (size_t)grow * p.lda + kt * BK + a_c8 * 8;
+        }
         ra0 = *reinterpret_cast<const float4*>(src);
         ra1 = *reinterpret_cast<const float4*>(src + 4);
         auto wload = [&](int row, int slot) {
@@ -275,7 +285,42 @@ __global__ __launch_bounds__(X6Tile::NT, 2) void gemm_x6_kernel(const GemmParams
             constexpr int LD = 36;                                  // floats per transposed row: 9 slots of 16 B (odd)
             float* wl = reinterpret_cast<float*>(lds + ((it - 1) & 1) * STAGE) + wave * (32 * LD);
             const int rl = lane >> 3, c4 = (lane & 7) * 4;          // this lane's row (of 8 per instruction) and 4 columns
-            const bool interior = m0 + BM <= p.M && n0 + BN <= p.N;
+            const bool interior = !CONV && m0 + BM <= p.M && n0 + BN <= p.N;
+            if constexpr (CONV) {
+                // convolution rows: output row mo = m * c_row_mul + c_row_add, written only where its position inside the
+                // tp-row frame is a valid frame (halo rows stay zero); C and / or C2, the residual R[mo][r_ld] added first
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        wl[mfma32_row(r, lane) * LD + l31] = acc0[j][r] + acc1[j][r];
+                    const int n = n0 + (wn * TN + j) * 32 + c4;
+                    const bool nok = n < p.N;
+                    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (p.bias && nok) bias4 = *reinterpret_cast<const float4*>(p.bias + n);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int row = q * 8 + rl;
+                        const float4 t = *reinterpret_cast<const float4*>(wl + row * LD + c4);
+                        const int m = m0 + wm * 32 + row;
+                        if (m >= p.M || !nok) continue;
+                        const int mo = p.c_row_mul ? m * p.c_row_mul + p.c_row_add : m;
+                        if (p.tp) {
+                            const int pos = mo % p.tp;
+                            if (pos < p.t_lo || pos >= p.t_hi) continue;
+                        }
+                        float v[4] = {t.x + bias4.x, t.y + bias4.y, t.z + bias4.z, t.w + bias4.w};
+                        if constexpr (EPI == EPI_RESID) {
+                            const float4 x = *reinterpret_cast<const float4*>(p.R + (size_t)mo * (p.r_ld ? p.r_ld : p.ldc) + n);
+                            v[0] += x.x; v[1] += x.y; v[2] += x.z; v[3] += x.w;
+                        }
+                        if (p.C) *reinterpret_cast<float4*>(p.C + (size_t)mo * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+                        if (p.C2) *reinterpret_cast<float4*>(p.C2 + (size_t)mo * p.ldc2 + n) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                }
+                __syncthreads();
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
 #pragma unroll

@@ -28,6 +28,10 @@ int gemm_auto_tile(int M, int N);
 bool gemm_x6_supports(GemmKind kind, const GemmParams& p);
 hipError_t launch_gemm_x6(GemmKind kind, const GemmParams& p, hipStream_t stream, int variant = 0);
 hipError_t launch_pack_x6(const float* src, void* dst, int64_t rows, int cols, int64_t ld, hipStream_t stream);
+// 1-D convolution over tap-shifted fp32 rows with exact operands (GemmParams taps / a_row_mul / c_row_* / tp / t_* / C2 / r_ld;
+// the U-Net's bf16x6 mode, round 5).  Kinds: PLAIN, RESID.  variant 2 = the rotated K step, 0 = the compiler's schedule.
+bool gemm_x6_conv_supports(GemmKind kind, const GemmParams& p);
+hipError_t launch_gemm_x6_conv(GemmKind kind, const GemmParams& p, hipStream_t stream, int variant = 2);
 
 // ---- gemm_h3.hip (split-f16, fp32-equivalent) ---------------------------------------------------
 // epi: H3Epi; tile: 0 auto, 1 = 128x128 (2 stages), 2 = 256x128 8 waves (3 stages), 3 = same (2 stages),

@@ -32,7 +32,7 @@ sub = lambda n: importlib.import_module(f"{PKG}.{n}")
 dev = torch.device("cuda:0")
 MODES = ("f16x3", "bf16x6", "f32")
 WANTS = REPO / "tools" / "data" / "recon_chain_wants.npz"
-ENV_TAG = "".join(f" [{k}={v}]" for k, v in sorted(__import__("os").environ.items()) if k in ("CMDI_LN_FOLD_KEEP", "CMDI_LN_FOLD", "CMDI_GROUPS"))
+ENV_TAG = "".join(f" [{k}={v}]" for k, v in sorted(__import__("os").environ.items()) if k in ("CMDI_LN_FOLD_KEEP", "CMDI_LN_FOLD", "CMDI_GROUPS", "CMDI_STASH_F32"))
 PLAN = ((3, 20.0), (3, 0.0), (10, 20.0), (10, 0.0), (100, 20.0))
 f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
 tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
