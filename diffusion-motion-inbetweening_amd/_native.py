@@ -97,6 +97,7 @@ SIGNATURES = {
     "cmdi_gemm_nt": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _VP]),
     "cmdi_attention_fwd": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _VP]),
     "cmdi_conv_rows_h3": (C.c_int, [_VP, _I32, _VP, _VP, _VP, _VP, _VP] + [_I32] * 12 + [_VP]),
+    "cmdi_conv_rows_x6": (C.c_int, [_VP, _I32, _VP, _VP, _VP, _VP, _VP, _I32] + [_I32] * 12 + [_VP]),
     "cmdi_gemm_h3_ln": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _VP]),
     "cmdi_attention_fwd_h3": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _VP]),
     "cmdi_attention_vjp_h3": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _VP]),

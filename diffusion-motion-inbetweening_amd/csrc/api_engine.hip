@@ -31,18 +31,23 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
         // the temporal U-Net of unet.hip; the sampler / condition machinery is shared
         if (desc->d_model != 512 || desc->max_frames > 224 || desc->pe_rows < 1)
             return fail(CMDI_E_INVALID, "UNET engine: latent_dim must be 512, max_frames <= 224");
-        if (desc->precision == CMDI_PREC_F32 || desc->precision == CMDI_PREC_BF16X6)
-            return fail(CMDI_E_INVALID, "UNET engine: only the f16x3 precision is built (CMDI_PREC_F16X3 or CMDI_PREC_DEFAULT)");
-        if (desc->precision == CMDI_PREC_DEFAULT) {   // (an environment override naming a mode this arch does not have)
+        // precisions of this arch: f16x3 (default) and, round 5, bf16x6 — exact three-plane operands on every convolution, no
+        // f16 range limit: what a checkpoint whose activations pass 65,504 falls back to (the reference U-Net is plain fp32
+        // at any scale, model/mdm_unet.py:561-849).  The fp32-MFMA engine is not built for the U-Net.
+        int uprec = desc->precision;
+        if (uprec == CMDI_PREC_DEFAULT) {
             const char* v = std::getenv("CMDI_PRECISION");
             const std::string name = v ? v : "";
-            if (name == "f32" || name == "bf16x6")
-                return fail(CMDI_E_INVALID, "UNET engine: CMDI_PRECISION names a precision that is not built for this arch (f16x3 only)");
+            if (name == "f32")
+                return fail(CMDI_E_INVALID, "UNET engine: CMDI_PRECISION names a precision that is not built for this arch (f16x3, bf16x6)");
+            uprec = name == "bf16x6" ? CMDI_PREC_BF16X6 : CMDI_PREC_F16X3;
         }
+        if (uprec != CMDI_PREC_F16X3 && uprec != CMDI_PREC_BF16X6)
+            return fail(CMDI_E_INVALID, "UNET engine: the precisions built are CMDI_PREC_F16X3 (default) and CMDI_PREC_BF16X6");
         cmdi_engine* e = new cmdi_engine();
         e->desc = *desc;
         e->d = desc->d_model; e->C = desc->n_feats; e->Tmax = desc->max_frames; e->Bmax = desc->max_batch;
-        e->precision = CMDI_PREC_F16X3;
+        e->precision = uprec;
         *out = e;
         const int d = e->d;
         const size_t nseq = 2 * (size_t)e->Bmax;
@@ -66,7 +71,7 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
         ALLOC(e->gs_bits, 16);
         if (desc->want_grad) { ALLOC(e->gout, nseq * e->C * e->Tmax); ALLOC(e->gx, nseq * e->C * e->Tmax); }
         e->unet = unet_new(desc->n_feats, desc->unet_added, desc->d_model, desc->unet_mults, (int)nseq,
-                           desc->text_cond != 0, desc->want_grad != 0, desc->unet_attention != 0);
+                           desc->text_cond != 0, desc->want_grad != 0, desc->unet_attention != 0, uprec == CMDI_PREC_BF16X6);
         if (unet_error(e->unet)[0]) return fail(CMDI_E_INVALID, std::string("UNET: ") + unet_error(e->unet));
         e->bytes += unet_bytes(e->unet);
         e->pipelines = 0;

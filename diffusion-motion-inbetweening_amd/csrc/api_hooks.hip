@@ -201,6 +201,25 @@ int cmdi_conv_rows_h3(const void* d_a_split, int32_t a_ld, const void* d_w_split
     return CMDI_OK;
 }
 
+int cmdi_conv_rows_x6(const float* d_a, int32_t a_ld, const void* d_w_packed, const float* d_bias, const float* d_resid,
+                      float* d_c, float* d_c2, int32_t ldc2, int32_t m, int32_t n, int32_t cin, int32_t taps, int32_t pad,
+                      int32_t a_row_mul, int32_t c_row_mul, int32_t c_row_add, int32_t tp, int32_t t_lo, int32_t t_hi,
+                      int32_t variant, cmdi_stream stream) {
+    if (!d_a || !d_w_packed || (!d_c && !d_c2)) return fail(CMDI_E_INVALID, "null tensor");
+    if (cin % 32 != 0 || n % 4 != 0 || taps < 1 || a_ld < cin || a_ld % 4 != 0)
+        return fail(CMDI_E_INVALID, "cin must be a multiple of 32, n and a_ld multiples of 4, a_ld >= cin");
+    GemmParams p{};
+    p.A = d_a - (ptrdiff_t)pad * a_ld; p.lda = a_ld;
+    p.Wx = d_w_packed; p.bias = d_bias; p.R = d_resid;
+    p.C = d_c; p.ldc = n; p.C2 = d_c2; p.ldc2 = ldc2;
+    p.M = m; p.N = n; p.K = taps * cin; p.out_scale = 1.f;
+    p.taps = taps; p.a_row_mul = a_row_mul; p.c_row_mul = c_row_mul; p.c_row_add = c_row_add;
+    p.tp = tp; p.t_lo = t_lo; p.t_hi = t_hi;
+    hipError_t err = launch_gemm_x6_conv(d_resid ? GK_RESID : GK_PLAIN, p, static_cast<hipStream_t>(stream), variant);
+    if (err != hipSuccess) return fail(CMDI_E_HIP, std::string("launch_gemm_x6_conv: ") + hipGetErrorString(err));
+    return CMDI_OK;
+}
+
 int cmdi_gemm_h3_ln(const void* d_a_split, const void* d_w_split, const float* d_bias,
                     const float* d_resid, const float* d_gamma, const float* d_beta, float* d_y,
                     void* d_y_split, int32_t m, int32_t n, int32_t k, cmdi_stream stream) {
@@ -256,6 +275,32 @@ int cmdi_attention_vjp_h3(const void* d_qkv_split, const float* d_dout, void* d_
 }
 
 #ifdef CMDI_PROBES
+// probes library only (not in include/condmdi.h): one tensor of the last stashing forward pass's per-layer stash, copied to
+// the host (tools/recon_chain_error.py --stash-audit).  which: 0 stats1, 1 stats2 ([M][2] fp32), 2 pre1_f, 3 pre2_f, 4 attn_f
+// ([M][d] fp32, CMDI_STASH_F32 copies), 5 aux ([M][f]).  Returns the number of floats copied (<= max_floats), negative on error.
+int64_t cmdi_probe_read_stash(cmdi_handle e, int32_t layer, int32_t which, float* host_dst, int64_t max_floats) {
+    if (!e || !host_dst || layer < 0 || layer >= (int)e->stash.size()) return -1;
+    const LayerStash& st = e->stash[layer];
+    const int S = e->T + 1, n_seq = e->cfg ? 2 * e->B : e->B;
+    const int64_t M = (int64_t)n_seq * S;
+    const float* src = nullptr;
+    int64_t n = 0;
+    switch (which) {
+        case 0: src = st.stats1; n = 2 * M; break;
+        case 1: src = st.stats2; n = 2 * M; break;
+        case 2: src = st.pre1_f; n = M * e->d; break;
+        case 3: src = st.pre2_f; n = M * e->d; break;
+        case 4: src = st.attn_f; n = M * e->d; break;
+        case 5: src = st.aux; n = M * e->f; break;
+        case 6: src = reinterpret_cast<const float*>(st.qkvS); n = M * 3 * e->d; break;   // split rows: [M][6d] halves
+        case 7: src = st.row_stats; n = (int64_t)n_seq * e->H * S * 2; break;               // (max in ln units, 1 / sum)
+    }
+    if (!src || n > max_floats) return -2;
+    if (hipDeviceSynchronize() != hipSuccess) return -3;
+    if (hipMemcpy(host_dst, src, (size_t)n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return -3;
+    return n;
+}
+
 // probes library only (not in include/condmdi.h): cycle stamps of the attention backward kernels, [3][1024][24] int64
 int cmdi_probe_bwd_stamps(void* host_dst) {
     if (!host_dst) return fail(CMDI_E_INVALID, "null");

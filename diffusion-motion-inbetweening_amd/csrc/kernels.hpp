@@ -117,8 +117,9 @@ hipError_t launch_transpose_pad(float* dst, const float* src, int rows, int cols
 
 // ---- unet.hip: MDM_UNET denoiser ------------------------------------------------------------------
 struct UnetModel;
+// x6: CMDI_PREC_BF16X6 — fp32 activation rows, every convolution / gradient GEMM on gemm_x6's convolution form (exact operands)
 UnetModel* unet_new(int n_feats, int added, int dim, const int mults[4], int max_seq, bool text, bool want_grad,
-                    bool attention);
+                    bool attention, bool x6);
 const char* unet_error(const UnetModel* u);
 const char* unet_probe_route(const UnetModel* u);   // kernel family of the bench-probed convolution GEMM
 int64_t unet_bytes(const UnetModel* u);

@@ -37,13 +37,34 @@ constexpr int GUARD = 16;      // rows in front of / behind every row buffer (ta
 
 __device__ __forceinline__ float mish(float x) { return mish_f(x); }   // common.hpp: one exponential + one division
 
+// Activation rows travel in one of two formats, the same 4 * C bytes per row either way: split-f16 rows (f16x3: the GEMM
+// operand format of gemm_h3.hpp) or plain fp32 rows (x6 = 1, the bf16x6 mode of round 5: gemm_x6's convolution form splits its
+// fp32 A operand into three exact bf16 planes on the fly — no f16 range limit).  ys_ld is in halves in both cases.
+__device__ __forceinline__ void store_act4(_Float16* ys, size_t row, int ys_ld, int c, const float (&y)[4], int x6, bool& overflow) {
+    if (x6) {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(ys) + row * (size_t)(ys_ld >> 1) + c) = make_float4(y[0], y[1], y[2], y[3]);
+        return;
+    }
+    h4 oh, ol;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        _Float16 a, l;
+        split_f16(y[e], a, l);
+        oh[e] = a; ol[e] = l;
+        overflow |= !(fabsf(y[e]) < 65504.0f);
+    }
+    _Float16* d = ys + row * ys_ld + split_pos(c);
+    *reinterpret_cast<h4*>(d) = oh;
+    *reinterpret_cast<h4*>(d + 32) = ol;
+}
+
 // ---- input frames: x' = obs*m + x*(1-m), cat(x', m), zero channel padding; CFG: both passes get the same rows ----
 // x, obs [B, J, T] (T contiguous), mask u8 [B, J, T]; out split rows [nseq * Tp, 2*Cp].  A block transposes 16 frames of
 // one sequence through LDS: the reads run along T, the writes along the channels (both coalesced).
 constexpr int IN_FR = 16;
 __global__ __launch_bounds__(256) void unet_input_kernel(const float* __restrict__ x, const float* __restrict__ obs,
                                                          const uint8_t* __restrict__ mask, _Float16* __restrict__ out,
-                                                         int B, int J, int T, int Cp, int Tp, int h, int keyframe) {
+                                                         int B, int J, int T, int Cp, int Tp, int h, int keyframe, int x6) {
     extern __shared__ float tile[];                    // [Cp][IN_FR + 1]
     const int seq = blockIdx.y, b = seq % B;           // sequences: [cond B | uncond B]
     const int t0 = blockIdx.x * IN_FR;
@@ -66,6 +87,15 @@ __global__ __launch_bounds__(256) void unet_input_kernel(const float* __restrict
     for (int it = threadIdx.x; it < IN_FR * chunks; it += 256) {
         const int fr = it / chunks, c = (it - fr * chunks) * 8;
         if (t0 + fr >= TPAD) continue;
+        if (x6) {
+            float* df = reinterpret_cast<float*>(out) + ((size_t)seq * Tp + h + t0 + fr) * (size_t)Cp + c;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = tile[(c + e) * (IN_FR + 1) + fr];
+            *reinterpret_cast<float4*>(df) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(df + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            continue;
+        }
         h8 oh, ol;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -154,7 +184,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ ss, const float* __restrict__ resid,
                                                        float* __restrict__ yf, _Float16* __restrict__ ys, int ys_ld,
                                                        int* __restrict__ range_flag, int C, int Tp, int h, int Tv, int ss_ld,
-                                                       int nsl, size_t sl) {
+                                                       int nsl, size_t sl, int x6) {
     const int seq = blockIdx.y;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= Tv) return;
@@ -183,19 +213,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
             y[0] += r.x; y[1] += r.y; y[2] += r.z; y[3] += r.w;
         }
         if (yf) *reinterpret_cast<float4*>(yf + row * C + c) = make_float4(y[0], y[1], y[2], y[3]);
-        if (ys) {
-            h4 oh, ol;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                _Float16 a, l;
-                split_f16(y[e], a, l);
-                oh[e] = a; ol[e] = l;
-                overflow |= !(fabsf(y[e]) < 65504.0f);
-            }
-            _Float16* d = ys + row * ys_ld + split_pos(c);
-            *reinterpret_cast<h4*>(d) = oh;
-            *reinterpret_cast<h4*>(d + 32) = ol;
-        }
+        if (ys) store_act4(ys, row, ys_ld, c, y, x6, overflow);
     }
     if (overflow && range_flag) atomicOr(range_flag, 1);
 }
@@ -215,7 +233,7 @@ __global__ __launch_bounds__(NT) void gn_fused_kernel(const float* __restrict__ 
                                                        const float* __restrict__ ss, const float* __restrict__ resid,
                                                        float* __restrict__ yf, _Float16* __restrict__ ys, int ys_ld,
                                                        int* __restrict__ range_flag, int C, int Tp, int h, int Tv, int ss_ld,
-                                                       int nsl, size_t sl) {
+                                                       int nsl, size_t sl, int x6) {
     __shared__ float red[NT / 64];
     constexpr int MAXV = GNF_MAXV * 256 / NT;
     const int seq = blockIdx.x, g = blockIdx.y, cg = C / NG;
@@ -288,19 +306,7 @@ __global__ __launch_bounds__(NT) void gn_fused_kernel(const float* __restrict__ 
             y[0] += rr.x; y[1] += rr.y; y[2] += rr.z; y[3] += rr.w;
         }
         if (yf) *reinterpret_cast<float4*>(yf + row * C + c) = make_float4(y[0], y[1], y[2], y[3]);
-        if (ys) {
-            h4 oh, ol;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                _Float16 a, l;
-                split_f16(y[e], a, l);
-                oh[e] = a; ol[e] = l;
-                overflow |= !(fabsf(y[e]) < 65504.0f);
-            }
-            _Float16* d = ys + row * ys_ld + split_pos(c);
-            *reinterpret_cast<h4*>(d) = oh;
-            *reinterpret_cast<h4*>(d + 32) = ol;
-        }
+        if (ys) store_act4(ys, row, ys_ld, c, y, x6, overflow);
     }
     if (overflow && range_flag) atomicOr(range_flag, 1);
 }
@@ -373,7 +379,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
                                                            int nsl, size_t sl, const float* __restrict__ stats,
                                                            const float* __restrict__ sums, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ ss,
-                                                           int ss_ld, _Float16* __restrict__ out, int C, int Tp, int h, int Tv) {
+                                                           int ss_ld, _Float16* __restrict__ out, int C, int Tp, int h, int Tv, int x6) {
     const int seq = blockIdx.y;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= Tv) return;
@@ -394,16 +400,10 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
         const float4 sh = ss ? *reinterpret_cast<const float4*>(ss + (size_t)seq * ss_ld + C + c) : zero;
         float xh[4], gg[4];
         gn_bwd_terms(fv, dv, mean, rstd, ga, be, sc, sh, ss != nullptr, xh, gg);
-        h4 oh, ol;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            _Float16 a, l;
-            split_f16(rstd * (gg[e] - m1 - xh[e] * m2), a, l);
-            oh[e] = a; ol[e] = l;
-        }
-        _Float16* d = out + row * (2 * (size_t)C) + split_pos(c);
-        *reinterpret_cast<h4*>(d) = oh;
-        *reinterpret_cast<h4*>(d + 32) = ol;
+        const float dv4[4] = {rstd * (gg[0] - m1 - xh[0] * m2), rstd * (gg[1] - m1 - xh[1] * m2),
+                              rstd * (gg[2] - m1 - xh[2] * m2), rstd * (gg[3] - m1 - xh[3] * m2)};
+        bool unused = false;     // (gradients carry no range flag)
+        store_act4(out, row, 2 * C, c, dv4, x6, unused);
     }
 }
 
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
 // gradient scale (common.hpp grad_scale_from_bits) that parks the chain mid-range of f16
 __global__ __launch_bounds__(256) void unet_output_bwd_kernel(const float* __restrict__ gout, _Float16* __restrict__ rows,
                                                               const unsigned* __restrict__ gs_bits, int J, int T, int Np,
-                                                              int Tp, int h) {
+                                                              int Tp, int h, int x6) {
     const int seq = blockIdx.y;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= TPAD) return;
@@ -420,6 +420,7 @@ __global__ __launch_bounds__(256) void unet_output_bwd_kernel(const float* __res
     _Float16* row = rows + ((size_t)seq * Tp + h + t) * (2 * (size_t)Np);
     for (int c = lane; c < Np; c += 64) {
         const float v = (t < T && c < J) ? gout[((size_t)seq * J + c) * T + t] * gs : 0.f;
+        if (x6) { reinterpret_cast<float*>(rows)[((size_t)seq * Tp + h + t) * (size_t)Np + c] = v; continue; }
         _Float16 a, l;
         split_f16(v, a, l);
         row[split_pos(c)] = a;
@@ -556,6 +557,9 @@ struct UnetModel {
     ResBlock down[4][2], mid[2], up[3][2];
     Conv downs[3], ups[3], fin, outc;
     GN fin_n;
+    bool x6 = false;                            // CMDI_PREC_BF16X6 (round 5): activation rows are plain fp32, every convolution /
+                                                // gradient GEMM runs on gemm_x6's convolution form (exact operands, no f16 range);
+                                                // the weight buffers ws / ws2 / wb / wb2 then hold three bf16 planes (6 B per value)
     bool attention = false;                     // attention=True: the eight LinearAttention sites below
     AttnSite at_down[4], at_mid, at_up[3];
     _Float16 *AYS[4] = {}, *AOS[4] = {}, *AGS[4] = {};   // per level: LayerNorm output / d y (split), core output, d qkv (split)
@@ -619,17 +623,18 @@ int conv_alloc(UnetModel* u, Conv& c, int cin, int cout, int k, bool transposed 
     c.cin = cin; c.cin_p = (cin + 31) / 32 * 32; c.cout = cout; c.k = k; c.transposed = transposed;
     const size_t np = (size_t)(cout + 31) / 32 * 32;   // output columns are padded to whole 32-chunks: zero rows / bias
     const size_t kk = (size_t)(transposed ? 2 : k) * c.cin_p;
-    if (ualloc_t(u, &c.b, np) || ualloc_t(u, &c.ws, np * kk * 2)) return -1;
-    if (hipMemset(c.b, 0, np * sizeof(float)) != hipSuccess || hipMemset(c.ws, 0, np * kk * 2 * sizeof(_Float16)) != hipSuccess) {
+    const size_t hv = u->x6 ? 3 : 2;                    // 2-byte words per weight value: split-f16 (hi, lo) or three bf16 planes
+    if (ualloc_t(u, &c.b, np) || ualloc_t(u, &c.ws, np * kk * hv)) return -1;
+    if (hipMemset(c.b, 0, np * sizeof(float)) != hipSuccess || hipMemset(c.ws, 0, np * kk * hv * sizeof(_Float16)) != hipSuccess) {
         u->err = "hipMemset failed"; return -1;
     }
-    if (transposed && ualloc_t(u, &c.ws2, np * kk * 2)) return -1;
+    if (transposed && (ualloc_t(u, &c.ws2, np * kk * hv) || hipMemset(c.ws2, 0, np * kk * hv * sizeof(_Float16)) != hipSuccess)) return -1;
     c.cout_p = (int)np;
     if (u->want_grad) {   // [cin_p rows][taps_b * cout_p] split: conv k -> k taps; stride-2 conv -> 1 + 2; transposed -> 4
         const size_t rows = (size_t)c.cin_p;
         const size_t k1 = (size_t)(transposed ? 4 : (k == 3 ? 1 : k)) * np;
-        if (ualloc_t(u, &c.wb, rows * k1 * 2)) return -1;
-        if (!transposed && k == 3 && ualloc_t(u, &c.wb2, rows * 2 * np * 2)) return -1;
+        if (ualloc_t(u, &c.wb, rows * k1 * hv)) return -1;
+        if (!transposed && k == 3 && ualloc_t(u, &c.wb2, rows * 2 * np * hv)) return -1;
     }
     // the fp32 original is a transient allocation (freed by unet_finalize)
     if (hipMalloc(reinterpret_cast<void**>(&c.w), (size_t)cin * cout * k * sizeof(float)) != hipSuccess) {
@@ -689,7 +694,8 @@ hipError_t pack(UnetModel* u, Conv& c, hipStream_t s) {
         const int64_t n = (int64_t)n_rows * kk;
         hipLaunchKernelGGL(pack_conv_w_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c.w, tmp, c.cout,
                            c.cin, c.cin_p, c.k, c.transposed ? 1 + pass : 0);
-        e = launch_split_f16(tmp, pass ? c.ws2 : c.ws, n_rows, kk, kk, u->range_flag, s);
+        e = u->x6 ? launch_pack_x6(tmp, pass ? c.ws2 : c.ws, n_rows, kk, kk, s)
+                  : launch_split_f16(tmp, pass ? c.ws2 : c.ws, n_rows, kk, kk, u->range_flag, s);
         if (e != hipSuccess) break;
     }
     if (e == hipSuccess && c.wb) {
@@ -705,7 +711,8 @@ hipError_t pack(UnetModel* u, Conv& c, hipStream_t s) {
             if (e != hipSuccess) break;
             hipLaunchKernelGGL(pack_conv_wT_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c.w, tb, c.cout, c.cin,
                                c.cin_p, c.cout_p, c.k, mode);
-            e = launch_split_f16(tb, pass ? c.wb2 : c.wb, c.cin_p, (int)K, K, u->range_flag, s);
+            e = u->x6 ? launch_pack_x6(tb, pass ? c.wb2 : c.wb, c.cin_p, (int)K, K, s)
+                      : launch_split_f16(tb, pass ? c.wb2 : c.wb, c.cin_p, (int)K, K, u->range_flag, s);
             hipError_t e3 = hipStreamSynchronize(s);
             (void)hipFree(tb);
             if (e == hipSuccess) e = e3;
@@ -721,10 +728,11 @@ hipError_t pack(UnetModel* u, Conv& c, hipStream_t s) {
 }  // namespace
 
 UnetModel* unet_new(int n_feats, int added, int dim, const int mults[4], int max_seq, bool text, bool want_grad,
-                    bool attention) {
+                    bool attention, bool x6) {
     UnetModel* u = new UnetModel();
     u->J = n_feats; u->added = added; u->dim = dim; u->max_seq = max_seq; u->text = text; u->want_grad = want_grad;
-    u->attention = attention;
+    u->attention = attention; u->x6 = x6;
+    if (attention && x6) { u->err = "MDM_UNET with LinearAttention sites is built for the f16x3 precision only"; return u; }
 #ifdef CMDI_PROBES   // tuning knobs: probes build only
     if (const char* v = std::getenv("CMDI_UNET_KSPLIT")) u->ksplit_ok = std::atoi(v);
     if (const char* v = std::getenv("CMDI_UNET_TILE")) u->big_tile = std::atoi(v);
@@ -923,11 +931,37 @@ inline Lvl lvl(int l) { return {256 >> l, 16 >> l, TPAD >> l}; }
         }                                                                         \
     } while (0)
 
+// bf16x6 mode: the same convolution / gradient GEMM on gemm_x6's convolution form.  `a`, `out_s` are the activation buffers of
+// the f16x3 engine read as plain fp32 rows (same bytes per row: a_ld / cs_ld arrive in halves), `wx` the three-plane weights.
+int x6_rows(UnetModel* u, const _Float16* a, int a_ld, const void* wx, const float* bias, int M, int N, int K1, int taps, int pad,
+            int a_mul, int c_mul, int c_add, int level_out, float* out_f, int ldc, _Float16* out_s, int cs_ld, const float* resid,
+            int r_ld, hipStream_t s) {
+    const Lvl lo = lvl(level_out);
+    GemmParams p{};
+    p.lda = a_ld / 2;
+    p.A = reinterpret_cast<const float*>(a) - (ptrdiff_t)pad * p.lda;
+    p.Wx = wx; p.bias = bias;
+    p.M = M; p.N = N; p.K = taps * K1; p.ldc = ldc;
+    p.taps = taps; p.a_row_mul = a_mul; p.c_row_mul = c_mul; p.c_row_add = c_add;
+    p.tp = lo.Tp; p.t_lo = lo.h; p.t_hi = lo.h + lo.Tv;
+    p.C = out_f; p.C2 = reinterpret_cast<float*>(out_s); p.ldc2 = cs_ld / 2;
+    p.R = resid; p.r_ld = r_ld; p.out_scale = 1.f;
+    UCHK(launch_gemm_x6_conv(resid ? GK_RESID : GK_PLAIN, p, s, 2));
+    u->probe_route = "gemm_x6_kernel";
+    return 0;
+}
+
 // conv as GEMM over rows; `a` points at row 0 of the input frame buffer (column block already applied)
 int conv_rows(UnetModel* u, const Conv& c, const _Float16* ws, const _Float16* a, int a_ld, int m_rows, int level_out,
               int taps, int pad, int a_mul, int c_mul, int c_add, float* out_f, _Float16* out_s, int cs_ld,
               const float* resid, hipStream_t s, int* nsl_out = nullptr) {
     const Lvl lo = lvl(level_out);
+    if (u->x6) {
+        if (nsl_out) *nsl_out = 1;
+        const int N = (c.cout + 31) / 32 * 32;
+        return x6_rows(u, a, a_ld, ws, c.b, m_rows, N, c.cin_p, taps, pad, a_mul, c_mul, c_add, level_out, out_f, N, out_s, cs_ld,
+                       resid, 0, s);
+    }
     H3Params p{};
     p.A = a - (ptrdiff_t)pad * a_ld;
     p.W = ws; p.bias = c.b;
@@ -980,17 +1014,17 @@ int group_norm(UnetModel* u, const float* x, int nsl, const GN& n, const float* 
     if (u->gn_one_pass && L.Tv * (C / NG / 4) <= 256 * GNF_MAXV) {   // CMDI_UNET_GN1=0: the two kernels below
         if (u->gn_one_pass >= 2)   // 1,024 threads: 7 float4 per thread (another summation order than the 256-thread form)
             hipLaunchKernelGGL(gn_fused_kernel<1024>, dim3(nseq, NG), dim3(1024), 0, s, x, stats, n.g, n.b, ss, resid, yf, ys, ys_ld,
-                               u->range_flag, C, L.Tp, L.h, L.Tv, u->ss_ld, nsl, sl);
+                               u->range_flag, C, L.Tp, L.h, L.Tv, u->ss_ld, nsl, sl, u->x6 ? 1 : 0);
         else
             hipLaunchKernelGGL(gn_fused_kernel<256>, dim3(nseq, NG), dim3(256), 0, s, x, stats, n.g, n.b, ss, resid, yf, ys, ys_ld,
-                               u->range_flag, C, L.Tp, L.h, L.Tv, u->ss_ld, nsl, sl);
+                               u->range_flag, C, L.Tp, L.h, L.Tv, u->ss_ld, nsl, sl, u->x6 ? 1 : 0);
         UCHK(hipGetLastError());
         return 0;
     }
     if (!stats) stats = u->stats;                // (a stashing forward pass keeps them per GroupNorm)
     hipLaunchKernelGGL(gn_stats_kernel, dim3(nseq, NG), dim3(256), 0, s, x, stats, C, L.Tp, L.h, L.Tv, nsl, sl);
     hipLaunchKernelGGL(gn_apply_kernel, dim3((L.Tv + 3) / 4, nseq), dim3(256), 0, s, x, stats, n.g, n.b, ss, resid, yf,
-                       ys, ys_ld, u->range_flag, C, L.Tp, L.h, L.Tv, u->ss_ld, nsl, sl);
+                       ys, ys_ld, u->range_flag, C, L.Tp, L.h, L.Tv, u->ss_ld, nsl, sl, u->x6 ? 1 : 0);
     UCHK(hipGetLastError());
     return 0;
 }
@@ -1000,7 +1034,7 @@ int group_norm(UnetModel* u, const float* x, int nsl, const GN& n, const float* 
 // forward pass (the backward needs the pre-GroupNorm values) nor where split-K applies (levels 2, 3).
 bool fused_gn_ok(const UnetModel* u, int level, bool keep) {
     const int cg = u->C[1] / NG;
-    return ((u->fuse_gn >> level) & 1) && !keep && level <= 1 && (cg == 128 || cg == 64);
+    return !u->x6 && ((u->fuse_gn >> level) & 1) && !keep && level <= 1 && (cg == 128 || cg == 64);
 }
 int conv_gn_rows(UnetModel* u, const Conv& c, const GN& n, const _Float16* a, int a_ld, int m_rows, int level,
                  const float* ss, const float* resid, float* out_f, _Float16* out_s, int cs_ld, hipStream_t s) {
@@ -1081,6 +1115,11 @@ int grad_gemm(UnetModel* u, const _Float16* a, int a_ld, const _Float16* w, int 
               int a_mul, int c_mul, int c_add, int level_out, float* out_f, int ldc, _Float16* out_s, int cs_ld,
               const float* resid, int r_ld, hipStream_t s, int* nsl_out = nullptr) {
     const Lvl lo = lvl(level_out);
+    if (u->x6) {
+        if (nsl_out) *nsl_out = 1;
+        return x6_rows(u, a, a_ld, w, nullptr, M, N, K1, taps, pad, a_mul, c_mul, c_add, level_out, out_f, ldc, out_s, cs_ld, resid,
+                       r_ld, s);
+    }
     H3Params p{};
     p.A = a - (ptrdiff_t)pad * a_ld;
     p.W = w;
@@ -1116,7 +1155,7 @@ int gn_bwd(UnetModel* u, const float* dy, int ld_dy, const float* f, int nsl, co
     hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(nseq, NG, GNB_CHUNKS), dim3(256), 0, s, dy, ld_dy, nsl_dy, sl, f, nsl, sl, stats,
                        n.g, n.b, ss, u->ss_ld, u->bsums, C, L.Tp, L.h, L.Tv);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((L.Tv + 3) / 4, nseq), dim3(256), 0, s, dy, ld_dy, nsl_dy, sl, f, nsl, sl, stats, u->bsums,
-                       n.g, n.b, ss, u->ss_ld, u->GS[level], C, L.Tp, L.h, L.Tv);
+                       n.g, n.b, ss, u->ss_ld, u->GS[level], C, L.Tp, L.h, L.Tv, u->x6 ? 1 : 0);
     UCHK(hipGetLastError());
     return 0;
 }
@@ -1206,7 +1245,7 @@ int unet_forward(UnetModel* u, const float* x, const float* obs, const uint8_t* 
         UCHK(launch_gemm(GK_PLAIN, r, 4, s));
     }
     hipLaunchKernelGGL(unet_input_kernel, dim3(TPAD / IN_FR, nseq), dim3(256), (size_t)u->Cin0p * (IN_FR + 1) * sizeof(float), s,
-                       x, obs, mask, u->in0S, B, u->J, T, u->Cin0p, 256, 16, u->added ? 1 : 0);
+                       x, obs, mask, u->in0S, B, u->J, T, u->Cin0p, 256, 16, u->added ? 1 : 0, u->x6 ? 1 : 0);
     UCHK(hipGetLastError());
 
     // ---- down path: the second block of each level is the skip (h.append(x)) and feeds the downsample ----
@@ -1285,7 +1324,7 @@ int unet_backward(UnetModel* u, const float* gout, const uint8_t* mask, const un
     const int Cw = u->C[1];
     auto rows = [&](int l) { return nseq * lvl(l).Tp; };
     hipLaunchKernelGGL(unet_output_bwd_kernel, dim3(TPAD / 4, nseq), dim3(256), 0, s, gout, u->gOutS, gs_bits, u->J, T, u->Np,
-                       256, 16);
+                       256, 16, u->x6 ? 1 : 0);
     UCHK(hipGetLastError());
     // final_conv.1 (1x1) and final_conv.0 (Conv5 -> GN -> Mish): d Sa0 as split rows (the upsampled frames of ups.2)
     if (grad_gemm(u, u->gOutS, 2 * u->Np, u->outc.wb, rows(0), Cw, u->Np, 1, 0, 1, 0, 0, 0, u->GA[0], Cw, nullptr, 0, nullptr, 0, s))

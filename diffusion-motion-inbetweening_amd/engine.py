@@ -103,8 +103,8 @@ class Engine:
                              "(the reference raises at pe[timesteps], model/mdm.py:352)")
         if flag.value & 1 and self.precision == "f16x3":
             what = "an activation left the f16 range (|x| >= 65504 or non-finite) in the split-f16 GEMM path: results are invalid; "
-            if self.arch == "unet":
-                raise N.RangeError(what + "the MDM_UNET engine is built for f16x3 only (no bf16x6 / f32 mode to fall back to): "
+            if self.arch == "unet" and self.desc.unet_attention:
+                raise N.RangeError(what + "MDM_UNET(attention=True) is built for f16x3 only (no bf16x6 mode to fall back to): "
                                           "check the checkpoint and the normalisation of the inputs")
             raise N.RangeError(what + "re-run with precision='bf16x6' (CMDI_PRECISION=bf16x6)")
 

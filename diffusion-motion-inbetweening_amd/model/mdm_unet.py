@@ -179,6 +179,7 @@ class MDM_UNET(nn.Module):
     _weights_key = MDM._weights_key
     invalidate_engine = MDM.invalidate_engine
     check_range = MDM.check_range
+    range_fallback = MDM.range_fallback     # after a RangeError of the default (f16x3) engine: bf16x6 for good (round 5)
 
     def engine(self, device, max_batch, max_frames, want_grad=False, n_time_rows=1000):
         """The native engine holding this module's weights on `device` (built / grown lazily)."""
@@ -189,20 +190,45 @@ class MDM_UNET(nn.Module):
         pe_rows = self.sequence_pos_encoder.pe.shape[0]
         n_time_rows = pe_rows   # one table for forward calls and every respacing (see MDM.engine)
         eng = self._engine
+        # precisions of the native U-Net: 'f16x3' (library default; 22-bit split operands, |x| < 65504) and 'bf16x6' (exact
+        # three-plane operands on every convolution, fp32's range — the reference U-Net is plain fp32 at any activation scale,
+        # model/mdm_unet.py:561-849).  As MDM.engine: None = the default, which falls back to bf16x6 when a weight (here) or an
+        # activation (GaussianDiffusion._range_probe / _with_range_fallback) leaves the f16 range; a pinned precision raises.
+        precision = getattr(self, "native_precision", None)
+        if precision is None and getattr(self, "_range_fallback", False):
+            precision = "bf16x6"
+        if precision == "bf16x6" and self.attention:
+            raise N.NativeError("MDM_UNET(attention=True) is built for the f16x3 precision only")
         need_new = (eng is None or eng.device != device or eng.max_batch < max_batch or eng.max_frames < max_frames
-                    or (want_grad and not eng.want_grad) or self._engine_key != self._weights_key(n_time_rows))
+                    or (want_grad and not eng.want_grad) or (precision is not None and eng.precision != precision)
+                    or self._engine_key != self._weights_key(n_time_rows))
         if need_new:
             if eng is not None:
                 max_batch, max_frames = max(max_batch, eng.max_batch), max(max_frames, eng.max_frames)
                 want_grad = want_grad or eng.want_grad
                 eng.close()
-            eng = Engine(n_layers=0, d_model=self.latent_dim, d_ff=0, n_heads=0, n_feats=self.input_feats,
-                         max_frames=max_frames, max_batch=max_batch, pe_rows=pe_rows,
-                         text_cond='text' in self.cond_mode, want_grad=want_grad, arch="unet",
-                         unet_added=self.added_channels, unet_mults=self.dim_mults, unet_attention=self.attention,
-                         device=device)
             sd = {k: v for k, v in self.state_dict().items() if not k.startswith('clip_model.')}
-            eng.load_state_dict(sd, n_time_rows=n_time_rows)
+
+            def build(prec):
+                e = Engine(n_layers=0, d_model=self.latent_dim, d_ff=0, n_heads=0, n_feats=self.input_feats,
+                           max_frames=max_frames, max_batch=max_batch, pe_rows=pe_rows,
+                           text_cond='text' in self.cond_mode, want_grad=want_grad, precision=prec, arch="unet",
+                           unet_added=self.added_channels, unet_mults=self.dim_mults, unet_attention=self.attention,
+                           device=device)
+                try:
+                    e.load_state_dict(sd, n_time_rows=n_time_rows)
+                except Exception:
+                    e.close()
+                    raise
+                return e
+
+            try:
+                eng = build(precision)
+            except N.RangeError:
+                if precision is not None or self.attention:
+                    raise              # pinned to f16x3 (or no wider mode for this geometry): report, do not switch silently
+                self._range_fallback = True
+                eng = build("bf16x6")  # a weight beyond the f16 range
             self._engine = eng
             self._engine_key = self._weights_key(n_time_rows)
         return eng

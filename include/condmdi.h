@@ -252,13 +252,13 @@ int cmdi_clip_encode_text(cmdi_clip_handle h, const int32_t* d_tokens, int32_t b
 int cmdi_gemm_nt(const float* d_a, const float* d_w, const float* d_bias, const float* d_resid,
                  float* d_c, int32_t m, int32_t n, int32_t k, int32_t epi, int32_t tile,
                  cmdi_stream stream);
-/* The precision the handle runs at (CMDI_PREC_F32, CMDI_PREC_F16X3 or CMDI_PREC_BF16X6; a CMDI_ARCH_UNET handle is always
- * CMDI_PREC_F16X3 — creating one with another precision fails). */
+/* The precision the handle runs at (CMDI_PREC_F32, CMDI_PREC_F16X3 or CMDI_PREC_BF16X6; a CMDI_ARCH_UNET handle is
+ * CMDI_PREC_F16X3 or, since round 5, CMDI_PREC_BF16X6 — the fp32-MFMA engine is not built for that architecture). */
 int cmdi_precision(cmdi_handle h);
 /* Status bits raised on the device since the last call (cleared by it):
  *   bit 0 (F16X3 only): an activation left the f16 range (|x| >= 65504 or non-finite) while being split; the results
  *         of that run are invalid and the caller should re-run on an engine created with CMDI_PREC_BF16X6 (exact operands,
- *         fp32's exponent range; or CMDI_PREC_F32).  CMDI_ARCH_UNET has no such mode: there the inputs must be rescaled;
+ *         fp32's exponent range; or CMDI_PREC_F32).  CMDI_ARCH_UNET: CMDI_PREC_BF16X6 likewise (unet_attention = 0);
  *   bit 1: a timestep outside [0, n_time_rows) reached the time-embedding lookup (the reference raises IndexError
  *         at pe[timesteps], model/mdm.py:352); the row was clamped.
  * SYNCHRONISES `stream` (one 4-byte read-back); call it once per sampling chain, not per step. */
@@ -300,6 +300,15 @@ int cmdi_conv_rows_h3(const void* d_a_split, int32_t a_ld, const void* d_w_split
                       const float* d_resid, float* d_c, void* d_c_split, int32_t m, int32_t n, int32_t cin,
                       int32_t taps, int32_t pad, int32_t a_row_mul, int32_t c_row_mul, int32_t c_row_add,
                       int32_t tp, int32_t t_lo, int32_t t_hi, int32_t tile, cmdi_stream stream);
+/* The same convolution over token rows with EXACT operands (bf16x6, round 5: the U-Net's CMDI_PREC_BF16X6 mode; replaces
+ * torch Conv1d / ConvTranspose1d of the reference's plain-fp32 U-Net at any activation scale, model/mdm_unet.py:15-99,561-849):
+ * activations are plain fp32 rows [.., a_ld floats], weights cmdi_pack_x6 of the [n, taps * cin] matrix in the chunk-major K
+ * order of cmdi_conv_rows_h3; row / frame arguments as there.  The result (+ d_resid[row][n] when given) goes to d_c [.., n]
+ * and / or d_c2 [.., ldc2] (fp32 both).  variant: 2 = the rotated K step of gemm_x6.hpp, 0 = the compiler's schedule. */
+int cmdi_conv_rows_x6(const float* d_a, int32_t a_ld, const void* d_w_packed, const float* d_bias, const float* d_resid,
+                      float* d_c, float* d_c2, int32_t ldc2, int32_t m, int32_t n, int32_t cin, int32_t taps, int32_t pad,
+                      int32_t a_row_mul, int32_t c_row_mul, int32_t c_row_add, int32_t tp, int32_t t_lo, int32_t t_hi,
+                      int32_t variant, cmdi_stream stream);
 /* Y = LayerNorm((A · W^T + bias) + resid; gamma, beta, eps 1e-5) with the normalisation fused into the
  * GEMM epilogue (N must be 512 = d_model); d_y fp32 [M,N], d_y_split optional split rows [M,2N]. */
 int cmdi_gemm_h3_ln(const void* d_a_split, const void* d_w_split, const float* d_bias,

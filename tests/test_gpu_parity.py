@@ -1360,6 +1360,62 @@ def test_conv_rows_h3_vs_torch(kind):
     assert ok("conv_rows_h3_vs_torch.rel_l2.0", rel_l2(got.numpy(), want.numpy()), 2e-6), rel_l2(got.numpy(), want.numpy())
 
 
+@pytest.mark.parametrize("variant", [2, 0])
+@pytest.mark.parametrize("kind", ["k5", "k1", "down", "up"])
+def test_conv_rows_x6_vs_torch(kind, variant):
+    """The U-Net's bf16x6 mode (round 5): conv1d (k=5 pad 2; k=1), the stride-2 convolution and ConvTranspose1d as gemm_x6
+    GEMMs over tap-shifted fp32 rows (cmdi_conv_rows_x6: exact three-plane operands) vs torch in float64 — inputs scaled to
+    3e5, beyond the f16 range the split-f16 form of the same convolutions is limited to; residual + second output covered."""
+    eng, N = sub("engine"), sub("_native")
+    lib = N.load()
+    g = torch.Generator().manual_seed(len(kind) * 7 + variant)
+    B, cin, cout = 3, 64, 96
+    T_in, h_in = (56, 4)
+    x = torch.randn(B, cin, T_in, generator=g) * 3e5
+    if kind in ("k5", "k1"):
+        k, T_out, h_out = (5 if kind == "k5" else 1), T_in, h_in
+        w = torch.randn(cout, cin, k, generator=g) * 0.1
+        ref = torch.nn.functional.conv1d(x.double(), w.double(), padding=k // 2)
+        wg = [w.permute(0, 2, 1).reshape(cout, k * cin)]
+        launches = [dict(taps=k, pad=k // 2, a_mul=1, c_mul=0, c_add=0)]
+    elif kind == "down":
+        T_out, h_out = T_in // 2, h_in // 2
+        w = torch.randn(cout, cin, 3, generator=g) * 0.1
+        ref = torch.nn.functional.conv1d(x.double(), w.double(), stride=2, padding=1)
+        wg = [w.permute(0, 2, 1).reshape(cout, 3 * cin)]
+        launches = [dict(taps=3, pad=1, a_mul=2, c_mul=0, c_add=0)]
+    else:
+        T_out, h_out = T_in * 2, h_in * 2
+        w = torch.randn(cin, cout, 4, generator=g) * 0.1
+        ref = torch.nn.functional.conv_transpose1d(x.double(), w.double(), stride=2, padding=1)
+        wg = [torch.cat([w[:, :, 3].T, w[:, :, 1].T], dim=1), torch.cat([w[:, :, 2].T, w[:, :, 0].T], dim=1)]
+        launches = [dict(taps=2, pad=1, a_mul=1, c_mul=2, c_add=0), dict(taps=2, pad=0, a_mul=1, c_mul=2, c_add=1)]
+    bias = torch.randn(cout, generator=g) * 1e4
+    tp_in, tp_out = T_in + 2 * h_in, T_out + 2 * h_out
+    guard = 8
+    rows = torch.zeros(guard + B * tp_in + guard, cin)
+    for b in range(B):
+        rows[guard + b * tp_in + h_in: guard + b * tp_in + h_in + T_in] = x[b].T
+    a = rows.to(DEV)
+    resid = (torch.randn(B * tp_out, cout, generator=g) * 1e5).to(DEV)
+    out = torch.zeros(B * tp_out, cout, device=DEV)
+    out2 = torch.zeros(B * tp_out, 2 * cout, device=DEV)            # second output with its own row stride (the skip's concat slot)
+    m_gemm = B * tp_in if kind == "up" else B * tp_out
+    for wmat, L in zip(wg, launches):
+        w_p = eng.pack_x6(eng.conv_weight_k_order(wmat.contiguous(), L["taps"]).to(DEV))
+        with torch.cuda.device(DEV):
+            N.check(lib.cmdi_conv_rows_x6(a.data_ptr() + guard * cin * 4, cin, N.ptr(w_p), N.ptr(bias.to(DEV)), N.ptr(resid), N.ptr(out),
+                                          out2.data_ptr() + cout * 4, 2 * cout, m_gemm, cout, cin, L["taps"], L["pad"], L["a_mul"],
+                                          L["c_mul"], L["c_add"], tp_out, h_out, h_out + T_out, variant,
+                                          N.current_stream(torch.device(DEV))))
+    got = out.cpu().view(B, tp_out, cout)
+    assert float(got[:, :h_out].abs().max()) == 0.0 and float(got[:, h_out + T_out:].abs().max()) == 0.0  # halo rows untouched
+    assert torch.equal(out2[:, cout:].cpu().view(B, tp_out, cout), got) and float(out2[:, :cout].abs().max()) == 0.0
+    got = got[:, h_out:h_out + T_out].permute(0, 2, 1)
+    want = ref + bias.double()[None, :, None] + resid.cpu().double().view(B, tp_out, cout)[:, h_out:h_out + T_out].permute(0, 2, 1)
+    assert ok("conv_rows_x6_vs_torch.rel_l2", rel_l2(got.numpy(), want.numpy()), 2e-6), rel_l2(got.numpy(), want.numpy())
+
+
 @pytest.mark.parametrize("kind", ["k5", "down", "up", "k1"])
 def test_conv_rows_persistent_is_bitwise_the_tiled_kernel(kind):
     """Round 4: the U-Net's long-K convolutions run on the persistent GEMM (gemm_h3p.hpp with tap-shifted A requests and the
@@ -1433,7 +1489,10 @@ def test_conv_rows_persistent_refuses_what_it_does_not_compute():
 
 
 # ---- MDM_UNET denoiser -------------------------------------------------------------
-def make_unet(cases):
+UNET_PRECISIONS = ["f16x3", "bf16x6"]     # the native U-Net's arithmetic modes (bf16x6: round 5, exact operands, no f16 range limit)
+
+
+def make_unet(cases, precision=None):
     mu = sub("utils.model_util")
     case = cases.UNET_CASE
     args = SimpleNamespace(dataset="humanml", arch="unet", keyframe_conditioned=True, dim_mults=case["dim_mults"],
@@ -1444,18 +1503,21 @@ def make_unet(cases):
     assert sorted(shapes) == list(g["names"]), "state-dict names differ from the reference's MDM_UNET"
     mu.load_model_wo_clip(model, weights.to_torch(weights.fill_like(shapes, case["weight_seed"])) |
                           {k: v for k, v in model.state_dict().items() if k.endswith(".pe")})
+    model.native_precision = precision
     return model.to(DEV).eval(), g
 
 
-def test_unet_forward_vs_reference(cases):
+@pytest.mark.parametrize("precision", UNET_PRECISIONS)
+def test_unet_forward_vs_reference(cases, precision):
     """MDM_UNET (keyframe-conditioned, text, CFG) on the device vs the real reference's CPU outputs."""
     inp = cases.make_unet_inputs()
-    model, g = make_unet(cases)
+    model, g = make_unet(cases, precision)
     assert np.array_equal(g["fingerprint"], cases.fingerprint(inp))
     x, t = tt(inp["x"]), tt(inp["t"])
     kw = dict(obs_x0=tt(inp["obs_x0"]), obs_mask=tt(inp["obs_mask"]))
     y = {"text_embed": tt(inp["enc_text"])}
     oc = model(x, t, y=y, **kw).cpu().numpy()
+    assert model._engine.precision == precision
     assert np.array_equal(oc, model(x, t, y=y, **kw).cpu().numpy())   # split-K accumulation is order-independent
     ou = model(x, t, y=dict(y, uncond=True), **kw).cpu().numpy()
     wrapped = sub("model.cfg_sampler").ClassifierFreeSampleModel(model)
@@ -1466,11 +1528,12 @@ def test_unet_forward_vs_reference(cases):
             (key, max_abs(mine, g[key]), rel_l2(mine, g[key]))
 
 
+@pytest.mark.parametrize("precision", UNET_PRECISIONS)
 @pytest.mark.parametrize("B,T", [(3, 100), (1, 224), (2, 17)])
-def test_unet_vs_oracle_other_shapes(cases, B, T):
+def test_unet_vs_oracle_other_shapes(cases, B, T, precision):
     """Frame counts other than the golden 196 (right-padded to 224 inside the model) vs the numpy oracle."""
     from oracle.unet_oracle import UnetOracle
-    model, _ = make_unet(cases)
+    model, _ = make_unet(cases, precision)
     sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
     rng = np.random.default_rng(1000 + 7 * B + T)
     shape = (B, 263, 1, T)
@@ -1486,14 +1549,15 @@ def test_unet_vs_oracle_other_shapes(cases, B, T):
     assert ok("unet_vs_oracle_other_shapes.max_abs.0", max_abs(got, want), 2e-4) and ok("unet_vs_oracle_other_shapes.rel_l2.0", rel_l2(got, want), 2e-5), (max_abs(got, want), rel_l2(got, want))
 
 
-def test_unet_chain_vs_reference(cases):
+@pytest.mark.parametrize("precision", UNET_PRECISIONS)
+def test_unet_chain_vs_reference(cases, precision):
     """The conditional_synthesis.py call (p_sample_loop, CFG wrapper, obs_x0 / obs_mask, imputation) with the
     native MDM_UNET vs the real reference's chain on the same injected noise."""
     cc = cases.UNET_CHAIN
     ci = cases.make_unet_chain_inputs()
     g = load_golden("unet_chain")
     assert np.array_equal(g["fingerprint"], cases.fingerprint(ci))
-    model, _ = make_unet(cases)
+    model, _ = make_unet(cases, precision)
     wrapped = sub("model.cfg_sampler").ClassifierFreeSampleModel(model)
     diffusion = make_diffusion(cc["respacing"])
     obs_mask = tt(ci["obs_mask"])
@@ -1507,13 +1571,14 @@ def test_unet_chain_vs_reference(cases):
     assert ok("unet_chain_vs_reference.rel_l2.0", rel_l2(final, g["final"]), 1e-4), rel_l2(final, g["final"])
 
 
-def test_unet_vjp_vs_reference_autograd(cases):
+@pytest.mark.parametrize("precision", UNET_PRECISIONS)
+def test_unet_vjp_vs_reference_autograd(cases, precision):
     """Input-VJP of ClassifierFreeSampleModel(MDM_UNET) (unet.hip::unet_backward) vs torch autograd through the real
     reference on CPU; also reached through torch.autograd.grad on the native module, and linear in gout over 21 decades."""
     vi = cases.make_unet_vjp_inputs()
     g = load_golden("unet_vjp")
     assert np.array_equal(g["fingerprint"], cases.fingerprint(vi))
-    model, _ = make_unet(cases)
+    model, _ = make_unet(cases, precision)
     wrapped = sub("model.cfg_sampler").ClassifierFreeSampleModel(model)
     y = {"text_embed": tt(vi["enc_text"]), "text_scale": tt(vi["text_scale"])}
     kw = dict(obs_x0=tt(vi["obs_x0"]), obs_mask=tt(vi["obs_mask"]))
@@ -1543,6 +1608,7 @@ def make_unet_attention(cases):
     assert sorted(shapes) == list(g["names"]), "state-dict names differ from the reference's MDM_UNET(attention=True)"
     mu.load_model_wo_clip(model, weights.to_torch(weights.fill_like(shapes, case["weight_seed"])) |
                           {k: v for k, v in model.state_dict().items() if k.endswith(".pe")})
+    model.native_precision = precision
     return model.to(DEV).eval(), g
 
 
@@ -1628,14 +1694,18 @@ def test_unet_groupnorm_one_pass_is_the_two_kernel_groupnorm(cases, monkeypatch)
     assert ok("unet_groupnorm_one_pass.rel_l2", rel_l2(outs["2"], g["out_cfg"]), 2e-5)
 
 
-@pytest.mark.parametrize("scale,expect", [(4000.0, "ok"), (60000.0, "range")])
+@pytest.mark.parametrize("scale,expect", [(4000.0, "f16x3"), (60000.0, "bf16x6"), (60000.0, "pinned")])
 def test_unet_real_scale_activations_and_range_probe(cases, scale, expect, monkeypatch):
-    """MDM_UNET is f16x3-only (the reference's U-Net is plain fp32 anywhere, model/mdm_unet.py:561-849).  Its range story
-    (VERDICT r3 task 2): activations far above the synthetic-weight scale stay exact to the usual tolerance — here the first
-    block's residual 1x1 convolution is scaled so that the block's output (a split-f16 operand of the next convolution) reaches
-    ~1e4 — and activations that DO leave the f16 range (the same weights x 15) are reported by the pre-chain probe: a RangeError that names the cause BEFORE the first of the chain's steps is
-    spent (rounds 1-3: after the last one), never a silent wrong sample."""
+    """MDM_UNET's range story.  The reference's U-Net is plain fp32 at any activation scale (model/mdm_unet.py:561-849); the
+    native default (f16x3) carries operands as split f16, |x| < 65504.  (1) Activations far above the synthetic-weight scale
+    stay exact to the usual tolerance on f16x3 — the first block's residual 1x1 convolution is scaled so that the block's
+    output (an operand of the next convolution) reaches ~1e4.  (2) Round 5 (VERDICT r4 task 4): activations that DO leave the
+    f16 range (the same weights x 15: ~1e5) no longer strand the checkpoint — the pre-chain probe sends the chain to the
+    bf16x6 engine (every convolution on gemm_x6: exact three-plane operands, fp32's range) BEFORE its first step, and both the
+    forward value and the chain's sample are within the tolerance of the float64-checked oracle.  (3) An engine PINNED to
+    f16x3 still refuses — a RangeError that names the cause before any step is spent, never a silent wrong sample."""
     from oracle.unet_oracle import UnetOracle
+    from oracle import diffusion_oracle as do
     N = sub("_native")
     mu = sub("utils.model_util")
     case = cases.UNET_CASE
@@ -1649,6 +1719,8 @@ def test_unet_real_scale_activations_and_range_probe(cases, scale, expect, monke
     sd[first] = sd[first] * np.float32(scale)
     mu.load_model_wo_clip(model, weights.to_torch(sd) | {k: v for k, v in model.state_dict().items() if k.endswith(".pe")})
     model = model.to(DEV).eval()
+    if expect == "pinned":
+        model.native_precision = "f16x3"
     wrapped = sub("model.cfg_sampler").ClassifierFreeSampleModel(model)
     B, T = 2, 64
     rng = np.random.default_rng(92)
@@ -1658,29 +1730,50 @@ def test_unet_real_scale_activations_and_range_probe(cases, scale, expect, monke
     m = rng.random(shape) < 0.2
     enc = rng.standard_normal((B, 512)).astype(np.float32)
     sc = np.full(B, 2.5, np.float32)
-    if expect == "ok":
-        t = rng.integers(0, 1000, B)
-        full = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
-        want, _, _ = UnetOracle(full).forward_cfg(x, t, enc, sc, obs, m)
-        got = wrapped(tt(x), tt(t), y={"text_embed": tt(enc), "text_scale": tt(sc)}, obs_x0=tt(obs), obs_mask=tt(m)).cpu().numpy()
+    t = rng.integers(0, 1000, B)
+    full = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    oracle = UnetOracle(full)
+    want, _, _ = oracle.forward_cfg(x, t, enc, sc, obs, m)
+    call = lambda: wrapped(tt(x), tt(t), y={"text_embed": tt(enc), "text_scale": tt(sc)}, obs_x0=tt(obs), obs_mask=tt(m)).cpu().numpy()
+    if expect == "f16x3":
+        got = call()
         model.check_range()
-        assert ok("unet_real_scale.rel_l2", rel_l2(got, want), 2e-5), rel_l2(got, want)
+        assert model._engine.precision == "f16x3"
+        assert ok("unet_real_scale.rel_l2", rel_l2(got, want), 2e-5, precision="f16x3"), rel_l2(got, want)
         return
-    gd = sub("diffusion.gaussian_diffusion")
-    diffusion = make_diffusion([60])      # >= RANGE_PROBE_MIN_STEPS: the probe runs
+    # ---- activations beyond the f16 range -------------------------------------------------------------------------------
+    n_steps = 60                          # >= RANGE_PROBE_MIN_STEPS: the probe runs
+    diffusion = make_diffusion([n_steps])
     calls = []
     eng_cls = sub("engine").Engine
     real = eng_cls.sample_loop
-    monkeypatch.setattr(eng_cls, "sample_loop", lambda self, *a, **k: (calls.append(1), real(self, *a, **k))[1])
+    monkeypatch.setattr(eng_cls, "sample_loop", lambda self, *a, **k: (calls.append(self.precision), real(self, *a, **k))[1])
     y = {"mask": torch.ones(B, 1, 1, T, dtype=torch.bool, device=DEV), "lengths": torch.full((B,), T),
          "text_embed": tt(enc), "text_scale": tt(sc)}
-    with pytest.raises(N.RangeError, match="MDM_UNET engine is built for f16x3 only"):
-        diffusion.p_sample_loop(wrapped, shape, noise=tt(x), clip_denoised=False,
-                                model_kwargs={"y": y, "obs_x0": tt(obs), "obs_mask": tt(m)})
-    assert not calls, "the chain was started although the probe evaluation left the f16 range"
+    noise = rng.standard_normal((n_steps + 1,) + shape).astype(np.float32)
+    diffusion.injected_noise = tt(noise[1:])
+    run = lambda: diffusion.p_sample_loop(wrapped, shape, noise=tt(noise[0]), clip_denoised=False,
+                                          model_kwargs={"y": y, "obs_x0": tt(obs), "obs_mask": tt(m)})
+    if expect == "pinned":
+        with pytest.raises(N.RangeError, match="left the f16 range"):
+            run()
+        assert not calls, "the chain was started although the probe evaluation left the f16 range"
+        return
+    final = run().cpu().numpy()
+    assert calls == ["bf16x6"], calls            # the probe switched BEFORE the chain; no f16x3 step was spent
+    assert model._engine.precision == "bf16x6" and np.isfinite(final).all()
+    got = call()                                 # the module stays on the unrestricted mode
+    assert ok("unet_real_scale.rel_l2", rel_l2(got, want), 2e-5, precision="bf16x6"), rel_l2(got, want)
+    sch = do.Schedule(do.named_betas("cosine", 1000), do.space_timesteps(1000, [n_steps]))
+    xo = noise[0]
+    for k, i in enumerate(range(n_steps - 1, -1, -1)):
+        hat, _, _ = oracle.forward_cfg(xo, np.full(B, sch.timestep_map[i]), enc, sc, obs, m)
+        xo, _ = do.step_update(sch, i, xo, hat, noise[1 + k])
+    assert ok("unet_real_scale.chain", rel_l2(final, xo), 1e-4, precision="bf16x6"), rel_l2(final, xo)
 
 
-def test_unet_xl_geometry_vs_reference(cases):
+@pytest.mark.parametrize("precision", UNET_PRECISIONS)
+def test_unet_xl_geometry_vs_reference(cases, precision):
     """The released geometry (configs/model.py motion_unet_adagn_xl: dim 512 x mults (2,2,2,2) = 1024 channels, 128 per
     GroupNorm group) — forward (cond / uncond / CFG) and input-VJP vs the REAL reference's CPU outputs
     (tests/golden/make_golden_unet_xl.py; rounds 1-3 compared this geometry with the torch port only)."""
@@ -1697,6 +1790,7 @@ def test_unet_xl_geometry_vs_reference(cases):
     mu.load_model_wo_clip(model, weights.to_torch(weights.fill_like(shapes, case["weight_seed"])) |
                           {k: v for k, v in model.state_dict().items() if k.endswith(".pe")})
     model = model.to(DEV).eval()
+    model.native_precision = precision
     net = sub("model.cfg_sampler").ClassifierFreeSampleModel(model)
     x, t = tt(inp["x"]), tt(inp["t"])
     kw = dict(obs_x0=tt(inp["obs_x0"]), obs_mask=tt(inp["obs_mask"]))
@@ -1763,13 +1857,14 @@ def test_unet_vjp_other_configs_vs_torch_port(cases, B, T, keyframe, cfg):
     assert ok("unet_vjp_other_configs_vs_torch_port.rel_l2.1", rel_l2(got.cpu().numpy(), want.numpy()), 5e-5), rel_l2(got.cpu().numpy(), want.numpy())
 
 
-def test_unet_recon_guidance_chain_vs_reference(cases):
+@pytest.mark.parametrize("precision", UNET_PRECISIONS)
+def test_unet_recon_guidance_chain_vs_reference(cases, precision):
     """p_sample_loop with imputation AND reconstruction guidance through the native MDM_UNET vs the real reference."""
     cc = cases.UNET_RECON_CHAIN
     ci = cases.make_unet_chain_inputs(cc)
     g = load_golden("unet_recon_chain")
     assert np.array_equal(g["fingerprint"], cases.fingerprint(ci))
-    model, _ = make_unet(cases)
+    model, _ = make_unet(cases, precision)
     wrapped = sub("model.cfg_sampler").ClassifierFreeSampleModel(model)
     diffusion = make_diffusion(cc["respacing"])
     obs_mask = tt(ci["obs_mask"])

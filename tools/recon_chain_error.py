@@ -157,6 +157,119 @@ def operating_point(sd, want, modes):
         hat = eng.mdm_forward(tt(x1), tt(t0)).cpu().numpy().astype(np.float64)
         g = eng.mdm_vjp(tt(seed)).cpu().numpy().astype(np.float64)
         row("engine " + mode + ENV_TAG, hat, g)
+        dump = __import__("os").environ.get("RECON_DUMP")
+        if dump:      # the raw tensors, for an error map on the build container
+            np.savez_compressed(f"{dump}_{mode}.npz", hat=hat, g=g)
+
+
+def stash_audit(sd, want):
+    """Probes library + CMDI_STASH_F32=6: read back, per layer, the (mean, rstd) the stashing forward handed to the LayerNorm
+    backward and the fp32 pre-LayerNorm rows, recompute the statistics in float64 on the host, list the rows that disagree."""
+    import ctypes
+    N = sub("_native")
+    lib = N.load()
+    if not hasattr(lib, "cmdi_probe_read_stash"):
+        print("# stash audit needs the probes library (CMDI_PROBES_LIB=1)")
+        return
+    lib.cmdi_probe_read_stash.restype = ctypes.c_int64
+    lib.cmdi_probe_read_stash.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64]
+    d = inputs(0, 3)
+    B, T, S, dm = 2, 60, 61, 512
+    M = 2 * B * S
+    model = native_model(sd, "f16x3")
+    eng = model.model.engine(dev, max_batch=B, max_frames=T, want_grad=True)
+    eng.set_condition(batch=B, n_frames=T, cfg=True, enc_text=tt(d["enc"]), text_scale=tt(d["scale"]))
+    eng.mdm_forward(tt(want["op_x1"]), tt(want["op_t"]))
+
+    def read(layer, which, n):
+        buf = np.empty(n, np.float32)
+        got = lib.cmdi_probe_read_stash(eng._h, layer, which, buf.ctypes.data, n)
+        return buf if got == n else None
+
+    print(f"# stash audit{ENV_TAG}: (mean, rstd) handed to the LayerNorm backward vs float64 statistics of the stashed fp32 rows")
+    for layer in range(8):
+        for which, pre_id, name in ((0, 2, "norm1"), (1, 3, "norm2")):
+            st, pre = read(layer, which, 2 * M), read(layer, pre_id, M * dm)
+            if st is None or pre is None:
+                print(f" layer {layer} {name}: not available (CMDI_STASH_F32 & {2 if which == 0 else 4}?)")
+                continue
+            st = st.reshape(M, 2).astype(np.float64)
+            x = pre.reshape(M, dm).astype(np.float64)
+            mean, rstd = x.mean(1), 1.0 / np.sqrt(x.var(1) + 1e-5)
+            em = np.abs(st[:, 0] - mean) * rstd             # mean error in units of sigma
+            er = np.abs(st[:, 1] / rstd - 1.0)
+            worst = np.argsort(-np.maximum(em, er))[:4]
+            print(f" layer {layer} {name}: |d mean|/sigma median {np.median(em):.2e} max {em.max():.2e} | |d rstd|/rstd median {np.median(er):.2e} "
+                  f"max {er.max():.2e} | worst rows (seq, token) {[(int(r) // S, int(r) % S) for r in worst]}", flush=True)
+
+
+def stash_audit2(sd, want):
+    """Second audit (probes library, CMDI_STASH_F32=6): the stash tensors the forward pass itself does not read back — the FFN
+    pre-activation (aux), the split qkv rows and the softmax row statistics — against float64 values recomputed on the host
+    from the stashed fp32 pre-LayerNorm rows.  Per layer: rel-L2 and the rows with the largest error."""
+    import ctypes
+    N = sub("_native")
+    lib = N.load()
+    if not hasattr(lib, "cmdi_probe_read_stash"):
+        print("# stash audit needs the probes library (CMDI_PROBES_LIB=1)")
+        return
+    lib.cmdi_probe_read_stash.restype = ctypes.c_int64
+    lib.cmdi_probe_read_stash.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64]
+    d = inputs(0, 3)
+    B, T, S, dm, f, H = 2, 60, 61, 512, 1024, 4
+    nseq = 2 * B
+    M = nseq * S
+    model = native_model(sd, "f16x3")
+    eng = model.model.engine(dev, max_batch=B, max_frames=T, want_grad=True)
+    eng.set_condition(batch=B, n_frames=T, cfg=True, enc_text=tt(d["enc"]), text_scale=tt(d["scale"]))
+    eng.mdm_forward(tt(want["op_x1"]), tt(want["op_t"]))
+
+    def read(layer, which, n):
+        buf = np.empty(n, np.float32)
+        got = lib.cmdi_probe_read_stash(eng._h, layer, which, buf.ctypes.data, n)
+        return buf if got == n else None
+
+    def ln(x, g, b):
+        mu = x.mean(1, keepdims=True)
+        return (x - mu) / np.sqrt(x.var(1, keepdims=True) + 1e-5) * g + b
+
+    def unsplit(raw, cols):          # [M][2 cols] halves in chunks of 32 (hi | lo) -> float64 [M][cols]
+        h = raw.view(np.float16).reshape(M, cols // 32, 2, 32).astype(np.float64)
+        return (h[:, :, 0, :] + h[:, :, 1, :] / 2048.0).reshape(M, cols)
+
+    def report(name, got, ref):
+        err = np.linalg.norm(got - ref, axis=1) / np.linalg.norm(ref, axis=1)
+        worst = np.argsort(-err)[:4]
+        print(f"   {name}: rel-L2 {np.linalg.norm(got - ref) / np.linalg.norm(ref):.2e} | per-row median {np.median(err):.2e} max {err.max():.2e} at "
+              f"(seq, token) {[(int(r) // S, int(r) % S) for r in worst]}", flush=True)
+
+    g64 = lambda k: np.asarray(sd[k], np.float64)
+    print(f"# stash audit 2{ENV_TAG}: aux / qkv / softmax statistics of the stashing forward vs float64 recomputation from the stashed rows")
+    for layer in range(8):
+        p = f"seqTransEncoder.layers.{layer}."
+        pre1, aux = read(layer, 2, M * dm), read(layer, 5, M * f)
+        print(f" layer {layer}:")
+        if pre1 is not None and aux is not None:
+            h1 = ln(pre1.reshape(M, dm).astype(np.float64), g64(p + "norm1.weight"), g64(p + "norm1.bias"))
+            report("aux (FFN pre-activation)", aux.reshape(M, f).astype(np.float64), h1 @ g64(p + "linear1.weight").T + g64(p + "linear1.bias"))
+        qraw, rs = read(layer, 6, M * 3 * dm), read(layer, 7, nseq * H * S * 2)
+        if layer > 0 and qraw is not None:
+            pre2 = read(layer - 1, 3, M * dm)
+            pp = f"seqTransEncoder.layers.{layer - 1}."
+            hin = ln(pre2.reshape(M, dm).astype(np.float64), g64(pp + "norm2.weight"), g64(pp + "norm2.bias"))
+            qkv_ref = hin @ g64(p + "self_attn.in_proj_weight").T + g64(p + "self_attn.in_proj_bias")
+            qkv = unsplit(qraw, 3 * dm)
+            report("qkv (split rows)", qkv, qkv_ref)
+            if rs is not None:      # P rows from the stashed statistics must sum to one: sum_j exp(s_ij - m_i) * inv_i
+                rs = rs.reshape(nseq, H, S, 2).astype(np.float64)
+                q = qkv[:, :dm].reshape(nseq, S, H, 128).transpose(0, 2, 1, 3)
+                k = qkv[:, dm:2 * dm].reshape(nseq, S, H, 128).transpose(0, 2, 1, 3)
+                s_ = (q @ k.transpose(0, 1, 3, 2)) / np.sqrt(128.0)
+                psum = (np.exp(s_ - rs[..., 0:1]) * rs[..., 1:2]).sum(-1)             # [nseq, H, S]
+                dev_ = np.abs(psum - 1.0)
+                w = np.argsort(-dev_.max(1).reshape(-1))[:4]
+                print(f"   softmax statistics: |sum_j P_ij - 1| median {np.median(dev_):.2e} max {dev_.max():.2e} at (seq, token) "
+                      f"{[(int(r) // S, int(r) % S) for r in w]}; max (true max - stashed reference max) {float((s_.max(-1) - rs[..., 0]).max()):.2f}", flush=True)
 
 
 def chain_wants(sd, n, w):
@@ -222,6 +335,10 @@ def main():
         one_evaluation(sd, want, modes)
     if "1b" in stages:
         operating_point(sd, want, modes)
+    if "audit" in stages:
+        stash_audit(sd, want)
+    if "audit2" in stages:
+        stash_audit2(sd, want)
     if "2" in stages:
         print("# stage 2: guided chains, rel-L2 of the final sample vs the float64 oracle chain (in brackets: vs the fp32 oracle chain)")
         for n, w in PLAN:
