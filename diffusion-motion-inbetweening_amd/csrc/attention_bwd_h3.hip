@@ -186,12 +186,26 @@ __device__ __forceinline__ h8 tr_frag(const TrUnit& u, int d1, int pl) {
 }
 
 // B operands of the transposed products from 8 accumulator-layout values (k-step kk of x[16])
-struct ProbOp { h8 h, l, s; };   // p_hi, p - p_hi (unscaled), p_hi * 2^-11
+// Round 5 — two defects of rounds 1-4, found by replaying the guided chain's per-layer (qkv, d out) through this kernel alone
+// (tools/attn_bwd_replay.py, profiles/r05_guided_error_attribution.md):
+// (1) x arrives as a PRODUCT (exp2(..) * 1/sum).  hipcc (-ffp-contract=fast) fused that product into the conversions: hi became
+//     RN16(exact product) (v_fma_mixlo_f16) while the residual was taken against RN32(product) — whenever the two roundings
+//     part (the product within one fp32 ulp of an f16 tie: one P entry in ~4,000) hi and lo belong to DIFFERENT splits and the
+//     entry is off by a whole f16 ulp, 2^-10 of its value.  With the large d out rows of a few keyframe queries behind it that
+//     was a 10-100x error on single d V rows — the heavy tail of the input-VJP's error outside the keyframes (1.2e-5 where the
+//     exact-operand engines have 1.7e-6).  The empty asm pins x to ONE rounded fp32 value, as gemm_h3.hpp split_f16 does.
+// (2) P here is the NORMALISED probability (~1/S): p - p_hi then lies below 2^-14, an f16 subnormal with an absolute step of
+//     2^-24 — 18 bits of P, not 22 (the forward's p is relative to the running maximum, ~1, where the same split is fine).
+//     The operand is therefore built from 2^8 p (exact scaling; <= 256), and the d V accumulators are scaled back by 2^-8
+//     once, before they are stored (attn_bwd_kv_h3_kernel epilogue).
+constexpr float kProbScale = 256.0f, kProbInv = 1.0f / 256.0f;
+struct ProbOp { h8 h, l, s; };   // of q = 2^8 p:  q_hi, q - q_hi (unscaled), q_hi * 2^-11
 __device__ __forceinline__ ProbOp prob_operand(const float* x) {
     ProbOp o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const float pv = x[e];
+        float pv = x[e] * kProbScale;
+        asm volatile("" : "+v"(pv));
         const _Float16 a = (_Float16)pv;
         o.h[e] = a;
         o.l[e] = (_Float16)(pv - (float)a);
@@ -458,7 +472,7 @@ __global__ __launch_bounds__(64 * BW, 1) void attn_bwd_kv_h3_kernel(const _Float
 #pragma unroll
         for (int d = 0; d < 4; ++d)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dk0[d][r] += dk1[d][r] * kLoInv;
+            for (int r = 0; r < 16; ++r) { dk0[d][r] += dk1[d][r] * kLoInv; dv[d][r] *= kProbInv; }   // (d V was summed on 2^8 P)
         store_rows_via_lds(ws, dk0, row0 + koff, ld, n_rows, l31, hi);
         store_rows_via_lds(ws, dv, row0 + voff, ld, n_rows, l31, hi);
     }

@@ -1608,7 +1608,6 @@ def make_unet_attention(cases):
     assert sorted(shapes) == list(g["names"]), "state-dict names differ from the reference's MDM_UNET(attention=True)"
     mu.load_model_wo_clip(model, weights.to_torch(weights.fill_like(shapes, case["weight_seed"])) |
                           {k: v for k, v in model.state_dict().items() if k.endswith(".pe")})
-    model.native_precision = precision
     return model.to(DEV).eval(), g
 
 
