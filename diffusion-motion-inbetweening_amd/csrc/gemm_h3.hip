@@ -20,6 +20,11 @@ using H128x256s2 = H3Tile<128, 256, 2, 4, 2, 2>;    // 8 waves, 64x64 per wave, 
 using H64x128w8s2 = H3Tile<64, 128, 2, 4, 2, 2>;    // 8 waves, 32x32 per wave: the tail tile of the mixed grid
 using H64x512ln = H3Tile<64, 512, 2, 4, 2, 2>;      // 8 waves, 32x128 per wave: full rows of d = 512 (LN fused)
 using H256x128w16 = H3Tile<256, 128, 8, 2, 3, 4>;   // 16 waves, 32x64 per wave, 3 stages = 144 KiB
+// fat K steps for small M (round 5; H3Tile::LPS): one request / wait / barrier per LPS * 32 columns
+using H64x64f4 = H3Tile<64, 64, 2, 2, 2, 2, 0, 4>;      // 4 waves of 32x32, 128 columns per step, 128 KiB: one block per CU
+using H64x64f2 = H3Tile<64, 64, 2, 2, 2, 2, 0, 2>;      // 4 waves, 64 columns per step, 64 KiB
+using H64x128f2 = H3Tile<64, 128, 2, 4, 2, 2, 0, 2>;    // 8 waves of 32x32, 64 columns per step, 96 KiB
+using H128x128f2 = H3Tile<128, 128, 4, 2, 2, 2, 0, 2>;  // 8 waves of 32x64, 64 columns per step, 128 KiB
 using H128x256w16 = H3Tile<128, 256, 4, 4, 3, 4>;   // 16 waves, 32x64 per wave
 
 template <class TC, int EPI>
@@ -92,6 +97,11 @@ static hipError_t launch_h3_tiles(const H3Params& p, int tile, hipStream_t s) {
         case 11: return launch_h3_one<H128x256w16, EPI>(p, s);
         case 20: return launch_h3_mixed<EPI>(p, s);
         case 21: return launch_h3_one<H64x128w8s2, EPI>(p, s);
+        // fat K steps: the K loop must be a whole number of them, no split-K
+        case 24: return p.K % 128 == 0 && p.ksplit <= 1 ? launch_h3_one<H64x64f4, EPI>(p, s) : hipErrorInvalidValue;
+        case 25: return p.K % 64 == 0 && p.ksplit <= 1 ? launch_h3_one<H64x128f2, EPI>(p, s) : hipErrorInvalidValue;
+        case 26: return p.K % 64 == 0 && p.ksplit <= 1 ? launch_h3_one<H64x64f2, EPI>(p, s) : hipErrorInvalidValue;
+        case 28: return p.K % 64 == 0 && p.ksplit <= 1 ? launch_h3_one<H128x128f2, EPI>(p, s) : hipErrorInvalidValue;
         default: return hipErrorInvalidValue;
     }
 }

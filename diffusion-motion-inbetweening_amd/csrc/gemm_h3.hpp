@@ -117,17 +117,24 @@ namespace cmdi {
 // (Round 2 measured four more K-loop schedules on this tile — requests between the trailing MFMAs, wait + barrier pinned behind
 // the last MFMA, the K step rotated around its barrier, the A operand from registers; all lost to the one below and were
 // removed in round 3: DESIGN.md "GEMM design".)
-template <int BM_, int BN_, int WM_, int WN_, int NSTAGE_, int MINW_, int EPI8_ = 0>
+template <int BM_, int BN_, int WM_, int WN_, int NSTAGE_, int MINW_, int EPI8_ = 0, int LPS_ = 1>
 struct H3Tile {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, NSTAGE = NSTAGE_, MINW = MINW_;
     static constexpr int EPI8 = EPI8_;             // interior tiles of the split epilogues without residual: 8 columns per lane
+    // LPS (round 5, small M): 128-byte lines per row and ring stage.  A block that is alone on its CU pays ~1,000-1,400 cycles
+    // per K step whatever the tile (requests, fragment reads and MFMAs of its lock-stepped waves add up: r04_kstep_ablation.md);
+    // with LPS lines per stage it requests, waits and meets at the barrier once per LPS * 32 columns — a "fat" K step of LPS
+    // ordinary ones back to back, each on its own 128-byte line of the row.  The products and their order per output are
+    // untouched (k ascending in steps of 16): the same bits as every other tile.
+    static constexpr int LPS = LPS_;
     static constexpr int BK = 32;                  // columns per K step = one 128-B line per row
     static constexpr int NW = WM * WN, NT = 64 * NW;
     static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     static constexpr int STAGE = (BM + BN) * 128;  // bytes: A rows then W rows, 128 B each
     static constexpr int PW = (BM + BN) / 8 / NW;  // LDS-DMA pieces (1 KiB = 8 rows) per wave per stage
     static constexpr size_t EPI_BYTES = (size_t)NW * 32 * 32 * TN * 4 + 2 * WN * BM * 4;  // transpose + LN sums
-    static constexpr size_t MAIN_BYTES = (size_t)NSTAGE * STAGE > EPI_BYTES ? (size_t)NSTAGE * STAGE : EPI_BYTES;
+    static constexpr size_t MAIN_BYTES = (size_t)NSTAGE * LPS * STAGE > EPI_BYTES ? (size_t)NSTAGE * LPS * STAGE : EPI_BYTES;
+    static_assert(LPS == 1 || NSTAGE == 2, "fat K steps run on a ring of two stage groups");
     static constexpr size_t LDS_BYTES = MAIN_BYTES + (size_t)BM * 8;   // + (mean, rstd) of the tile's rows (folded LayerNorm)
     static_assert(NSTAGE == 2 || NSTAGE == 3, "NSTAGE");
     static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "wave tile must be 32-aligned");
@@ -792,6 +799,63 @@ __device__ __forceinline__ void gemm_h3_body(const H3Params& p, int block_id, in
 
     const int nk_all = p.K / 32;
     const int kt0 = (int)((long)nk_all * kslice / nslice), nk = (int)((long)nk_all * (kslice + 1) / nslice);
+    if constexpr (TC::LPS > 1) {
+        // ---- fat K steps: group g of the ring = LPS mini-stages of the ordinary layout (A rows | W rows, one line each) -------
+        constexpr int LPS = TC::LPS;
+        auto mini = [&](const char* st) __attribute__((always_inline)) {
+            h8 ah[2][TM], al[2][TM], wh[2][TN], wl[2][TN];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ah[ks][i] = *reinterpret_cast<const h8*>(st + a_row + i * 4096 + off_hi[ks]);
+                    al[ks][i] = *reinterpret_cast<const h8*>(st + a_row + i * 4096 + off_lo[ks]);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    wh[ks][j] = *reinterpret_cast<const h8*>(st + w_row + j * 4096 + off_hi[ks]);
+                    wl[ks][j] = *reinterpret_cast<const h8*>(st + w_row + j * 4096 + off_lo[ks]);
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][i], wh[ks][j], acc0[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][i], wl[ks][j], acc1[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks][i], wh[ks][j], acc1[i][j], 0, 0, 0);
+            }
+        };
+#pragma unroll
+        for (int l = 0; l < LPS; ++l) issue(kt0 + l, l);
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        int g = 0;
+        for (int kt = kt0; kt < nk; kt += LPS) {
+            if (kt + LPS < nk) {     // the next fat step into the other group (every wave left it at the last barrier)
+#pragma unroll
+                for (int l = 0; l < LPS; ++l) issue(kt + LPS + l, (g ^ 1) * LPS + l);
+            }
+#pragma unroll
+            for (int l = 0; l < LPS; ++l) mini(lds + (g * LPS + l) * STAGE);
+            wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            g ^= 1;
+        }
+        h3_epilogue<TC, EPI>(p, acc0, acc1, m0, n0, M, kslice, lds);
+        return;
+    }
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s)
         if (kt0 + s < nk) issue(kt0 + s, s);

@@ -1288,6 +1288,46 @@ def test_graph_replay_of_the_pipelined_schedule_is_bitwise_identical(precision, 
     eng.set_graph(False)
 
 
+@pytest.mark.parametrize("groups", ["1", "2"])
+def test_graph_cache_hit_replays_the_graphs_of_an_earlier_call(groups, monkeypatch):
+    """the part-graph cache (api_sampler.hip: key = stream, seed, first_sample, x pointer, parts) was never HIT in
+    a test — every run above calls set_condition first, which drops the graphs.  Here a chain is cut into two
+    cmdi_sample_loop calls on the SAME x tensor with no set_condition in between: the second call replays the graphs the
+    first one captured (cursors and per-step tables re-uploaded for its step range) and must continue the chain bit for bit
+    as the eager single call does — across the guidance gate (stop_recguidance_at = 4) and the imputation gate."""
+    N = sub("_native")
+    monkeypatch.setenv("CMDI_GROUPS", groups)
+    case = dict(text=True, weight_seed=11, cfg=True)
+    model, _ = make_model(case, layers=2, precision="f16x3")
+    diffusion = make_diffusion([12])
+    B, T = 5, 52
+    rng = np.random.default_rng(11)
+    shape = (B, 263, 1, T)
+    emb = tt(rng.standard_normal((B, 512)).astype(np.float32))
+    x0 = tt(rng.standard_normal(shape).astype(np.float32))
+    mask = tt(rng.random(shape) < 0.3)
+    eng = model.model.engine(torch.device(DEV), max_batch=B, max_frames=T, want_grad=True)
+    eng.set_schedule(diffusion.engine_tables(), key="gc")
+    cond = lambda: eng.set_condition(batch=B, n_frames=T, cfg=True, enc_text=emb, text_scale=torch.full((B,), 2.5, device=DEV),
+                                     inpaint_mask=mask, inpaint_motion=x0, imputate=True, stop_imputation_at=1, recon_guidance=True,
+                                     stop_recguidance_at=4, recon_w=np.full((12,), 20.0, dtype=np.float32))
+    for sid in (N.CMDI_SAMPLER_DDPM, N.CMDI_SAMPLER_DDIM):
+        eng.set_graph(False)
+        cond()
+        want = eng.randn(shape, seed=6)
+        eng.sample_loop(want, 11, 0, sampler=sid, eta=0.3, seed=79, first_sample=2)
+        eng.set_graph(True)
+        cond()                                   # drops every graph: the first call below captures afresh
+        x = eng.randn(shape, seed=6)
+        eng.sample_loop(x, 11, 7, sampler=sid, eta=0.3, seed=79, first_sample=2)     # captures (kind: with guidance)
+        eng.sample_loop(x, 6, 3, sampler=sid, eta=0.3, seed=79, first_sample=2)      # cache hit + the second kind from step 3
+        eng.sample_loop(x, 2, 0, sampler=sid, eta=0.3, seed=79, first_sample=2)      # cache hit, both kinds known
+        eng.check_range()
+        assert eng.pipeline_parts() == int(groups)
+        assert torch.isfinite(want).all() and torch.equal(x, want), float((x - want).abs().max())
+    eng.set_graph(False)
+
+
 # ---- post-sampling step (SURVEY.md §8f rank 2) -----------------------------------------------------------
 @pytest.mark.parametrize("abs_3d", [False, True])
 def test_recover_xyz_vs_reference(cases, abs_3d):

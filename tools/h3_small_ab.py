@@ -1,12 +1,13 @@
 """Small-M GEMMs (latency-bound regime): tile 21 (64x128) vs 8 (128x128); rings of 3 and 4 stages were measured with it in round 3: no gain."""
 import importlib, sys, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parent.parent))
 eng = importlib.import_module("diffusion-motion-inbetweening_amd.engine")
 from tools.x6_bench import timeit
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(1)
 TILES = tuple(int(t) for t in sys.argv[1].split(",")) if len(sys.argv) > 1 else (21, 8)
-for M in (244, 788, 3152):
+MS = tuple(int(m) for m in sys.argv[2].split(",")) if len(sys.argv) > 2 else (244, 788, 3152)
+for M in MS:
     for (n, k, epi, name) in [(1536, 512, 0, "in_proj"), (1024, 512, 1, "linear1"), (512, 512, 4, "out_proj"), (512, 1024, 4, "linear2")]:
         a = torch.randn(M, k, generator=g).to(dev); w = (torch.randn(n, k, generator=g) * 0.05).to(dev); b = torch.randn(n, generator=g).to(dev); r = torch.randn(M, n, generator=g).to(dev)
         a_s, w_s, r_s = eng.split_f16(a), eng.split_f16(w), eng.split_f16(r)
