@@ -24,7 +24,6 @@ using H256x128w16 = H3Tile<256, 128, 8, 2, 3, 4>;   // 16 waves, 32x64 per wave,
 using H64x64f4 = H3Tile<64, 64, 2, 2, 2, 2, 0, 4>;      // 4 waves of 32x32, 128 columns per step, 128 KiB: one block per CU
 using H64x64f2 = H3Tile<64, 64, 2, 2, 2, 2, 0, 2>;      // 4 waves, 64 columns per step, 64 KiB
 using H64x128f2 = H3Tile<64, 128, 2, 4, 2, 2, 0, 2>;    // 8 waves of 32x32, 64 columns per step, 96 KiB
-using H128x128f2 = H3Tile<128, 128, 4, 2, 2, 2, 0, 2>;  // 8 waves of 32x64, 64 columns per step, 128 KiB
 using H128x256w16 = H3Tile<128, 256, 4, 4, 3, 4>;   // 16 waves, 32x64 per wave
 
 template <class TC, int EPI>
@@ -101,7 +100,6 @@ static hipError_t launch_h3_tiles(const H3Params& p, int tile, hipStream_t s) {
         case 24: return p.K % 128 == 0 && p.ksplit <= 1 ? launch_h3_one<H64x64f4, EPI>(p, s) : hipErrorInvalidValue;
         case 25: return p.K % 64 == 0 && p.ksplit <= 1 ? launch_h3_one<H64x128f2, EPI>(p, s) : hipErrorInvalidValue;
         case 26: return p.K % 64 == 0 && p.ksplit <= 1 ? launch_h3_one<H64x64f2, EPI>(p, s) : hipErrorInvalidValue;
-        case 28: return p.K % 64 == 0 && p.ksplit <= 1 ? launch_h3_one<H128x128f2, EPI>(p, s) : hipErrorInvalidValue;
         default: return hipErrorInvalidValue;
     }
 }
@@ -113,6 +111,20 @@ int gemm_h3_auto_tile(int M, int N) {
     // halve the tile height so twice as many blocks share the work
     const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
     return tiles < 384 ? 21 : 8;
+}
+
+// Small batches (round 5; plain GEMMs only): when a launch cannot fill the chip the blocks run alone on their CUs and a K step is
+// a fixed ~1,000-1,400 cycles of request round trip whatever the tile — so take fewer, fatter K steps (H3Tile::LPS) on the
+// smallest tile that still fits ONE round of block slots.  Same bits as every other tile (profiles/r05_small_batch_tiles.txt:
+// M = 788: linear1 12.2 -> 8.8 us, out_proj 12.1 -> 8.9, linear2 19.1 -> 13.1, in_proj 11.8 -> 10.7; no gain once the launch
+// needs a second round).  256 = CUs of an MI355X (one 128-KiB block each; two 64-KiB blocks each for tile 26).
+static int gemm_h3_small_m_tile(const H3Params& p) {
+    if (p.cpt || p.ksplit > 1 || p.N % 64 != 0 || p.K % 64 != 0) return 0;
+    const long t64 = (long)((p.M + 63) / 64) * (p.N / 64);
+    if (t64 <= 256 && p.K % 128 == 0) return 24;                 // 64x64, 128 columns per K step
+    if (t64 <= 512) return 26;                                    // 64x64, 64 columns per K step, two blocks per CU
+    if (p.N % 128 == 0 && (long)((p.M + 63) / 64) * (p.N / 128) <= 256) return 25;   // 64x128, 64 columns per K step
+    return 0;
 }
 
 // The persistent kernel (gemm_h3p.hpp) computes the same bits as the tiles above; which one runs is a pure speed choice.
@@ -167,6 +179,8 @@ static hipError_t launch_gemm_h3_routed(int epi, const H3Params& p, int tile, hi
         return launch_gemm_h3p(epi, p, s, 0);
     }
     if (tile >= 1000) { *route = "gemm_h3p_kernel"; return launch_gemm_h3p(epi, p, s, tile - 1000); }   // structure variants / ablations (probes library only)
+    if (tile == 0 && (epi == H3_PLAIN || epi == H3_GELU_SPLIT || epi == H3_RESID || epi == H3_PLAIN_SPLIT || epi == H3_GELUGRAD_SPLIT))
+        tile = gemm_h3_small_m_tile(p);
     if (tile == 0) {
         tile = gemm_h3_auto_tile(p.M, p.N);
         static int epi8 = -1;
