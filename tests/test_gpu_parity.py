@@ -533,6 +533,30 @@ def test_vjp_vs_reference_autograd(cases, precision):
         assert ok("vjp_vs_reference_autograd.rel_l2.2", rel_l2(gk, g["gx"]), 5e-5), (k, rel_l2(gk, g["gx"]))
 
 
+@pytest.mark.parametrize("bits", ["1", "6", "7"])
+def test_vjp_with_fp32_copies_beside_the_split_stash(cases, bits, monkeypatch):
+    """CMDI_STASH_F32 (round 5; the attribution switches of profiles/r05_guided_error_attribution.md, kept as a selectable
+    schedule): the folded stashing forward also writes fp32 copies of the attention output (bit 1) / pre1 (2) / pre2 (4) and the
+    backward reads those instead of the split rows.  Same forward bits, an input-VJP within the usual bound of the reference's
+    autograd, and within rounding of the default data flow (the 22-bit stash is NOT where the guided path lost accuracy)."""
+    case = cases.CASES["vjp_text_cfg"]
+    inp = cases.make_inputs(case)
+    g = load_golden("vjp_text_cfg")
+    B, _, _, T = inp["x"].shape
+    outs = {}
+    for mode in ("0", bits):
+        monkeypatch.setenv("CMDI_STASH_F32", mode)
+        model, _ = make_model(case, precision="f16x3")
+        eng = model.model.engine(torch.device(DEV), max_batch=B, max_frames=T, want_grad=True)
+        eng.set_condition(batch=B, n_frames=T, cfg=True, enc_text=tt(inp["enc_text"]), text_scale=tt(inp["text_scale"]))
+        out = eng.mdm_forward(tt(inp["x"]), tt(inp["t"])).cpu().numpy()
+        gx = eng.mdm_vjp(tt(inp["gout"])).cpu().numpy()
+        outs[mode] = (out, gx)
+        assert ok("vjp_stash_f32.vjp", rel_l2(gx, g["gx"]), 5e-5), (mode, rel_l2(gx, g["gx"]))
+    assert np.array_equal(outs["0"][0], outs[bits][0])                       # the copies do not touch the forward values
+    assert ok("vjp_stash_f32.vs_default", rel_l2(outs[bits][1], outs["0"][1]), 2e-6), rel_l2(outs[bits][1], outs["0"][1])
+
+
 def test_torch_autograd_through_the_native_denoiser(cases):
     """torch.autograd.grad(loss(model(z, t, **kw)), z) — the reference's reconstruction-guidance / cond_fn pattern
     (gaussian_diffusion.py:411-416) — runs the native forward + input-VJP behind an autograd.Function."""
