@@ -2,6 +2,9 @@
 // interior path and gemm_h3p.hpp).  Included by gemm_h3.hpp after its own helpers (split_f16, kLoInv, h4 / h8, split_pos).
 #pragma once
 
+#ifndef CMDI_H3P_OUT_SC1
+#define CMDI_H3P_OUT_SC1 0   // 1: the persistent kernel's split-row stores carry sc1 (experiment builds)
+#endif
 namespace cmdi {
 
 // Epilogue geometry: a lane owns EIGHT consecutive columns of a row (4 lanes per 32-column row segment, 16 rows per
@@ -193,8 +196,15 @@ __device__ __forceinline__ void h3p_epi_block(const H3Params& p, const f32x16& a
             }
             if (live) {
                 _Float16* dst = p.Cs + (size_t)m * (p.cs_ld ? p.cs_ld : 2 * p.N) + npos;
+#if CMDI_H3P_OUT_SC1
+                // experiment builds only (profiles/r05_inproj_l2_counters.txt): split rows written through the L2 (`sc1`) instead of
+                // parked there as dirty lines — fabric reads of the C4 in_proj 718 -> see the file; costs the kernel time
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(oh) : "memory");
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst + 32), "v"(ol) : "memory");
+#else
                 *reinterpret_cast<h8*>(dst) = oh;
                 *reinterpret_cast<h8*>(dst + 32) = ol;
+#endif
             }
         }
         if constexpr (EPI == H3_RESID) {
