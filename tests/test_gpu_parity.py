@@ -401,6 +401,40 @@ def test_attention_vjp_h3_vs_torch_autograd(S):
         assert ok(f"attention_vjp_h3.d{part}", err, 5e-6), (part, err)
 
 
+def test_attention_vjp_h3_has_no_row_outliers_under_sparse_large_gradients():
+    """Regression test of round 5's finding (profiles/r05_guided_error_attribution.md).  Reconstruction guidance drives the
+    attention backward with d out rows that are large on a FEW queries (the keyframes) and zero elsewhere; a single softmax
+    probability that is off by one f16 ulp — rounds 1-4: hi and lo of the split P operand of dV taken from different roundings of
+    a contracted product, one entry in ~4,000 — then stands out in ONE row of dV by two orders of magnitude while every
+    whole-tensor norm stays fine (the test above never saw it).  Here: 4 sequences x 197 tokens, diffuse attention, d out on every
+    fifth query only, and the error is measured PER ROW of dq / dk / dv against float64 autograd.  On the round-4 kernel (library
+    variant built from the parent commit of the fix, same box) this test FAILS with a worst dV row at 6.3e-5 of its norm, median
+    row 3.6e-6; at HEAD the worst row of dq / dk / dv is 2.2e-7."""
+    eng = sub("engine")
+    n_seq, S, H = 4, 197, 4
+    g = torch.Generator().manual_seed(20260927)
+    qkv = torch.randn(n_seq * S, 3 * H * 128, generator=g)
+    qkv[:, :1024] *= 0.3                                   # diffuse softmax rows (P ~ 1 / S), as under the random-init denoiser
+    dout = torch.zeros(n_seq * S, H * 128)
+    key_rows = torch.arange(0, n_seq * S, 5)
+    dout[key_rows] = torch.randn(len(key_rows), H * 128, generator=g) * 8.0
+    x = qkv.double().requires_grad_(True)
+    q, k, v = (x[:, i * 512:(i + 1) * 512].view(n_seq, S, H, 128).transpose(1, 2) for i in range(3))
+    p = torch.softmax(q @ k.transpose(-1, -2) / 128 ** 0.5, dim=-1)
+    out = (p @ v).transpose(1, 2).reshape(n_seq * S, 512)
+    want, = torch.autograd.grad((out * dout.double()).sum(), x)
+    got = eng.attention_vjp_h3(qkv.to(DEV), dout.to(DEV), n_seq, S, H).cpu().double()
+    for i, part in enumerate("qkv"):
+        a, b = got[:, i * 512:(i + 1) * 512], want[:, i * 512:(i + 1) * 512]
+        row_norm = b.norm(dim=1)
+        floor = 0.05 * float(row_norm.median()) if float(row_norm.median()) > 0 else 1e-30   # (dq rows of queries without d out are 0)
+        rel = ((a - b).norm(dim=1) / torch.clamp(row_norm, min=max(floor, 1e-30)))
+        rel = rel[row_norm > 0] if part != "q" else rel[key_rows]
+        worst, med = float(rel.max()), float(rel.median())
+        assert ok(f"attention_vjp_rows.d{part}.worst_row", worst, 1e-5), (part, worst, med)
+        assert worst <= 20 * med + 1e-12, (part, worst, med)       # no heavy tail: the worst row is an ordinary row (it was 100-700 x)
+
+
 def test_engine_rng_matches_oracle():
     Engine = sub("engine").Engine
     e = Engine(n_layers=0, d_model=0, d_ff=0, n_heads=0, n_feats=263, max_frames=196, max_batch=4,
