@@ -17,7 +17,7 @@ _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "csrc" / "libcondmdi_hip.so"
 if __import__("os").environ.get("CMDI_PROBES_LIB") == "1":   # tools/ only: the instrumented build (build.py --probes)
     LIB_PATH = _PKG / "csrc" / "libcondmdi_hip_probes.so"
-if __import__("os").environ.get("CMDI_LIB_VARIANT"):        # tools/ only: experiment builds (tools/st_policy_build.sh, tools/ab_variants.sh)
+if __import__("os").environ.get("CMDI_LIB_VARIANT"):        # tools/ only: experiment builds (tools/variant_build.sh, tools/ab_variants.sh)
     _variant = __import__("os").environ["CMDI_LIB_VARIANT"]
     if not __import__("re").fullmatch(r"[A-Za-z0-9_]+", _variant):   # a name, never a path
         raise ValueError(f"CMDI_LIB_VARIANT must match [A-Za-z0-9_]+, got {_variant!r}")

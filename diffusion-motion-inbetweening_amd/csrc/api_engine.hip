@@ -1,4 +1,5 @@
 // C-ABI of libcondmdi_hip.so (include/condmdi.h), engine part: handle life cycle, weight packing, schedule, condition.
+#include <utility>
 #include "engine.hpp"
 
 using namespace cmdi;
@@ -145,6 +146,7 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
     e->h3_tile_proj = env_probe("CMDI_H3_TILE_PROJ", env_probe("CMDI_H3_TILE", 0));
     e->h3_tile_ffn1 = env_probe("CMDI_H3_TILE_FFN1", env_probe("CMDI_H3_TILE", 0));
     e->h3_tile_ffn2 = env_probe("CMDI_H3_TILE_FFN2", env_probe("CMDI_H3_TILE", 0));
+    e->h3w = env_int("CMDI_H3W", 0);    // (round 6, in progress: the weight-stationary kernel is opt-in until it beats the tiled one at every shape it is routed to)
     e->ln_fuse = env_probe("CMDI_LN_FUSE", 0) && desc->d_model == 512;
     e->io_h3 = e->precision == CMDI_PREC_F16X3 && !e->ln_fuse && env_probe("CMDI_IO_H3", 1);
     e->ln_fold = e->io_h3 && desc->d_model == 512 && env_int("CMDI_LN_FOLD", 1);
@@ -212,6 +214,22 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
             }
             ALLOC(e->partA, Mmax * 32); ALLOC(e->partB, Mmax * 32);
         }
+        if (e->h3w && d == 512) {     // fragment-ordered copies for the weight-stationary GEMM (K = 512, N % 128 == 0)
+            auto pk = [&](const _Float16* ws, size_t n) -> int {
+                if (!ws || n % 128 != 0) return CMDI_OK;
+                _Float16* wp = nullptr;
+                int rc = dalloc(e, reinterpret_cast<void**>(&wp), n * 2048);
+                if (rc == CMDI_OK) e->h3w_packed[ws] = wp;
+                return rc;
+            };
+            for (LayerW& w : e->layers) {
+                int rc = pk(w.in_ws, 3 * d); if (rc != CMDI_OK) return rc;
+                rc = pk(w.in_wsf, 3 * d); if (rc != CMDI_OK) return rc;
+                rc = pk(w.out_ws, d); if (rc != CMDI_OK) return rc;
+                rc = pk(w.l1_ws, f); if (rc != CMDI_OK) return rc;
+                rc = pk(w.l1_wsf, f); if (rc != CMDI_OK) return rc;
+            }
+        }
         ALLOC(e->w_in_s, (size_t)d * e->Cpad * 2); ALLOC(e->w_out_s, (size_t)C * d * 2);
         ALLOC(e->xS, (size_t)e->Bmax * e->Tmax * e->Cpad * 2);
         ALLOC(e->tokS, Mmax * d * 2); ALLOC(e->bufHS, Mmax * d * 2);
@@ -220,6 +238,16 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
             for (LayerW& w : e->layers) {
                 ALLOC(w.in_wTs, (size_t)3 * d * d * 2); ALLOC(w.out_wTs, (size_t)d * d * 2);
                 ALLOC(w.l1_wTs, (size_t)f * d * 2); ALLOC(w.l2_wTs, (size_t)d * f * 2);
+            }
+            if (e->h3w && d == 512) {     // the two dX GEMMs with K = 512: out_proj^T [d][d], linear2^T [f][d]
+                for (LayerW& w : e->layers)
+                    for (auto pr : {std::make_pair(w.out_wTs, (size_t)d), std::make_pair(w.l2_wTs, (size_t)f)}) {
+                        if (pr.second % 128 != 0) continue;
+                        _Float16* wp = nullptr;
+                        int rc = dalloc(e, reinterpret_cast<void**>(&wp), pr.second * 2048);
+                        if (rc != CMDI_OK) return rc;
+                        e->h3w_packed[pr.first] = wp;
+                    }
             }
             ALLOC(e->dBS, Mmax * d * 2); ALLOC(e->dffnS, Mmax * f * 2); ALLOC(e->dqkvS, Mmax * 3 * d * 2);
             ALLOC(e->dOS, Mmax * d * 2);
@@ -421,6 +449,17 @@ int cmdi_finalize_weights(cmdi_handle e, int32_t n_time_rows, cmdi_stream stream
         hipError_t se = hipStreamSynchronize(s);   // one-time setup: tmp must outlive the kernels
         (void)hipFree(tmp);
         HIPCHK(fe); HIPCHK(se);
+    }
+    for (const auto& kv : e->h3w_packed) {   // every split weight the weight-stationary GEMM can take, in fragment order
+        int n = 0;
+        for (const LayerW& w : e->layers) {
+            if (kv.first == w.in_ws || kv.first == w.in_wsf) n = 3 * d;
+            else if (kv.first == w.out_ws || kv.first == w.out_wTs) n = d;
+            else if (kv.first == w.l1_ws || kv.first == w.l1_wsf || kv.first == w.l2_wTs) n = f;
+            if (n) break;
+        }
+        if (!n) return fail(CMDI_E_INVALID, "h3w_packed holds an unknown weight");
+        HIPCHK(launch_pack_w_h3w(static_cast<const _Float16*>(kv.first), kv.second, n, s));
     }
     if (e->precision == CMDI_PREC_BF16X6) {
         for (LayerW& w : e->layers) {

@@ -208,6 +208,12 @@ int cmdi_conv_rows_x6(const float* d_a, int32_t a_ld, const void* d_w_packed, co
     if (!d_a || !d_w_packed || (!d_c && !d_c2)) return fail(CMDI_E_INVALID, "null tensor");
     if (cin % 32 != 0 || n % 4 != 0 || taps < 1 || a_ld < cin || a_ld % 4 != 0)
         return fail(CMDI_E_INVALID, "cin must be a multiple of 32, n and a_ld multiples of 4, a_ld >= cin");
+    if (pad < 0 || a_row_mul < 0 || c_row_mul < 0 || m < 1 || n < 1)
+        return fail(CMDI_E_INVALID, "pad, a_row_mul and c_row_mul must be >= 0, m and n >= 1");
+    if (c_row_mul == 0 && c_row_add != 0) return fail(CMDI_E_INVALID, "c_row_add needs c_row_mul != 0 (output row = m * c_row_mul + c_row_add)");
+    if (tp < 0 || (tp > 0 && (t_lo < 0 || t_hi > tp || t_hi <= t_lo)))
+        return fail(CMDI_E_INVALID, "tp > 0 needs 0 <= t_lo < t_hi <= tp");
+    if (d_c2 && (ldc2 < n || ldc2 % 4 != 0)) return fail(CMDI_E_INVALID, "d_c2 needs ldc2 >= n, a multiple of 4");
     GemmParams p{};
     p.A = d_a - (ptrdiff_t)pad * a_ld; p.lda = a_ld;
     p.Wx = d_w_packed; p.bias = d_bias; p.R = d_resid;

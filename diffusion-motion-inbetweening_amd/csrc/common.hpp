@@ -30,6 +30,18 @@ struct PerDevice {
     }
 };
 
+// Compute units of the current device (256 on an MI355X in SPX mode; fewer in CPX partitions), queried once per device.
+inline int device_cu_count() {
+    static PerDevice<int> cus_dev;
+    int& cus = cus_dev.get();
+    if (!cus) {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        cus = n > 0 ? n : 256;
+    }
+    return cus;
+}
+
 // Row r (0..15) of a 32x32 MFMA C/D fragment held by lane `lane`:
 // col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
 __device__ __forceinline__ int mfma32_row(int r, int lane) {

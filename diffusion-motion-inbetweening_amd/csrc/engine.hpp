@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/condmdi.h"
@@ -128,6 +129,15 @@ struct cmdi_engine {
     float* text_term_p = nullptr;  // text_term in the slot order of the independent pipelines (cmdi_sample_loop)
     int pipelines = 1;             // CMDI_PIPELINES=0: keep the fork/join-per-step schedule in cmdi_sample_loop
     int h3_tile_qkv = 0, h3_tile_proj = 0, h3_tile_ffn1 = 0, h3_tile_ffn2 = 0;
+    // weight-stationary GEMM (gemm_h3w.hpp, K = d = 512): fragment-ordered copies of the split weights it can take, keyed by the
+    // split copy's address (filled at create, packed at cmdi_finalize_weights); h3w = CMDI_H3W (0: never route to it)
+    int h3w = 0;
+    std::unordered_map<const void*, _Float16*> h3w_packed;
+    const _Float16* packed(const _Float16* w_split) const {
+        if (!h3w) return nullptr;
+        auto it = h3w_packed.find(w_split);
+        return it == h3w_packed.end() ? nullptr : it->second;
+    }
     // f16x3: LayerNorm inside the out_proj / linear2 GEMM epilogue (d_model = 512).  Off by default:
     // the full-row 64x512 tile it needs (197 blocks, 8 waves per CU) loses more in the GEMM than the
     // saved LayerNorm pass returns (B=32 CFG: 2.60 vs 2.29 ms per step on MI355X).

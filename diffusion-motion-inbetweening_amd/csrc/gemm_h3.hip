@@ -117,13 +117,15 @@ int gemm_h3_auto_tile(int M, int N) {
 // a fixed ~1,000-1,400 cycles of request round trip whatever the tile — so take fewer, fatter K steps (H3Tile::LPS) on the
 // smallest tile that still fits ONE round of block slots.  Same bits as every other tile (profiles/r05_small_batch_tiles.txt:
 // M = 788: linear1 12.2 -> 8.8 us, out_proj 12.1 -> 8.9, linear2 19.1 -> 13.1, in_proj 11.8 -> 10.7; no gain once the launch
-// needs a second round).  256 = CUs of an MI355X (one 128-KiB block each; two 64-KiB blocks each for tile 26).
+// needs a second round).  One round = the device's CUs (256 on an MI355X; one 128-KiB block each, two 64-KiB blocks each for
+// tile 26) — queried, not assumed, so that a CPX partition does not take the fat tiles into a second round.
 static int gemm_h3_small_m_tile(const H3Params& p) {
     if (p.cpt || p.ksplit > 1 || p.N % 64 != 0 || p.K % 64 != 0) return 0;
+    const long cus = device_cu_count();
     const long t64 = (long)((p.M + 63) / 64) * (p.N / 64);
-    if (t64 <= 256 && p.K % 128 == 0) return 24;                 // 64x64, 128 columns per K step
-    if (t64 <= 512) return 26;                                    // 64x64, 64 columns per K step, two blocks per CU
-    if (p.N % 128 == 0 && (long)((p.M + 63) / 64) * (p.N / 128) <= 256) return 25;   // 64x128, 64 columns per K step
+    if (t64 <= cus && p.K % 128 == 0) return 24;                 // 64x64, 128 columns per K step
+    if (t64 <= 2 * cus) return 26;                                // 64x64, 64 columns per K step, two blocks per CU
+    if (p.N % 128 == 0 && (long)((p.M + 63) / 64) * (p.N / 128) <= cus) return 25;   // 64x128, 64 columns per K step
     return 0;
 }
 
@@ -173,10 +175,17 @@ static hipError_t launch_gemm_h3_routed(int epi, const H3Params& p, int tile, hi
         (p.ln_c1 && (!p.ln_part || p.K != 512)))
         return hipErrorInvalidValue;
     if (tile == 50) { *route = "gemm_h3p_kernel"; return launch_gemm_h3p(epi, p, s, 0); }
+    if (tile == 60) { *route = "gemm_h3w_kernel"; return launch_gemm_h3w(epi, p, s); }      // weight-stationary (K = 512), gemm_h3w.hpp
     if (p.rc_tv) return hipErrorInvalidValue;      // logical-row GEMMs exist on the persistent kernel only
     if (tile == 0 && gemm_h3_persistent_for(p.M) && gemm_h3p_supports(epi, p)) {
         *route = "gemm_h3p_kernel";
         return launch_gemm_h3p(epi, p, s, 0);
+    }
+    // the weight-stationary kernel (K = 512; gemm_h3w.hpp) where the caller holds a fragment-ordered copy of W and the launch is
+    // tall enough to give every block whole tiles; same bits as the tiles below — a pure speed choice
+    if (tile == 0 && p.Wp && gemm_h3w_supports(epi, p) && gemm_h3w_wanted(p.M, p.N)) {
+        *route = "gemm_h3w_kernel";
+        return launch_gemm_h3w(epi, p, s);
     }
     if (tile >= 1000) { *route = "gemm_h3p_kernel"; return launch_gemm_h3p(epi, p, s, tile - 1000); }   // structure variants / ablations (probes library only)
     if (tile == 0 && (epi == H3_PLAIN || epi == H3_GELU_SPLIT || epi == H3_RESID || epi == H3_PLAIN_SPLIT || epi == H3_GELUGRAD_SPLIT))

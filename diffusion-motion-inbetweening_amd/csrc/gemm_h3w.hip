@@ -1,0 +1,83 @@
+// Instantiations + host launcher of the weight-stationary split-f16 GEMM (gemm_h3w.hpp): K = 512, N a multiple of 128.
+#include <cstdlib>
+
+#include "gemm_h3w.hpp"
+#include "kernels.hpp"
+
+namespace cmdi {
+
+bool gemm_h3w_supports(int epi, const H3Params& p) {
+    if (epi != H3_PLAIN && epi != H3_GELU_SPLIT && epi != H3_RESID && epi != H3_PLAIN_SPLIT && epi != H3_GELUGRAD_SPLIT) return false;
+    if (p.K != 512 || p.N % 128 != 0 || p.N <= 0 || p.M <= 0) return false;
+    if ((p.a_ld && p.a_ld != 1024) || p.a_row_mul > 1 || p.taps > 1 || p.cpt || p.c_row_mul || p.tp || p.rc_tv || p.ksplit > 1) return false;
+    if ((size_t)p.M * 2048 >= (1ull << 32)) return false;        // 32-bit request offsets
+    return true;
+}
+
+// Rows from which the weight-stationary kernel is taken when the caller passes a packed W: every block should hold several
+// 32-row tiles per pass (a block's W load is 256 KiB whatever M is).  CMDI_H3W_MIN_M overrides (experiments).
+bool gemm_h3w_wanted(int M, int N) {
+    static int min_m = -1;
+    if (min_m < 0) { const char* v = std::getenv("CMDI_H3W_MIN_M"); min_m = v ? std::atoi(v) : 8192; }
+    (void)N;
+    return M >= min_m;
+}
+
+static int gcd_int(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
+
+template <int EPI>
+static hipError_t launch_h3w(const H3Params& p, hipStream_t stream) {
+    auto kern = gemm_h3w_kernel<EPI>;
+    static PerDevice<bool> attr_done_dev;   // benign race: the attribute call is idempotent
+    bool& attr_done = attr_done_dev.get();
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)H3WTile::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    int nb = device_cu_count() / 8;      // blocks per XCD: one per CU; block id % 8 = XCD
+    if (nb < 1) nb = 1;
+    const int strips = p.N / 128, g = gcd_int(strips, nb);
+    const int passes = strips / g, subs = nb / g;
+    hipLaunchKernelGGL(kern, dim3(8 * nb), dim3(H3WTile::NT), H3WTile::LDS_BYTES, stream, p, passes, subs,
+                       p.ln_part ? p.ln_part : reinterpret_cast<const float*>(p.A));
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_w_h3w(const _Float16* w_split, _Float16* w_packed, int n, hipStream_t stream) {
+    if (n <= 0 || n % 128 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pack_w_h3w_kernel, dim3((unsigned)(n * 128 + 255) / 256), dim3(256), 0, stream, w_split, w_packed, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm_h3w(int epi, const H3Params& p0, hipStream_t s) {
+    if (!gemm_h3w_supports(epi, p0)) return hipErrorInvalidValue;
+    H3Params p = p0;
+    if (!p.Wp) {
+        // single-kernel hooks (tests, tools): the caller holds split rows only — pack them into a per-thread scratch copy on the
+        // launch stream.  The engine packs once at cmdi_finalize_weights and passes Wp.
+        static thread_local _Float16* scratch = nullptr;
+        static thread_local size_t scratch_bytes = 0;
+        const size_t need = (size_t)p.N * 2048;
+        if (need > scratch_bytes) {
+            if (scratch) { (void)hipStreamSynchronize(s); (void)hipFree(scratch); scratch = nullptr; scratch_bytes = 0; }
+            hipError_t e = hipMalloc(reinterpret_cast<void**>(&scratch), need);
+            if (e != hipSuccess) return e;
+            scratch_bytes = need;
+        }
+        hipError_t e = launch_pack_w_h3w(p.W, scratch, p.N, s);
+        if (e != hipSuccess) return e;
+        p.Wp = scratch;
+    }
+    switch (epi) {
+        case H3_PLAIN: return launch_h3w<H3_PLAIN>(p, s);
+        case H3_GELU_SPLIT: return launch_h3w<H3_GELU_SPLIT>(p, s);
+        case H3_RESID: return launch_h3w<H3_RESID>(p, s);
+        case H3_PLAIN_SPLIT: return launch_h3w<H3_PLAIN_SPLIT>(p, s);
+        case H3_GELUGRAD_SPLIT: return launch_h3w<H3_GELUGRAD_SPLIT>(p, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace cmdi

@@ -73,6 +73,7 @@ enum H3Epi {
 struct H3Params {
     const _Float16* A;  // split rows [M][2K]
     const _Float16* W;  // split rows [N][2K]
+    const _Float16* Wp; // gemm_h3w (weight-stationary, K = 512) only: W in fragment order (pack_w_h3w_kernel), same bytes as W
     const float* bias;  // [N] or null
     float* C;           // fp32 output [M][ldc]
     _Float16* Cs;       // split output [M][2N]

@@ -45,6 +45,12 @@ bool gemm_h3p_supports(int epi, const H3Params& p);
 const char* gemm_h3_last_route();   // kernel family of this thread's most recent launch_gemm_h3
 bool gemm_h3_persistent_for(int M);   // policy (CMDI_H3_PERSIST), gemm_h3.hip
 hipError_t launch_gemm_h3p(int epi, const H3Params& p, hipStream_t stream, int ablation = 0);   // ablation: probes library only
+// gemm_h3w.hip: the weight-stationary kernel for K = 512 (tile id 60 of launch_gemm_h3; W fragments resident in the accumulation
+// registers, A streamed through LDS); same bits as the tiles above
+bool gemm_h3w_supports(int epi, const H3Params& p);
+bool gemm_h3w_wanted(int M, int N);     // tall enough for the weight-stationary kernel to win (measured; CMDI_H3W_MIN_M)
+hipError_t launch_gemm_h3w(int epi, const H3Params& p, hipStream_t stream);
+hipError_t launch_pack_w_h3w(const _Float16* w_split, _Float16* w_packed, int n, hipStream_t stream);   // [n][1024] -> fragment order
 // fp32 [rows][cols] (row stride ld_src) -> split rows [rows][2*cols] halves (format: gemm_h3.hpp)
 hipError_t launch_split_f16(const float* src, _Float16* dst, int64_t rows, int cols, int64_t ld_src,
                             int* range_flag, hipStream_t stream);

@@ -1068,7 +1068,7 @@ int res_block(UnetModel* u, const ResBlock& r, const _Float16* xs, int a_ld, con
                 u->probe_mnk[0] = nseq * L.Tv; u->probe_mnk[1] = C; u->probe_mnk[2] = 5 * r.c2.cin_p;
             }
             if (conv_gn_rows(u, r.c2, r.n2, u->H1S[level], 2 * C, rows, level, nullptr, xf, out_f, out_s, out_ld, s)) return -1;
-            if (probe) { UCHK(hipEventRecord(u->probe_ev[1], s)); u->probe_route = gemm_h3_last_route(); }
+            if (probe) { UCHK(hipEventRecord(u->probe_ev[1], s)); if (!u->x6) u->probe_route = gemm_h3_last_route(); }
             return 0;
         }
         if (conv_gn_rows(u, r.c2, r.n2, u->H1S[level], 2 * C, rows, level, nullptr, nullptr, u->F1[level], nullptr, 0, s)) return -1;
@@ -1085,7 +1085,7 @@ int res_block(UnetModel* u, const ResBlock& r, const _Float16* xs, int a_ld, con
         u->probe_mnk[0] = nseq * L.Tv; u->probe_mnk[1] = C; u->probe_mnk[2] = 5 * r.c2.cin_p;   // algorithmic: valid frames only
     }
     if (conv_rows(u, r.c2, r.c2.ws, u->H1S[level], 2 * C, rows, level, 5, 2, 1, 0, 0, f2, nullptr, 0, nullptr, s, &n2)) return -1;
-    if (probe) { UCHK(hipEventRecord(u->probe_ev[1], s)); u->probe_route = gemm_h3_last_route(); }
+    if (probe) { UCHK(hipEventRecord(u->probe_ev[1], s)); if (!u->x6) u->probe_route = gemm_h3_last_route(); }
     if (st) { st->n1 = n1; st->n2 = n2; }
     float* stats2 = st ? st->st2 : nullptr;
     if (!r.res.ws) {   // identity residual, added behind the Mish

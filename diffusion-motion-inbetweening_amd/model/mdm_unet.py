@@ -179,7 +179,14 @@ class MDM_UNET(nn.Module):
     _weights_key = MDM._weights_key
     invalidate_engine = MDM.invalidate_engine
     check_range = MDM.check_range
-    range_fallback = MDM.range_fallback     # after a RangeError of the default (f16x3) engine: bf16x6 for good (round 5)
+
+    def range_fallback(self) -> bool:
+        """After a RangeError of the default (f16x3) engine: bf16x6 for good (round 5) — except for attention=True, whose
+        LinearAttention sites exist in f16x3 only: no fallback is taken and no state changes, so the caller's RangeError
+        propagates and the module keeps working on in-range inputs."""
+        if self.attention:
+            return False
+        return MDM.range_fallback(self)
 
     def engine(self, device, max_batch, max_frames, want_grad=False, n_time_rows=1000):
         """The native engine holding this module's weights on `device` (built / grown lazily)."""

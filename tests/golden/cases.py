@@ -235,6 +235,13 @@ BIG_CASES = {
                     seed=509, ragged=True, skip=90, init_image=True, keep=(0, 63, 64, 127, 128, 255)),
     "c5_rank": dict(kind="chain", text=True, cfg=True, weight_seed=47, B=128, T=196, respacing=[10], sampler="ddpm",
                     seed=510, ragged=True, keep=(0, 31, 32, 63, 64, 127)),
+    # (VERDICT r5 task 1a) BASELINE config 4 itself, END TO END: B=256 on 'ddim100', CFG, ragged lengths, ALL 100 steps from
+    # pure noise (no init_image / skip) — once through ddim_sample_loop (eta 0, reference gaussian_diffusion.py:1454-1587)
+    # and once through p_sample_loop on the respaced chain (what the sample scripts call).  Sample 0's x_t every 10 steps.
+    "c4_ddim_long": dict(kind="chain", text=True, cfg=True, weight_seed=46, B=256, T=196, respacing="ddim100", sampler="ddim",
+                         eta=0.0, seed=514, ragged=True, every=10, keep=(0, 63, 64, 127, 128, 255)),
+    "c4_ddpm_long": dict(kind="chain", text=True, cfg=True, weight_seed=46, B=256, T=196, respacing="ddim100", sampler="ddpm",
+                         seed=515, ragged=True, every=10, keep=(0, 63, 64, 127, 128, 255)),
     # (VERDICT r3 task 5b) BASELINE config 2 itself, END TO END: B=32 x 196 frames, text CFG, ragged lengths, ALL 1000
     # ancestral steps through the reference on CPU (~15 min), so that the two-pipeline / two-stream one-call schedule is
     # compared with reference values over the whole chain, not its first 20 steps.  Sample 0's x_t every 100 steps.

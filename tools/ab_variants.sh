@@ -1,5 +1,5 @@
 # usage (GPU box): bash tools/ab_variants.sh <config> "<variant list: none p1 ...>"  — same-box A/B of library variants
-# built by tools/st_policy_build.sh (CMDI_LIB_VARIANT); prints ms per step and the in-run time of the dominant GEMM
+# built by tools/variant_build.sh (CMDI_LIB_VARIANT); prints ms per step and the in-run time of the dominant GEMM
 cfg=$1
 for v in $2; do
 if [ $v != none ]; then export CMDI_LIB_VARIANT=$v; else unset CMDI_LIB_VARIANT; fi
