@@ -31,7 +31,7 @@ int run_layers(cmdi_engine* e, int seq0, int nseq, bool keep, bool prof, hipStre
                   int N, int K) {
         H3Params p{};
         p.A = A; p.W = W; p.bias = bias; p.C = C; p.Cs = Cs; p.range_flag = e->range_flag;
-        p.Wp = e->packed(W);
+        p.Wp = e->packed(W, M);
         p.M = M; p.N = N; p.K = K; p.ldc = N;
         return p;
     };
@@ -398,7 +398,7 @@ int run_layers_bwd(cmdi_engine* e, int seq0, int nseq, hipStream_t s) {
         // gradients carry no range flag: a gradient beyond the f16 range would already have shown
         // up as a non-finite sample (bench / callers check), and the forward pass guards the rest
         p.A = A; p.W = W; p.C = C; p.Cs = Cs;
-        p.Wp = e->packed(W);
+        p.Wp = e->packed(W, M);
         p.M = M; p.N = N; p.K = K; p.ldc = N;
         return p;
     };

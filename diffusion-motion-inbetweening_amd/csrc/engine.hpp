@@ -131,10 +131,10 @@ struct cmdi_engine {
     int h3_tile_qkv = 0, h3_tile_proj = 0, h3_tile_ffn1 = 0, h3_tile_ffn2 = 0;
     // weight-stationary GEMM (gemm_h3w.hpp, K = d = 512): fragment-ordered copies of the split weights it can take, keyed by the
     // split copy's address (filled at create, packed at cmdi_finalize_weights); h3w = CMDI_H3W (0: never route to it)
-    int h3w = 0;
+    int h3w = 0, h3w_min_m = 8192;                 // CMDI_H3W, CMDI_H3W_MIN_M: route launches of at least that many rows
     std::unordered_map<const void*, _Float16*> h3w_packed;
-    const _Float16* packed(const _Float16* w_split) const {
-        if (!h3w) return nullptr;
+    const _Float16* packed(const _Float16* w_split, int m) const {
+        if (!h3w || m < h3w_min_m) return nullptr;
         auto it = h3w_packed.find(w_split);
         return it == h3w_packed.end() ? nullptr : it->second;
     }

@@ -181,9 +181,9 @@ static hipError_t launch_gemm_h3_routed(int epi, const H3Params& p, int tile, hi
         *route = "gemm_h3p_kernel";
         return launch_gemm_h3p(epi, p, s, 0);
     }
-    // the weight-stationary kernel (K = 512; gemm_h3w.hpp) where the caller holds a fragment-ordered copy of W and the launch is
-    // tall enough to give every block whole tiles; same bits as the tiles below — a pure speed choice
-    if (tile == 0 && p.Wp && gemm_h3w_supports(epi, p) && gemm_h3w_wanted(p.M, p.N)) {
+    // the weight-stationary kernel (K = 512; gemm_h3w.hpp) where the caller passes a fragment-ordered copy of W (the engine does
+    // for launches of at least CMDI_H3W_MIN_M rows when CMDI_H3W=1); same bits as the tiles below — a pure speed choice
+    if (tile == 0 && p.Wp && gemm_h3w_supports(epi, p)) {
         *route = "gemm_h3w_kernel";
         return launch_gemm_h3w(epi, p, s);
     }

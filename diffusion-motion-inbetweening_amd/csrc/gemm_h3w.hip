@@ -14,15 +14,6 @@ bool gemm_h3w_supports(int epi, const H3Params& p) {
     return true;
 }
 
-// Rows from which the weight-stationary kernel is taken when the caller passes a packed W: every block should hold several
-// 32-row tiles per pass (a block's W load is 256 KiB whatever M is).  CMDI_H3W_MIN_M overrides (experiments).
-bool gemm_h3w_wanted(int M, int N) {
-    static int min_m = -1;
-    if (min_m < 0) { const char* v = std::getenv("CMDI_H3W_MIN_M"); min_m = v ? std::atoi(v) : 8192; }
-    (void)N;
-    return M >= min_m;
-}
-
 static int gcd_int(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
 
 template <int EPI>

@@ -85,12 +85,12 @@ __device__ __forceinline__ void h3w_dma(i32x4 rsrc, unsigned voff, int soff, uns
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(__builtin_amdgcn_readfirstlane((int)lds_dst)), "v"(voff), "s"(rsrc), "s"(soff)
                  : "memory");
 }
-// the next piece of a stream: LDS destination + ADVANCE, source + 128 B (the next chunk of the same rows); `soff` is the running
-// scalar offset (one register for the sixteen chunks: sixteen "s" constants would be hoisted out of the tile loop and kept)
-template <int ADVANCE>
+// the next piece of a sequence: LDS destination + ADVANCE, source + SRC bytes; `soff` is the running scalar offset (one register
+// for the whole sequence: sixteen "s" constants would be hoisted out of the tile loop and kept)
+template <int ADVANCE, int SRC = 128>
 __device__ __forceinline__ void h3w_dma_next(i32x4 rsrc, unsigned voff, int& soff) {
-    asm volatile("s_add_u32 m0, m0, %3\n\ts_add_u32 %0, %0, 0x80\n\tbuffer_load_dwordx4 %1, %2, %0 offen lds"
-                 : "+s"(soff) : "v"(voff), "s"(rsrc), "n"(ADVANCE) : "memory", "scc");
+    asm volatile("s_add_u32 m0, m0, %3\n\ts_add_u32 %0, %0, %4\n\tbuffer_load_dwordx4 %1, %2, %0 offen lds"
+                 : "+s"(soff) : "v"(voff), "s"(rsrc), "n"(ADVANCE), "n"(SRC) : "memory", "scc");
 }
 
 // ---- the deferred epilogue ------------------------------------------------------------------------------------------------
@@ -101,12 +101,14 @@ __device__ __forceinline__ void h3w_dma_next(i32x4 rsrc, unsigned voff, int& sof
 // as h3_epilogue in the same order per value: the same bits.
 struct H3WNoFill {
     static constexpr int kStoresBehindRequests = 0;
+    static constexpr int lds_ops(int) { return 0; }
     template <int G> __device__ __forceinline__ void slice() {}
 };
 // a deferred epilogue bound to the accumulator set of the tile it finishes
 template <class D>
 struct H3WFill {
     static constexpr int kStoresBehindRequests = D::kStoresBehindRequests;
+    static constexpr int lds_ops(int G) { return D::lds_ops(G); }
     D& d;
     const f32x16& a0;
     const f32x16& a1;
@@ -116,9 +118,13 @@ struct H3WFill {
 template <int EPI>
 struct H3WDefer {
     static constexpr bool kSupported = (EPI == H3_PLAIN_SPLIT || EPI == H3_GELU_SPLIT) && !(H3W_ABL & 32);
-    // vector-memory operations this epilogue is GUARANTEED to issue behind the stream's last request (step 16 = gap 50): the two
+    // vector-memory operations this epilogue is guaranteed to issue behind the stream's last request (step 16 = gap 50): the two
     // split stores of iterations 1, 2, 3 (gaps >= 54); stash stores, if any, only add to them
     static constexpr int kStoresBehindRequests = 6;
+    // LDS operations of the slice behind MFMA G (one transpose store; two read-backs): the stream's counted fragment waits add
+    // them — without that a wait "all but the newest two" lands on this step's OWN fragment reads as soon as a slice has put
+    // an LDS operation behind them, and every step of the transpose phase paid an LDS round trip (+ 530 cycles per tile)
+    static constexpr int lds_ops(int G) { return G < 16 ? 1 : (G >= 18 && G < 22 ? 2 : 0); }
     const H3Params& p;
     const int lane, wave;
     // per pass (lane constants of the strip)
@@ -130,44 +136,51 @@ struct H3WDefer {
     const float2* row_stats;
     char* dst0;                // split output of this lane's first row (row m0 + lane / 8) at its four columns
     float* aux0;
-    long long dst_step, aux_step;   // bytes per 8 rows
+    unsigned dst_step, aux_step;    // bytes per 8 rows
     float4 tt[4];
     float2 rst[4];
     float v[4];
     h4 oh, ol;
     unsigned ovf;              // max over every value split so far of (bits << 1): >= (bits of 65504.f) << 1 <=> !(|x| < 65504), NaN included
-    long long lane_dst;        // per pass: byte offset of this lane's (row lane / 8, its four columns) inside a 32-row output block
-    long long ld_bytes;
+    unsigned lane_dst;         // per pass: byte offset of this lane's (row lane / 8, its four columns) inside a 32-row output block
+    unsigned ld_bytes;         // row pitch of the split output (launch_gemm_h3w refuses pitches beyond 32 bits)
+    long long head_base;       // cs_head_major: byte offset of this lane's (q|k|v, head) block
 
     __device__ __forceinline__ H3WDefer(const H3Params& p_, int lane_, int wave_) : p(p_), lane(lane_), wave(wave_), ovf(0) {}
 
-    // lane constants of the pass at strip n0; the loads are CONSUMED here (an empty asm pins them) so that no compiler wait for them
-    // lands inside a stream, where it would also wait for every hand-issued request in flight.  Without folded LayerNorm the
-    // slices run the SAME formula on c1 = 0, (mean, rstd) = (0, 1): fma(1, fma(-0, 0, t), b) = t + b exactly, no select per value.
-    __device__ __forceinline__ void begin_pass(int n0) {
-        const int cl = (lane & 7) * 4;
-        n = n0 + wave * 32 + cl;
+    // Lane constants of the pass at strip n0.  prefetch_pass() runs IN FRONT of the pass's first stream — in which the epilogue of
+    // the previous pass's last tile may still ride on the old constants — and only issues the loads; commit_pass() takes them over
+    // BEHIND that stream (whose closing wait has covered the loads: no compiler wait for them lands inside a stream, where it
+    // would also wait for every hand-issued request in flight).  Without folded LayerNorm the slices run the SAME formula on
+    // c1 = 0, (mean, rstd) = (0, 1): fma(1, fma(-0, 0, t), b) = t + b exactly, no select per value.
+    float4 nbias4, nc14;
+    int nn;
+    __device__ __forceinline__ void prefetch_pass(int n0) {
+        nn = n0 + wave * 32 + (lane & 7) * 4;
+        nbias4 = p.bias ? *reinterpret_cast<const float4*>(p.bias + nn) : make_float4(0.f, 0.f, 0.f, 0.f);
+        nc14 = p.ln_c1 ? *reinterpret_cast<const float4*>(p.ln_c1 + nn) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __device__ __forceinline__ void commit_pass() {
+        n = nn; bias4 = nbias4; c14 = nc14;
         fold = p.ln_c1 != nullptr && p.ln_part != nullptr;
         has_aux = p.aux != nullptr;
-        bias4 = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-        c14 = p.ln_c1 ? *reinterpret_cast<const float4*>(p.ln_c1 + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-        asm volatile("" : "+v"(bias4.x), "+v"(bias4.y), "+v"(bias4.z), "+v"(bias4.w), "+v"(c14.x), "+v"(c14.y), "+v"(c14.z), "+v"(c14.w));
         // output addressing of the pass: row pitch and this lane's offset inside a 32-row block (a tile then adds ONE wave-uniform
         // product m0 * pitch — scalar unit — and a store slice adds it * 8 rows)
         const int rl = lane >> 3;
-        ld_bytes = 2 * (long long)(p.cs_ld ? (size_t)p.cs_ld : 2 * (size_t)p.N);
-        lane_dst = rl * ld_bytes + 2 * (long long)split_pos(n);
+        ld_bytes = 2u * (unsigned)(p.cs_ld ? p.cs_ld : 2 * p.N);
+        lane_dst = (unsigned)rl * ld_bytes + 2u * (unsigned)split_pos(n);
+        head_base = 0;
         if constexpr (EPI == H3_PLAIN_SPLIT) {
-            if (p.cs_head_major) { ld_bytes = 512; lane_dst = ((long long)(n >> 7) * p.M + rl) * 512 + 2 * (long long)split_pos(n & 127); }
+            if (p.cs_head_major) { ld_bytes = 512; lane_dst = (unsigned)rl * 512u + 2u * (unsigned)split_pos(n & 127); head_base = (long long)(n >> 7) * p.M * 512; }
         }
         dst_step = 8 * ld_bytes;
-        aux_step = (long long)8 * p.ldc * 4;
+        aux_step = 8u * (unsigned)p.ldc * 4u;
     }
     __device__ __forceinline__ void begin_tile(int m0, char* lds_epi) {
         wl = reinterpret_cast<float*>(lds_epi) + wave * (32 * 32);
         row_stats = reinterpret_cast<const float2*>(lds_epi + H3WTile::MAIN_BYTES);
         const long long row0 = (long long)__builtin_amdgcn_readfirstlane(m0);
-        dst0 = reinterpret_cast<char*>(p.Cs) + (row0 * ld_bytes + lane_dst);
+        dst0 = reinterpret_cast<char*>(p.Cs) + (row0 * (long long)ld_bytes + head_base + lane_dst);
         aux0 = has_aux ? p.aux + ((row0 + (lane >> 3)) * p.ldc + n) : nullptr;
     }
     __device__ __forceinline__ void finish() {
@@ -209,7 +222,7 @@ struct H3WDefer {
                 asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
             } else if constexpr (m == 1) {
                 if (__builtin_expect(has_aux, 0)) {   // pre-activation stash of a forward pass that keeps activations
-                    float* dst = reinterpret_cast<float*>(reinterpret_cast<char*>(aux0) + it * aux_step);
+                    float* dst = reinterpret_cast<float*>(reinterpret_cast<char*>(aux0) + (size_t)(it * aux_step));
 #if CMDI_AUX_SC1
                     h3_store_f4(dst, make_float4(v[0], v[1], v[2], v[3]));
 #else
@@ -258,7 +271,7 @@ struct H3WDefer {
                     asm volatile("" : "+v"(ol));
                 }
             } else if constexpr (m == kStore) {
-                _Float16* dst = reinterpret_cast<_Float16*>(dst0 + it * dst_step);
+                _Float16* dst = reinterpret_cast<_Float16*>(dst0 + (size_t)(it * dst_step));
                 h3_store_h4(dst, oh);
                 h3_store_h4(dst + 32, ol);
             }
@@ -267,24 +280,76 @@ struct H3WDefer {
 };
 
 // ---- the stream of one tile ------------------------------------------------------------------------------------------------
-// k16-step S: [wait] MFMA | read | MFMA | read | MFMA | request — one companion instruction per MFMA, so that each issues under
-// a running MFMA (a lone wave per SIMD hides about five issue slots per MFMA and nothing else), and behind each MFMA one slice
-// of the deferred epilogue.  The reads fetch the fragments of step S + 2 into the register set step S - 1 has just released; at
-// the wait of step S the two reads of step S + 1 may still be in flight.  FIRST: the pass's W loads are still landing — step S
-// may start once loads 2S and 2S + 1 (w_lo[S], w_hi[S]) have: newer W loads 62 - 2S, newer requests min(S, 16) (+ 1 behind step 16: the partial statistics).  Step 0 starts
-// the sums (srcC = 0: no zeroing pass, and no VALU write in front of an MFMA the compiler cannot see).
-template <int S, bool FIRST, class Fill>
+// Issue order behind the MFMAs of step s: [request of chunk s, s < 16] [partial-statistics request, s = 16].
+struct H3WStreamArgs {
+    unsigned slot_base;          // LDS byte address of this tile's A slot
+    i32x4 rsrc;                  // A rows
+    unsigned voff;               // this lane's byte offset into them for the NEXT tile's requests
+    unsigned dma_dst;            // LDS byte address of this wave's first piece of the next tile (other slot + wave * 1024)
+    i32x4 rsrc_part;             // partial LayerNorm statistics (or a stand-in, see the kernel)
+    unsigned part_voff, part_dst;
+};
+
+// ---- a pass's W fragments: global -> LDS by LDS-DMA -> accumulation registers by ds_read --------------------------------------
+// NOT by loads into registers: the register-return path of a CU sustains 20-24 B/clk (profiles/r04_ingest_rate.txt: 64 lanes x 16
+// B come back through the vector-register write port), LDS-DMA 60-110 — the 64 W loads of a wave measured 11-13k cycles per pass
+// (profiles/r06_h3w_timeline_*), four times the pass's first tile.  The wave stages its own 64 KiB (fragment-ordered copy: piece i
+// = instruction i = one contiguous KiB, lane-linear — conflict-free ds_read_b128) through a PRIVATE 16-KiB quarter of the A slot
+// that is idle at a pass boundary, as two 8-KiB halves in flight: wait for a half, read its 8 fragments, request the half after
+// next.  No block barrier inside (the caller puts one behind it: the slot then goes back to the A requests of all waves).
+template <int R>
+__device__ __forceinline__ void h3w_stage_read(h8 (&wh)[32], h8 (&wl)[32], unsigned addr) {
+    // half-round R: pieces 8R .. 8R + 7 = k16-steps 4R .. 4R + 3 (lo plane, hi plane each), at `addr` + (R & 1) * 8 KiB
+    constexpr int o = (R & 1) * 8192, s = 4 * R;
+    asm volatile("ds_read_b128 %0, %8 offset:%9\n\tds_read_b128 %1, %8 offset:%10\n\tds_read_b128 %2, %8 offset:%11\n\t"
+                 "ds_read_b128 %3, %8 offset:%12\n\tds_read_b128 %4, %8 offset:%13\n\tds_read_b128 %5, %8 offset:%14\n\t"
+                 "ds_read_b128 %6, %8 offset:%15\n\tds_read_b128 %7, %8 offset:%16\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&a"(wl[s]), "=&a"(wh[s]), "=&a"(wl[s + 1]), "=&a"(wh[s + 1]), "=&a"(wl[s + 2]), "=&a"(wh[s + 2]), "=&a"(wl[s + 3]),
+                   "=&a"(wh[s + 3])
+                 : "v"(addr), "n"(o), "n"(o + 1024), "n"(o + 2048), "n"(o + 3072), "n"(o + 4096), "n"(o + 5120), "n"(o + 6144),
+                   "n"(o + 7168)
+                 : "memory");
+}
+template <int R>
+__device__ __forceinline__ void h3w_stage_round(h8 (&wh)[32], h8 (&wl)[32], i32x4 rsrc_w, unsigned wv, unsigned region, int& soff) {
+    // half R has landed when at most the 8 pieces of half R + 1 are still in flight
+    if constexpr (R < 7) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    h3w_stage_read<R>(wh, wl, region + wv);
+    if constexpr (R + 2 < 8) {      // the half after next, into the 8 KiB just read (M0: back to the start of that half)
+        soff += 1024;
+        h3w_dma(rsrc_w, wv, soff, region + (R & 1) * 8192);
+#pragma unroll
+        for (int q = 1; q < 8; ++q) h3w_dma_next<1024, 1024>(rsrc_w, wv, soff);
+    }
+    if constexpr (R + 1 < 8) h3w_stage_round<R + 1>(wh, wl, rsrc_w, wv, region, soff);
+}
+__device__ __forceinline__ void h3w_stage_w(h8 (&wh)[32], h8 (&wl)[32], i32x4 rsrc_w, unsigned wv, unsigned region) {
+    int soff = 0;
+    h3w_dma(rsrc_w, wv, 0, region);
+#pragma unroll
+    for (int q = 1; q < 16; ++q) h3w_dma_next<1024, 1024>(rsrc_w, wv, soff);
+    h3w_stage_round<0>(wh, wl, rsrc_w, wv, region, soff);
+}
+
+// k16-step S: [wait] MFMA | read | MFMA | read | MFMA — one companion instruction per MFMA, so that each issues under a running
+// MFMA (a lone wave per SIMD hides about five issue slots per MFMA and nothing else), and behind each MFMA one slice of the
+// deferred epilogue.  The reads fetch the fragments of step S + 2 into the register set step S - 1 has just released; at the
+// wait of step S the two reads of step S + 1 may still be in flight.  Step 0 starts the sums (srcC = 0: no zeroing pass, and no
+// VALU write in front of an MFMA the compiler cannot see).
+template <int S, class Fill>
 __device__ __forceinline__ void h3w_step(f32x16& c0, f32x16& c1, h8 (&fh)[3], h8 (&fl)[3], const h8& wh, const h8& wl,
                                          const unsigned (&ad)[4], Fill& fill) {
     constexpr int cur = S % 3, nxt = (S + 2) % 3;
-    constexpr int LG = S + 1 < 32 ? 2 : 0;                         // fragment reads that may stay in flight
-    constexpr int VM = 62 - 2 * S + (S < 16 ? S : 16) + (S > 16 ? 1 : 0);   // FIRST: vector-memory operations that may stay in flight
-    static_assert(VM <= 63, "vmcnt is a 6-bit counter");
+    // LDS operations that may stay in flight at the wait of step S: the two fragment reads of step S + 1 and whatever the
+    // epilogue slices of step S - 1 issued (all of it younger than the fragments of step S: the waits carry memory clobbers, the
+    // compiler cannot move its LDS operations out of the step it wrote them in)
+    constexpr int LG = (S + 1 < 32 ? 2 : 0) + (S >= 1 ? Fill::lds_ops(3 * S - 3) + Fill::lds_ops(3 * S - 2) + Fill::lds_ops(3 * S - 1) : 0);
+    static_assert(LG <= 15, "lgkmcnt is a 4-bit counter");
     constexpr int off = ((S + 2) >> 1) * 4096;
     constexpr bool RD = S + 2 < 32;
     // MFMA 1: acc1 (+)= a_hi w_lo, and the read of the hi-plane fragment of step S + 2
-    if constexpr (FIRST) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(%1)" ::"n"(VM), "n"(LG) : "memory");
-    else asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(LG) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(LG) : "memory");
     if constexpr (S == 0) {
         asm volatile("v_mfma_f32_32x32x16_f16 %[c1], %[fh], %[wl], 0\n\tds_read_b128 %[nh], %[ah] offset:%[off]"
                      : [c1] "=&v"(c1), [nh] "=&v"(fh[nxt])
@@ -314,53 +379,48 @@ __device__ __forceinline__ void h3w_step(f32x16& c0, f32x16& c1, h8 (&fh)[3], h8
     asm volatile("v_mfma_f32_32x32x16_f16 %[c1], %[fl], %[wh], %[c1]" : [c1] "+v"(c1) : [fl] "v"(fl[cur]), [wh] "a"(wh));
 }
 
-template <int S, bool FIRST, class Fill>
+template <int S, class Fill>
 struct H3WSteps {
     static __device__ __forceinline__ void run(f32x16& c0, f32x16& c1, h8 (&fh)[3], h8 (&fl)[3], const h8 (&wh)[32],
-                                               const h8 (&wl)[32], const unsigned (&ad)[4], i32x4 rsrc, unsigned voff,
-                                               unsigned dma_dst, int& soff, i32x4 rsrc_part, unsigned part_voff, unsigned part_dst,
+                                               const h8 (&wl)[32], const unsigned (&ad)[4], const H3WStreamArgs& a, int& soff,
                                                Fill& fill, unsigned long long (&tk)[8]) {
-        h3w_step<S, FIRST>(c0, c1, fh, fl, wh[S], wl[S], ad, fill);
+        h3w_step<S>(c0, c1, fh, fl, wh[S], wl[S], ad, fill);
         if constexpr ((H3W_ABL & 16) && (S % 8 == 7 || S == 0)) asm volatile("s_memtime %0" : "=s"(tk[S == 0 ? 1 : 2 + S / 8]));
         // the next tile's piece of chunk S (this wave's 8 rows of it), behind the step's last MFMA: 16 pieces in the first 16
         // steps, the last one >= 1,500 cycles ahead of the wait at the end of the tile
-        if constexpr (S == 0 && !(H3W_ABL & 1)) { soff = 0; h3w_dma(rsrc, voff, 0, dma_dst); }
-        else if constexpr (S < 16 && !(H3W_ABL & 1)) h3w_dma_next<4096>(rsrc, voff, soff);
+        if constexpr (S == 0 && !(H3W_ABL & 1)) { soff = 0; h3w_dma(a.rsrc, a.voff, 0, a.dma_dst); }
+        else if constexpr (S < 16 && !(H3W_ABL & 1)) h3w_dma_next<4096>(a.rsrc, a.voff, soff);
         // ... and its rows' partial LayerNorm statistics (8 rows x 128 B: one piece per wave; without folded LayerNorm the
         // request fetches a KiB of A rows instead and nobody reads it)
-        if constexpr (S == 16 && !(H3W_ABL & 1)) h3w_dma(rsrc_part, part_voff, 0, part_dst);
+        if constexpr (S == 16 && !(H3W_ABL & 1)) h3w_dma(a.rsrc_part, a.part_voff, 0, a.part_dst);
         fill.template slice<3 * S + 2>();
-        if constexpr (S + 1 < 32)
-            H3WSteps<S + 1, FIRST, Fill>::run(c0, c1, fh, fl, wh, wl, ad, rsrc, voff, dma_dst, soff, rsrc_part, part_voff, part_dst, fill, tk);
+        if constexpr (S + 1 < 32) H3WSteps<S + 1, Fill>::run(c0, c1, fh, fl, wh, wl, ad, a, soff, fill, tk);
     }
 };
 
-// The MFMA stream of one tile.  `slot_base`: LDS byte address of the tile's slot; `ad_lane`: this lane's four fragment offsets
-// inside a slot (hi / lo plane of k-substep 0, then of k-substep 1); the requests of the NEXT tile (rows via `voff`) go to
-// `dma_dst` = the other slot + wave * 1024; `fill`: the deferred epilogue of the previous tile (or H3WNoFill).
-template <bool FIRST, class Fill>
+// The stream of one tile.  `ad_lane`: this lane's four fragment offsets inside a slot (hi / lo plane of k-substep 0, then of
+// k-substep 1); `fill`: the deferred epilogue of the previous tile (or H3WNoFill).
+template <class Fill>
 __device__ __forceinline__ void h3w_tile_stream(f32x16& c0, f32x16& c1, const h8 (&wh)[32], const h8 (&wl)[32],
-                                                unsigned slot_base, const unsigned (&ad_lane)[4], i32x4 rsrc, unsigned voff,
-                                                unsigned dma_dst, i32x4 rsrc_part, unsigned part_voff, unsigned part_dst, Fill& fill,
+                                                const unsigned (&ad_lane)[4], const H3WStreamArgs& a, Fill& fill,
                                                 unsigned long long (&tk)[8]) {
     if constexpr (H3W_ABL & 16) asm volatile("s_memtime %0" : "=s"(tk[0]));
     unsigned ad[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) ad[q] = slot_base + ad_lane[q];
+    for (int q = 0; q < 4; ++q) ad[q] = a.slot_base + ad_lane[q];
     h8 fh[3], fl[3];
     // fragments of steps 0 and 1 (chunk 0, both k-substeps)
     asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7"
                  : "=&v"(fh[0]), "=&v"(fl[0]), "=&v"(fh[1]), "=&v"(fl[1])
                  : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]));
     int soff = 0;
-    H3WSteps<0, FIRST, Fill>::run(c0, c1, fh, fl, wh, wl, ad, rsrc, voff, dma_dst, soff, rsrc_part, part_voff, part_dst, fill, tk);
-    // (1) this wave's pieces of the next tile have landed; (2) the accumulators may be read by ordinary instructions: an MFMA's
-    // result is not interlocked against a VALU / LDS / VMEM read that follows within passes + 3 wait states — the compiler
-    // inserts those for its own MFMAs and cannot see these
-    // (with a deferred epilogue riding in the stream, the six split stores of its iterations 1-3 are YOUNGER than the last request —
-    // behind step 16 — and need not have completed: waiting for their write-through cost 520 cycles per tile)
-    if constexpr (Fill::kStoresBehindRequests > 0) asm volatile("s_waitcnt vmcnt(%2)\n\ts_nop 7\n\ts_nop 7" : "+v"(c0), "+v"(c1) : "n"(Fill::kStoresBehindRequests) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 7\n\ts_nop 7" : "+v"(c0), "+v"(c1)::"memory");
+    H3WSteps<0, Fill>::run(c0, c1, fh, fl, wh, wl, ad, a, soff, fill, tk);
+    // End of the stream: (1) this wave's pieces of the next tile have landed — operations issued BEHIND the last request (step
+    // 16) may stay in flight: a riding epilogue's six split stores of its iterations 1-3 (waiting for their write-through cost
+    // 520 cycles per tile); (2) the accumulators may be read by ordinary instructions: an MFMA's result is not interlocked
+    // against a VALU / LDS / VMEM read that follows within passes + 3 wait states — the compiler inserts those for its own
+    // MFMAs and cannot see these
+    asm volatile("s_waitcnt vmcnt(%2)\n\ts_nop 7\n\ts_nop 7" : "+v"(c0), "+v"(c1) : "n"(Fill::kStoresBehindRequests) : "memory");
     if constexpr (H3W_ABL & 16) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tk[6]));
 }
 
@@ -411,7 +471,8 @@ __global__ __launch_bounds__(256, 1) void gemm_h3w_kernel(const H3Params p, int 
     // requests: this wave's 8 rows of a chunk (row = lane / 8, 16-B slot = lane % 8, source slot swizzled)
     const int prow = wave * 8 + (lane >> 3), pslot = lane & 7;
     const unsigned long long a_addr = (unsigned long long)(size_t)p.A;
-    const i32x4 rsrc = {(int)(unsigned)a_addr, (int)(unsigned)((a_addr >> 32) & 0xffff), -1, 0x00020000};
+    H3WStreamArgs sa;
+    sa.rsrc = i32x4{(int)(unsigned)a_addr, (int)(unsigned)((a_addr >> 32) & 0xffff), -1, 0x00020000};
     auto row_voff = [&](int t) __attribute__((always_inline)) {
         int grow = t * 32 + prow;
         grow = grow < M ? grow : M - 1;
@@ -419,13 +480,13 @@ __global__ __launch_bounds__(256, 1) void gemm_h3w_kernel(const H3Params p, int 
     };
     // folded LayerNorm: the raw partial statistics of a tile's rows are requested with its A rows (one 8-row piece per wave) into
     // part buffer `par`; behind the barrier that publishes them wave 0 — one row per lane of its lower half — turns them into
-    // (mean, rstd) in statistics buffer par3 (read by that tile's epilogue, deferred or not, behind the NEXT barrier)
-    char* part_lds = scratch + TC::SCRATCH_BYTES;
+    // (mean, rstd) in statistics buffer par3 (read by that tile's epilogue, deferred or not, behind the NEXT barrier).
     // (`part_src` = p.ln_part, or — without folded LayerNorm — the A rows themselves, chosen on the host: the request is issued
-    // either way, the counted waits of a pass's first tile depend on it, and a device-side select of the two pointers ends up in
+    // either way, the counted waits of a cold start depend on it, and a device-side select of the two pointers ends up in
     // vector registers, which an "s" operand then gets unchanged)
+    char* part_lds = scratch + TC::SCRATCH_BYTES;
     const unsigned long long part_addr = (unsigned long long)(size_t)part_src;
-    const i32x4 rsrc_part = {(int)(unsigned)part_addr, (int)(unsigned)((part_addr >> 32) & 0xffff), -1, 0x00020000};
+    sa.rsrc_part = i32x4{(int)(unsigned)part_addr, (int)(unsigned)((part_addr >> 32) & 0xffff), -1, 0x00020000};
     auto part_voff_of = [&](int t) __attribute__((always_inline)) {
         int grow = t * 32 + prow;
         grow = grow < M ? grow : M - 1;
@@ -439,6 +500,12 @@ __global__ __launch_bounds__(256, 1) void gemm_h3w_kernel(const H3Params p, int 
             if (p.ln_stats && write_out && t * 32 + tid < M) *reinterpret_cast<float2*>(p.ln_stats + 2 * (size_t)(t * 32 + tid)) = ms;
         }
     };
+    // this wave's 64 KiB of the fragment-ordered W of the strip at column n0 (pack_w_h3w_kernel)
+    auto w_rsrc = [&](int n0) __attribute__((always_inline)) {
+        const unsigned long long w_addr = (unsigned long long)(size_t)p.Wp + ((size_t)(n0 >> 7) * 4 + wave) * 65536ull;
+        return i32x4{(int)(unsigned)w_addr, (int)(unsigned)((w_addr >> 32) & 0xffff), -1, 0x00020000};
+    };
+    auto strip_of = [&](int pass) __attribute__((always_inline)) { return ((pass * nb + j) / subs) * 128; };
 
     int par = 0, par3 = 0;                          // slot of the current tile; its statistics buffer (of three)
     // probes build, dbg & 16: cycle stamps of wave 0 — [0] start, [1] first barrier passed, then per tile (stream end, barrier
@@ -453,74 +520,56 @@ __global__ __launch_bounds__(256, 1) void gemm_h3w_kernel(const H3Params p, int 
         if (tid == 0) { stamps[63] = (long long)__builtin_amdgcn_s_memrealtime(); stamps[62] = 0; }
         stamp();
     }
-    // the first tile of the first pass: its requests
-#pragma unroll
-    for (int c = 0; c < 16; ++c) h3w_dma(rsrc, row_voff(t_begin), c * 128, lds_base + c * 4096 + wave * 1024);
     const unsigned part_base = lds_base + 2 * TC::SLOT + (unsigned)TC::SCRATCH_BYTES;
-    h3w_dma(rsrc_part, part_voff_of(t_begin), 0, part_base + wave * 1024);
 
     Defer defer(p, lane, wave);
     H3WNoFill nofill;
     f32x16 acc0[2][1][1], acc1[2][1][1];            // two accumulator sets: tiles alternate
+    h8 wh[32], wl[32];                              // the pass's W fragments: the 256 accumulation registers
+
+    // the first tile of the first pass: its requests (and its rows' partial statistics) into slot 0
+#pragma unroll
+    for (int c = 0; c < 16; ++c) h3w_dma(sa.rsrc, row_voff(t_begin), c * 128, lds_base + c * 4096 + wave * 1024);
+    h3w_dma(sa.rsrc_part, part_voff_of(t_begin), 0, part_base + wave * 1024);
+
+    bool pending = false;                           // a deferred epilogue waits for the next stream to ride in
+    int kset = 0;                                   // accumulator set of the next tile
     for (int pass = 0; pass < passes; ++pass) {
-        const int n0 = ((pass * nb + j) / subs) * 128;
+        const int n0 = strip_of(pass);
         if (n0 >= p.N) break;
-        const int n0_next = (((pass + 1) * nb + j) / subs) * 128;
-        const bool last_pass = pass + 1 >= passes || n0_next >= p.N;
-        if constexpr (Defer::kSupported) defer.begin_pass(n0);
-        // ---- this pass's W fragments from the fragment-ordered copy (pack_w_h3w_kernel): instruction i = 2 s + (0: lo plane,
-        // 1: hi plane) of this wave is ONE contiguous KiB, 16 B per lane — 64 KiB per wave, whole lines only.  (From the split
-        // rows themselves a lane would fetch 16 B out of 32 different rows per instruction: measured 14-16k cycles per pass
-        // against 7k.)
-        h8 wh[32], wl[32];
-        {
-            const unsigned long long w_addr = (unsigned long long)(size_t)p.Wp + ((size_t)(n0 >> 7) * 4 + wave) * 65536ull;
-            const i32x4 rsrc_w = {(int)(unsigned)w_addr, (int)(unsigned)((w_addr >> 32) & 0xffff), -1, 0x00020000};
-            const unsigned wv = (unsigned)lane * 16u;
-            int wso = 0;      // running scalar offset: + 4 KiB per two k16-steps (four instructions)
-#define H3W_LOADW(s, o)                                                                                                      \
-    asm volatile("buffer_load_dwordx4 %0, %2, %3, %4 offen offset:%5\n\tbuffer_load_dwordx4 %1, %2, %3, %4 offen offset:%6"    \
-                 : "=&a"(wl[s]), "=&a"(wh[s])                                                                                \
-                 : "v"(wv), "s"(rsrc_w), "s"(wso), "n"(o), "n"((o) + 1024)                                                   \
-                 : "memory");
-#define H3W_LOADW2(s) H3W_LOADW(s, 0) H3W_LOADW(s + 1, 2048) asm volatile("s_add_u32 %0, %0, 0x1000" : "+s"(wso)::"scc");
-#define H3W_LOADW4(s) H3W_LOADW2(s) H3W_LOADW2(s + 2)
-            H3W_LOADW4(0) H3W_LOADW4(4) H3W_LOADW4(8) H3W_LOADW4(12) H3W_LOADW4(16) H3W_LOADW4(20) H3W_LOADW4(24) H3W_LOADW4(28)
-#undef H3W_LOADW2
-#undef H3W_LOADW4
-#undef H3W_LOADW
-        }
-        if (pass == 0) {
-            // the first tile's pieces are older than the 64 W loads, and a wave cannot have more than 63 vector-memory operations
-            // outstanding: once the last W load has ISSUED the pieces have landed — in every wave behind the barrier
-            asm volatile("s_waitcnt vmcnt(63) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            stamp();
-        }
+        const bool last_pass = pass + 1 >= passes || strip_of(pass + 1) >= p.N;
+        // ---- the pass's W fragments, staged through this wave's quarter of the idle A slot (the one the previous tile has just
+        // left); the barrier behind it hands the slot back to the A requests of all waves — and, in the first pass, publishes the
+        // first tile's pieces (older than the staging requests, whose last wait is vmcnt(0))
+        h3w_stage_w(wh, wl, w_rsrc(n0), (unsigned)lane * 16u, lds_base + (par ^ 1) * TC::SLOT + wave * 16384);
+        __builtin_amdgcn_s_barrier();
+        if (pass == 0) stamp();
         // (mean, rstd) of the pass's first tile (every pass: the statistics buffers rotate)
         stats_from_lds(t_begin, par, par3, n0 == 0);
-        // one tile; K = the accumulator set it sums into (tiles alternate, so the deferred epilogue of the tile before reads
-        // the OTHER set in place — no 32-register copy per tile)
-        auto tile = [&](auto K_, int it) __attribute__((always_inline)) {
+
+        // one tile.  K = the accumulator set it sums into (tiles alternate, so the deferred epilogue of the tile before reads the
+        // OTHER set in place); FILL: that epilogue rides in this stream
+        auto tile = [&](auto K_, auto FILL_, int it) __attribute__((always_inline)) {
             constexpr int K = decltype(K_)::value;
+            constexpr bool FILL = decltype(FILL_)::value;
             const int t = t_begin + it;
             // the tile after this one: the next of the sub-range, or the first of the next pass, or (nothing left) this one again
             const int t_next = it + 1 < n_tiles ? t + 1 : (last_pass ? t : t_begin);
-            const unsigned slot_base = lds_base + par * TC::SLOT;
-            const unsigned dma_dst = lds_base + (par ^ 1) * TC::SLOT + wave * 1024;
-            const unsigned voff = row_voff(t_next);
+            sa.slot_base = lds_base + par * TC::SLOT;
+            sa.dma_dst = lds_base + (par ^ 1) * TC::SLOT + wave * 1024;
+            sa.voff = row_voff(t_next);
+            sa.part_voff = part_voff_of(t_next);
+            sa.part_dst = part_base + (par ^ 1) * TC::PART + wave * 1024;
             const int par3_next = par3 == 2 ? 0 : par3 + 1;
-            const unsigned part_voff = part_voff_of(t_next), part_dst = part_base + (par ^ 1) * TC::PART + wave * 1024;
+            // first tile of a pass: the epilogue riding in its stream (if any) still belongs to the pass before; this pass's lane
+            // constants are requested in front of the stream and taken over behind it
+            if constexpr (Defer::kSupported) { if (it == 0) defer.prefetch_pass(n0); }
             [[maybe_unused]] unsigned long long tk[8] = {};   // H3W_ABL & 16: stream begin, steps 0 / 7 / 15 / 23 / 31 issued, end
-            // the first tile of a pass runs under its W loads and carries no deferred epilogue (the last tile of the previous pass
-            // finished its own); every later tile carries the epilogue of the tile before it
-            if (it == 0) {
-                h3w_tile_stream<true>(acc0[K][0][0], acc1[K][0][0], wh, wl, slot_base, ad_lane, rsrc, voff, dma_dst, rsrc_part, part_voff, part_dst, nofill, tk);
-            } else if constexpr (Defer::kSupported) {
+            if constexpr (FILL) {
                 H3WFill<Defer> fill{defer, acc0[K ^ 1][0][0], acc1[K ^ 1][0][0]};
-                h3w_tile_stream<false>(acc0[K][0][0], acc1[K][0][0], wh, wl, slot_base, ad_lane, rsrc, voff, dma_dst, rsrc_part, part_voff, part_dst, fill, tk);
+                h3w_tile_stream(acc0[K][0][0], acc1[K][0][0], wh, wl, ad_lane, sa, fill, tk);
             } else {
-                h3w_tile_stream<false>(acc0[K][0][0], acc1[K][0][0], wh, wl, slot_base, ad_lane, rsrc, voff, dma_dst, rsrc_part, part_voff, part_dst, nofill, tk);
+                h3w_tile_stream(acc0[K][0][0], acc1[K][0][0], wh, wl, ad_lane, sa, nofill, tk);
             }
             if constexpr ((H3W_ABL & 16) != 0) {
                 if ((CMDI_DBG(p) & 16) && stamps && tid == 0 && it == 2)
@@ -532,25 +581,32 @@ __global__ __launch_bounds__(256, 1) void gemm_h3w_kernel(const H3Params p, int 
             stamp();
             // the next tile's (mean, rstd) — unless it is the first tile of the next pass, which computes its own above
             if (it + 1 < n_tiles) stats_from_lds(t_next, par ^ 1, par3_next, n0 == 0);
-            // interior tile with another tile of the pass behind it: its epilogue rides in that tile's stream; otherwise here
-            bool deferred = false;
+            if constexpr (Defer::kSupported) { if (it == 0) defer.commit_pass(); }
+            // interior tile with another stream behind it (the pass's next tile or the next pass's first): its epilogue rides
+            // there; otherwise here
+            pending = false;
             if constexpr (Defer::kSupported) {
-                if (it + 1 < n_tiles && t * 32 + 32 <= M) {
+                if ((it + 1 < n_tiles || !last_pass) && t * 32 + 32 <= M) {
                     defer.begin_tile(t * 32, scratch + par3 * 256);
-                    deferred = true;
+                    pending = true;
                 }
             }
-            if (!deferred) {
+            if (!pending) {
                 if constexpr (Defer::kSupported) defer.finish();
-                h3_epilogue<TC, EPI>(p, acc0[K], acc1[K], t * 32, n0, M, 0, scratch + par3 * 256);
+                int n0_here = n0;      // (opaque: the lane constants of this epilogue are loaded where it runs — once per block —
+                asm volatile("" : "+s"(n0_here));   //  instead of being hoisted out of the tile loop into registers every stream then carries)
+                h3_epilogue<TC, EPI>(p, acc0[K], acc1[K], t * 32, n0_here, M, 0, scratch + par3 * 256);
             }
             stamp();
             par ^= 1;
             par3 = par3_next;
+            kset = K ^ 1;
         };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
         for (int it = 0; it < n_tiles; ++it) {
-            if (it & 1) tile(std::integral_constant<int, 1>{}, it);
-            else tile(std::integral_constant<int, 0>{}, it);
+            if (kset) { if (pending) tile(I1{}, std::true_type{}, it); else tile(I1{}, std::false_type{}, it); }
+            else { if (pending) tile(I0{}, std::true_type{}, it); else tile(I0{}, std::false_type{}, it); }
         }
     }
     if ((CMDI_DBG(p) & 16) && stamps && tid == 0) stamps[62] = n_stamp;

@@ -48,7 +48,6 @@ hipError_t launch_gemm_h3p(int epi, const H3Params& p, hipStream_t stream, int a
 // gemm_h3w.hip: the weight-stationary kernel for K = 512 (tile id 60 of launch_gemm_h3; W fragments resident in the accumulation
 // registers, A streamed through LDS); same bits as the tiles above
 bool gemm_h3w_supports(int epi, const H3Params& p);
-bool gemm_h3w_wanted(int M, int N);     // tall enough for the weight-stationary kernel to win (measured; CMDI_H3W_MIN_M)
 hipError_t launch_gemm_h3w(int epi, const H3Params& p, hipStream_t stream);
 hipError_t launch_pack_w_h3w(const _Float16* w_split, _Float16* w_packed, int n, hipStream_t stream);   // [n][1024] -> fragment order
 // fp32 [rows][cols] (row stride ld_src) -> split rows [rows][2*cols] halves (format: gemm_h3.hpp)

@@ -196,6 +196,45 @@ UNET_ATTN_CASE = dict(UNET_CASE, seed=305, weight_seed=33, t=[700, 41], text_sca
 UNET_XL_CASE = dict(UNET_CASE, seed=306, weight_seed=78, dim_mults=(2, 2, 2, 2), t=[612, 27], text_scale=[2.5, 0.7], mask_prob=0.2)
 
 
+# (VERDICT r5 task 1b) the U-Net at the transformer's parity depth, by the REAL reference (make_golden_unet_long.py):
+#   long_unet  the released geometry (dim_mults (2,2,2,2): 1024 channels), B=2, ALL 1000 ancestral steps, keyframe-conditioned
+#              (obs_x0 / obs_mask) + imputation + reconstruction guidance (weight 20) on every step, run in fp32 AND float64
+#   big_unet   the same geometry and guidance at B=32 on the 'ddim100' respacing through p_sample_loop (what
+#              sample/conditional_synthesis.py calls), ragged lengths; six stored samples + float64 (sum, sum^2) of all 32
+# Noise: draw k of a chain = default_rng([seed, k]) (k = 0: x_T, k = 1 + i: step i), as the BIG cases.
+UNET_LONG_CASES = {
+    "long_unet": dict(B=2, T=196, seed=601, weight_seed=79, dim_mults=(2, 2, 2, 2), respacing=None, lengths=[196, 150],
+                      text_scale=[2.5, 2.5], trans_length=5, stop_imputation_at=1, recon_weight=20.0, stop_recguidance_at=0,
+                      every=100, f64=True),
+    "big_unet": dict(B=32, T=196, seed=602, weight_seed=79, dim_mults=(2, 2, 2, 2), respacing="ddim100", ragged=True,
+                     text_scale=[2.5] * 32, trans_length=5, stop_imputation_at=1, recon_weight=20.0, stop_recguidance_at=0,
+                     every=10, keep=(0, 7, 15, 16, 24, 31)),
+}
+
+
+def unet_long_draw(case, k: int) -> np.ndarray:
+    shape = (case["B"], N_FEATS, 1, case["T"])
+    return np.random.default_rng([case["seed"], k]).standard_normal(shape).astype(np.float32)
+
+
+def unet_long_steps(case) -> int:
+    r = case.get("respacing")
+    return 1000 if r is None else int(r[len("ddim"):])
+
+
+def make_unet_long_inputs(case: dict) -> dict:
+    rng = np.random.default_rng(case["seed"])
+    B, T = case["B"], case["T"]
+    shape = (B, N_FEATS, 1, T)
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    lengths = (rng.integers(40, T + 1, B) if case.get("ragged") else np.asarray(case["lengths"])).astype(np.int64)
+    return {"x0": f32(rng.standard_normal(shape)), "lengths": lengths,
+            "len_mask": (np.arange(T)[None, :] < lengths[:, None]).reshape(B, 1, 1, T),
+            "obs_mask": sparse_keyframe_mask(lengths, T, case["trans_length"]),
+            "enc_text": f32(rng.standard_normal((B, 512))), "text_scale": f32(case["text_scale"]),
+            "draw0": unet_long_draw(case, 0), "draw_last": unet_long_draw(case, unet_long_steps(case))}
+
+
 def make_unet_vjp_inputs(case: dict = UNET_VJP_CASE) -> dict:
     inp = make_unet_inputs(case)
     rng = np.random.default_rng(case["seed"] + 1000)

@@ -186,6 +186,52 @@ def test_persistent_gemm_keep_path_is_bitwise_the_tiled_schedule(cases, tmp_path
     assert ok("persistent_keep_path.chain", rel_l2(outs["1"]["chain_final"], load_golden("chain_edit_recon")["final"]), 1e-4)
 
 
+@pytest.mark.parametrize("m", [1, 31, 32, 33, 333, 788, 3940, 6304, 12608, 40000])
+@pytest.mark.parametrize("n", [128, 512, 1024, 1536])
+def test_gemm_h3w_is_bitwise_the_tiled_kernel(m, n):
+    """gemm_h3w.hpp (tile id 60; round 6): the weight-stationary form for K = 512 — a wave owns 32 output columns for the whole K
+    (its W fragments fill the 256 accumulation registers, read from a fragment-ordered copy of W), A streams through LDS in
+    32-row tiles, the MFMA stream is hand-issued, the epilogue of an interior tile rides in the MFMA gaps of the next tile's
+    stream — must produce the SAME BITS as the one-tile-per-block kernel (tile 8) for every epilogue: products and their
+    order per output and the epilogue arithmetic are the same, and a sample must not depend on which kernel its batch size
+    selects.  Row counts: one ragged tile, fewer tiles than XCDs, sub-ranges of 0 / 1 / several tiles, 1 - 3 passes."""
+    eng = sub("engine")
+    k = 512
+    g = torch.Generator().manual_seed(m * 7 + n)
+    a = torch.randn(m, k, generator=g).to(DEV)
+    w = (torch.randn(n, k, generator=g) * (torch.arange(n).float()[:, None] % 7 + 1) * 0.05).to(DEV)
+    b = torch.randn(n, generator=g).to(DEV)
+    r = torch.randn(m, n, generator=g).to(DEV)
+    a_s, w_s, r_s = eng.split_f16(a), eng.split_f16(w), eng.split_f16(r)
+    for epi, kw in ((0, dict(split_out=True)), (0, {}), (1, {}), (3, dict(resid=r)), (4, dict(resid=r_s))):
+        ref = eng.gemm_h3(a_s, w_s, b, tile=8, epi=epi, **kw)
+        out = eng.gemm_h3(a_s, w_s, b, tile=60, epi=epi, **kw)
+        assert torch.equal(out, ref), (m, n, epi, kw.keys())
+    ref64 = a.double() @ w.double().T + b.double()
+    assert ok("gemm_h3w_is_bitwise_the_tiled_kernel.rel_l2.0", rel_l2(eng.gemm_h3(a_s, w_s, b, tile=60).cpu().numpy(), ref64.cpu().numpy()), 2e-6)
+
+
+def test_weight_stationary_schedule_is_bitwise_the_tiled_schedule(cases, tmp_path):
+    """CMDI_H3W=1 routes every K = 512 GEMM of the engine whose launch has at least CMDI_H3W_MIN_M rows to gemm_h3w — with the
+    fragment-ordered weight copies packed at cmdi_finalize_weights, the folded LayerNorms (ln_part through LDS-DMA, ln_c1, ln_rg,
+    out_part, ln_stats), the stash (aux) and the backward GEMMs (GELU-gradient and residual epilogues on the packed transposes).
+    Forced on the small goldens (MIN_M = 1; subprocesses: the switches are read when an engine is created): forward with stash,
+    input-VJP and a reconstruction-guidance chain must equal the tiled schedule BIT FOR BIT."""
+    import os
+    import subprocess
+    import sys
+    helper = str(__import__("pathlib").Path(__file__).resolve().parent / "helpers" / "persist_probe.py")
+    outs = {}
+    for mode in ("0", "1"):
+        path = tmp_path / f"h3w{mode}.npz"
+        env = dict(os.environ, CMDI_H3W=mode, CMDI_H3W_MIN_M="1")
+        r = subprocess.run([sys.executable, helper, str(path)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[mode] = np.load(path)
+    for key in ("vjp_out", "vjp_gx", "chain_final"):
+        assert np.array_equal(outs["0"][key], outs["1"][key]), key
+
+
 def test_attention_split_schedule_is_bitwise_identical(tmp_path):
     """Round 4: below half a chip of (sequence, head) pairs the attention core runs as two 4-wave blocks per pair
     (attention_h3.hip launch_attention_h3).  A sample must not depend on the schedule its batch size selects: forced off,
@@ -849,6 +895,39 @@ def test_c4_c5_shape_chains_vs_reference(cases, name, precision):
 
 
 C4C5_PARTS = {256: 2, 128: 2}     # engine pipelines at these batch sizes (api_sampler.hip n_parts), as observed
+
+
+@pytest.mark.parametrize("name", ["c4_ddim_long", "c4_ddpm_long"])
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_baseline_config4_full_100_step_chain_vs_reference(cases, name, precision):
+    """BASELINE config 4 END TO END (VERDICT r5 task 1a): B=256 x 196 frames on the 'ddim100' respacing, text CFG, ragged lengths,
+    ALL 100 steps from pure noise — once through ddim_sample_loop (eta 0; reference gaussian_diffusion.py:1454-1587) and once
+    through p_sample_loop on the respaced chain (what the sample scripts call) — through the one-call path at M = 2 x 50,432 rows
+    per evaluation (two pipelines; the persistent / weight-stationary GEMM routes of that height), against the REAL reference's
+    CPU chains (make_golden_big.py c4_ddim_long / c4_ddpm_long, ~25 min each): six stored samples, float64 (sum, sum^2) of all
+    256, and sample 0's x_t every 10 steps on the way (per-step generator, default precision)."""
+    case, inp, g, model, diffusion, kw = big_setup(cases, name, precision)
+    loop = diffusion.ddim_sample_loop if case["sampler"] == "ddim" else diffusion.p_sample_loop
+    final = loop(model, inp["draw0"].shape, **kw)
+    eng = model.model._engine
+    assert eng.pipeline_parts() == C4C5_PARTS[case["B"]], eng.pipeline_parts()
+    final = final.cpu().numpy()
+    keep = list(case["keep"])
+    err = rel_l2(final[keep], g["final"])
+    per = [rel_l2(final[k], g["final"][i]) for i, k in enumerate(keep)]
+    print(json_line({"case": name, "precision": precision, "rel_l2": err, "per_sample": per}))
+    assert np.isfinite(final).all()
+    assert ok("baseline_config4_full_chain.rel_l2", err, 1e-4) and ok("baseline_config4_full_chain.per_sample", max(per), 2e-4), (err, per)
+    assert ok("baseline_config4_full_chain.stats", stats_err(cases.sample_stats(final), g["stats"]), 2e-4)
+    if precision == PRECISIONS[0]:
+        prog = diffusion.ddim_sample_loop_progressive if case["sampler"] == "ddim" else diffusion.p_sample_loop_progressive
+        at = {int(i): k for k, i in enumerate(g["dump_at"])}
+        last = None
+        for i, out in enumerate(prog(model, inp["draw0"].shape, **kw)):
+            last = out["sample"]
+            if i in at:
+                assert ok("baseline_config4_full_chain.on_the_way", rel_l2(last[:1].cpu().numpy(), g["dumps"][at[i]]), 1e-4), i
+        assert np.array_equal(last.cpu().numpy(), final)
 
 
 @pytest.mark.parametrize("name", ["synthesize", "edit", "conditional_synthesis"])

@@ -358,6 +358,73 @@ def test_attention_backward_isa_audit(tmp_path):
     assert re.search(r"(\d+) hand-issued LDS loads, 0 violations", a.stdout) and int(re.search(r"(\d+) hand-issued", a.stdout).group(1)) >= 64
 
 
+def test_weight_stationary_gemm_isa_audit(tmp_path):
+    """csrc/gemm_h3w.hpp hand-issues the whole MFMA stream of a tile (inline asm): fragment reads two steps ahead of the MFMAs
+    that consume them under COUNTED waits, LDS-DMA requests on a running M0, W fragments as "a"-constrained operands filling the
+    accumulation file.  hipcc sees none of it.  Compile the unit to gfx950 ISA and check what the design relies on:
+      * no compiler-generated instruction touches a register between the asm fragment read that writes it and the asm MFMA that
+        consumes it (a copy or a spill there would move data that has not landed; the compiler may — and does — use a ring
+        register as a temporary once its MFMA has issued);
+      * nothing outside the asm statements touches an accumulation register (no v_accvgpr_* shuffles of the resident W fragments)
+        or M0 (the requests of a stream advance it in place);
+      * no scratch access inside a stream, 512 registers at most, every kernel has its 96-MFMA streams."""
+    import shutil
+    import subprocess
+    from pathlib import Path
+    from conftest import PKG
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(hipcc).exists():
+        pytest.skip("hipcc not available")
+    src = REPO / PKG / "csrc" / "gemm_h3w.hip"
+    out = tmp_path / "gemm_h3w.s"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fno-gpu-rdc", "-I", str(src.parent),
+                        "-S", "--cuda-device-only", "-o", str(out), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = out.read_text()
+
+    def vregs(tok):
+        found = set()
+        for m in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", tok):
+            found |= set(range(int(m.group(1)), int(m.group(2)) + 1)) if m.group(1) else {int(m.group(3))}
+        return found
+
+    kernels = re.findall(r"^(_ZN4cmdi15gemm_h3w_kernelILi\d+EEEvNS_8H3ParamsEiiPKf):[^\n]*\n(.*?)\n\s*s_endpgm", text, re.S | re.M)
+    assert len(kernels) == 5, [k for k, _ in kernels]
+    for name, body in kernels:
+        in_asm, in_stream, flying, n_mfma, n_streams = False, False, set(), 0, 0
+        for raw in body.split("\n"):
+            line = raw.strip()
+            if line.startswith(";;#ASMSTART"):
+                in_asm = True
+                continue
+            if line.startswith(";;#ASMEND"):
+                in_asm = False
+                continue
+            code = line.split(";")[0].strip()
+            if not code or code.endswith(":") or code.startswith("."):
+                continue
+            if in_asm:
+                if re.match(r"ds_read_b128 v\[", code):
+                    in_stream = True                          # (the four reads in front of step 0 open a stream)
+                    flying |= vregs(code.split(",")[0])       # in flight until an MFMA statement takes it as an operand
+                if code.startswith("v_mfma"):
+                    assert in_stream, (name, code)
+                    n_mfma += 1
+                    flying -= vregs(code.split(",", 1)[1])
+                if code.startswith("s_nop 7") and in_stream:   # the closing statement of a stream
+                    assert not flying, (name, "fragment read never consumed", sorted(flying))
+                    in_stream = False
+                    n_streams += 1
+                continue
+            assert not re.search(r"\ba\[?\d", code) and "accvgpr" not in code, (name, "accumulation register outside asm", code)
+            assert not re.search(r"\bm0\b", code), (name, "M0 outside asm", code)
+            if in_stream:
+                assert not code.startswith("scratch_"), (name, "scratch access inside a stream", code)
+                assert not (vregs(code) & flying), (name, "compiler code touches a fragment register whose read is in flight", code)
+        assert n_streams >= 2 and n_mfma == 96 * n_streams, (name, n_streams, n_mfma)
+    assert max(int(v) for v in re.findall(r"; TotalNumVgprs: (\d+)", text)) <= 512
+
+
 def test_no_undefined_names_in_bench_and_package():
     """A module-level constant deleted by an edit shows up only when its line runs — on the GPU box (round 4: `N_XCD` vanished
     from bench.py with a neighbouring function and the roofline leg died there).  Static check: every name loaded anywhere in
