@@ -204,11 +204,10 @@ __device__ __forceinline__ ProbOp prob_operand(const float* x) {
     ProbOp o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        float pv = x[e] * kProbScale;
-        asm volatile("" : "+v"(pv));
-        const _Float16 a = (_Float16)pv;
+        _Float16 a, r;
+        split_f16_unscaled(x[e] * kProbScale, a, r);          // (gemm_h3.hpp: pinned — the product must not reach the conversions)
         o.h[e] = a;
-        o.l[e] = (_Float16)(pv - (float)a);
+        o.l[e] = r;
     }
     o.s = o.h * (_Float16)kLoInv;   // packed f16 multiply: exact (power of two) above 2^-14
     return o;

@@ -252,10 +252,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const _Float16
             h8 ph, pl, ps;   // p_hi (round to nearest), p - p_hi (unscaled), p_hi * 2^-11
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float pvv = s[8 * kk + e];
-                const _Float16 a = (_Float16)pvv;
+                _Float16 a, b;
+                split_f16_unscaled(s[8 * kk + e], a, b);      // (gemm_h3.hpp: the one pinned split of an unscaled operand)
                 ph[e] = a;
-                pl[e] = (_Float16)(pvv - (float)a);
+                pl[e] = b;
             }
             ps = ph * (_Float16)kLoInv;   // packed f16 multiply: exact (power of two) above 2^-14
             h8 vh[4], vl[4];

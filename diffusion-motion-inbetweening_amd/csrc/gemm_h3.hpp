@@ -62,6 +62,16 @@ __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
     lo = (_Float16)((x - (float)hi) * kLoScale);
 }
 
+// The same for an operand that needs no lo-scaling (attention probabilities, 0 <= x <= 2^8): hi = f16(x), rest = f16(x - hi).
+// EVERY split of a computed value goes through one of these two helpers — the pin is what keeps hi and its remainder on the
+// same rounding of x (rounds 2 and 5 each found a hand-rolled split whose product hipcc had contracted into the conversions);
+// tests/test_host_logic.py::test_split_conversions_are_pinned scans the compiled ISA for v_fma_mix*_f16 outside a whitelist.
+__device__ __forceinline__ void split_f16_unscaled(float x, _Float16& hi, _Float16& rest) {
+    asm volatile("" : "+v"(x));
+    hi = (_Float16)x;
+    rest = (_Float16)(x - (float)hi);
+}
+
 // Output stores carry `sc1` (device scope: written through the XCD's L2 instead of parked there as dirty lines).  The
 // outputs of these GEMMs (26-78 MB) are never re-read by the kernel that writes them, and as dirty L2 lines they evict the
 // weight panel every block of that XCD re-reads: measured at C2 (in-run counters of the in_proj GEMM) 187 -> 162 MB of L2

@@ -2060,6 +2060,95 @@ def test_unet_recon_guidance_chain_vs_reference(cases, precision):
     assert ok("unet_recon_guidance_chain_vs_reference.rel_l2.0", rel_l2(final, g["final"]), 2e-4), rel_l2(final, g["final"])
 
 
+def unet_long_setup(cases, name, precision):
+    """The released U-Net geometry on the native engine + the call the reference made for tests/golden/<name>.npz
+    (make_golden_unet_long.py): p_sample_loop through ClassifierFreeSampleModel(MDM_UNET), keyframe conditioning (obs_x0 /
+    obs_mask), imputation + reconstruction guidance (weight 20) on every step, injected noise."""
+    mu = sub("utils.model_util")
+    case = cases.UNET_LONG_CASES[name]
+    inp = cases.make_unet_long_inputs(case)
+    g = load_golden(name)
+    assert np.array_equal(g["fingerprint"], cases.fingerprint(inp)), f"inputs of {name} drifted"
+    args = SimpleNamespace(dataset="humanml", arch="unet", keyframe_conditioned=True, dim_mults=case["dim_mults"], cond_mask_prob=0.1)
+    model, _ = mu.create_model_and_diffusion(args, None)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert sorted(shapes) == list(g["names"]), "state-dict names differ from the reference's MDM_UNET"
+    mu.load_model_wo_clip(model, weights.to_torch(weights.fill_like(shapes, case["weight_seed"])) |
+                          {k: v for k, v in model.state_dict().items() if k.endswith(".pe")})
+    model = model.to(DEV).eval()
+    model.native_precision = precision
+    wrapped = sub("model.cfg_sampler").ClassifierFreeSampleModel(model)
+    gd, rs = sub("diffusion.gaussian_diffusion"), sub("diffusion.respace")
+    diffusion = rs.SpacedDiffusion(rs.space_timesteps(1000, case.get("respacing") or [1000]),
+                                   gd.DiffusionConfig(betas=gd.get_named_beta_schedule("cosine", 1000)))
+    n = diffusion.num_timesteps
+    assert n == cases.unet_long_steps(case)
+    if name not in _BIG_NOISE:
+        noise = torch.empty((n,) + inp["draw0"].shape, dtype=torch.float32, device=DEV)
+        for k in range(n):
+            noise[k].copy_(torch.from_numpy(cases.unet_long_draw(case, 1 + k)))
+        _BIG_NOISE.clear()
+        _BIG_NOISE[name] = noise
+    diffusion.injected_noise = _BIG_NOISE[name]
+    obs_mask = tt(inp["obs_mask"])
+    y = {"mask": tt(inp["len_mask"]), "lengths": tt(inp["lengths"]), "text_embed": tt(inp["enc_text"]),
+         "text_scale": tt(inp["text_scale"]), "inpainting_mask": obs_mask, "inpainted_motion": tt(inp["x0"]),
+         "imputate": True, "stop_imputation_at": case["stop_imputation_at"], "replacement_distribution": "conditional",
+         "reconstruction_guidance": True, "reconstruction_weight": case["recon_weight"], "gradient_schedule": None,
+         "stop_recguidance_at": case["stop_recguidance_at"], "diffusion_steps": 1000}
+    kw = dict(noise=tt(inp["draw0"]), clip_denoised=False, model_kwargs={"y": y, "obs_x0": tt(inp["x0"]), "obs_mask": obs_mask})
+    return case, inp, g, wrapped, diffusion, kw
+
+
+@pytest.mark.parametrize("precision", UNET_PRECISIONS)
+def test_unet_baseline_batch_guided_chain_vs_reference(cases, precision):
+    """VERDICT r5 task 1b: the U-Net at the bench's batch — released geometry (1024 channels), B=32, ragged lengths, all 100 steps
+    of p_sample_loop on 'ddim100' (what sample/conditional_synthesis.py calls) with keyframe conditioning, imputation and
+    reconstruction guidance on every step (forward AND input-VJP of csrc/unet.hip at M = 64 x 224 rows per evaluation) — vs the
+    REAL reference's CPU chain (make_golden_unet_long.py big_unet; model/mdm_unet.py:561-849, gaussian_diffusion.py:405-435):
+    six stored samples, float64 (sum, sum^2) of all 32, sample 0's x_t every 10 steps on the way."""
+    name = "big_unet"
+    case, inp, g, wrapped, diffusion, kw = unet_long_setup(cases, name, precision)
+    at = {int(i): k for k, i in enumerate(g["dump_at"])}
+    last, on_the_way = None, 0.0
+    for i, out in enumerate(diffusion.p_sample_loop_progressive(wrapped, inp["draw0"].shape, **kw)):
+        last = out["sample"]
+        if i in at:
+            on_the_way = max(on_the_way, rel_l2(last[:1].cpu().numpy(), g["dumps"][at[i]]))
+    final = last.cpu().numpy()
+    keep = list(case["keep"])
+    err = rel_l2(final[keep], g["final"])
+    per = [rel_l2(final[k], g["final"][i]) for i, k in enumerate(keep)]
+    print(json_line({"case": name, "precision": precision, "rel_l2": err, "per_sample": per, "on_the_way": on_the_way}))
+    assert np.isfinite(final).all()
+    assert ok("unet_big_chain.rel_l2", err, 2e-4) and ok("unet_big_chain.per_sample", max(per), 4e-4), (err, per)
+    assert ok("unet_big_chain.on_the_way", on_the_way, 2e-4), on_the_way
+    assert ok("unet_big_chain.stats", stats_err(cases.sample_stats(final), g["stats"]), 4e-4)
+    one_call = diffusion.p_sample_loop(wrapped, inp["draw0"].shape, **kw).cpu().numpy()
+    assert ok("unet_big_chain.per_step_vs_one_call", rel_l2(one_call, final), 1e-6), rel_l2(one_call, final)
+
+
+@pytest.mark.parametrize("precision", UNET_PRECISIONS)
+def test_unet_long_chain_drift_vs_reference(cases, precision):
+    """VERDICT r5 task 1b: the U-Net's full chain — released geometry, B=2, ALL 1000 ancestral steps, keyframe conditioning +
+    imputation + reconstruction guidance (weight 20) on every step — against the reference's fp32 chain AND the same chain run
+    by the reference in float64 (ground truth): every precision mode must land no further from the truth than 2 x the
+    reference's own fp32 arithmetic does (its distance is in the golden), the yardstick the transformer's long chains meet."""
+    name = "long_unet"
+    if "final_f64" not in load_golden(name).files:
+        pytest.skip("long_unet.npz without the float64 chain")
+    case, inp, g, wrapped, diffusion, kw = unet_long_setup(cases, name, precision)
+    final = diffusion.p_sample_loop(wrapped, inp["draw0"].shape, **kw).cpu().numpy()
+    assert np.isfinite(final).all()
+    ref32, ref64 = g["final"], g["final_f64"]
+    d_ref = rel_l2(ref32, ref64)
+    d32, d64 = rel_l2(final, ref32), rel_l2(final, ref64)
+    print(json_line({"case": name, "precision": precision, "vs_fp32": d32, "vs_f64": d64, "reference_fp32_vs_f64": d_ref}))
+    assert ok("unet_long_chain.vs_fp32", d32, 2e-4), d32
+    assert ok("unet_long_chain.vs_f64", d64, 2e-4), d64
+    assert d64 <= 2.0 * d_ref + 1e-6, (d64, d_ref)
+
+
 def test_keyframes_mask_built_on_device(cases):
     """get_keyframes_mask with device inputs: built on the device (no per-sample host loop), bit-exact vs the reference."""
     eu = sub("utils.editing_util")

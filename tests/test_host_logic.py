@@ -425,6 +425,56 @@ def test_weight_stationary_gemm_isa_audit(tmp_path):
     assert max(int(v) for v in re.findall(r"; TotalNumVgprs: (\d+)", text)) <= 512
 
 
+def test_split_conversions_are_pinned(tmp_path):
+    """the defect of round 2 (GELU epilogue) and of round 5 (attention backward's P operand) was the same
+    compiler behaviour — hipcc contracts a PRODUCT that feeds a hi / lo split into the f16 conversions (v_fma_mixlo_f16 /
+    v_fma_mixhi_f16), so hi and lo come from different roundings of the value.  split_f16 / split_f16_unscaled (gemm_h3.hpp)
+    pin the value with an empty asm; this test makes the convention a fact of the compiled code: every v_fma_mix*_f16 in the
+    product's ISA must belong to a whitelisted kernel, with the whitelisted count, in the benign form (a value times a scalar
+    constant plus literal zero: the power-of-two scale of a lo plane or of a gradient, exact in fp32, rounded once)."""
+    import shutil
+    import subprocess
+    from concurrent.futures import ThreadPoolExecutor
+    from pathlib import Path
+    from conftest import PKG
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(hipcc).exists():
+        pytest.skip("hipcc not available")
+    csrc = REPO / PKG / "csrc"
+    units = {"elementwise": [], "gemm_h3": [], "gemm_h3p": [], "gemm_h3w": ["-fno-slp-vectorize"], "attention_h3": [],
+             "attention_bwd_h3": [], "unet": [], "clip_text": []}      # every unit that writes split rows
+
+    def compile_unit(item):
+        name, extra = item
+        out = tmp_path / f"{name}.s"
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-gpu-rdc", *extra, "-I", str(csrc), "-S",
+                            "--cuda-device-only", "-o", str(out), str(csrc / f"{name}.hip")], capture_output=True, text=True)
+        assert r.returncode == 0, (name, r.stderr[-1500:])
+        return name, out.read_text()
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        texts = dict(ex.map(compile_unit, units.items()))
+    # kernel (substring of the mangled name) -> instructions allowed: the power-of-two scale sites
+    allowed = {"token0_kernel": 1,                 # condition token: hi / lo of a sum, lo scaled by 2^11
+               "unet_output_bwd_kernel": 1,        # gradient rows scaled by the power-of-two gradient scale
+               "gemm_h3w_kernelILi1E": 32,         # deferred epilogue, lo = f16((x - hi) * 2^11) of a PINNED x (GELU split)
+               "gemm_h3w_kernelILi3E": 32}         # ... (plain split)
+    seen = {}
+    for name, text in texts.items():
+        fn = None
+        for line in text.split("\n"):
+            m = re.match(r"^(_Z\w+):", line)
+            if m:
+                fn = m.group(1)
+            code = line.split(";")[0].strip()
+            if code.startswith("v_fma_mix") and "_f16" in code.split()[0]:
+                key = next((k for k in allowed if fn and k in fn), None)
+                assert key is not None, (name, fn, code)
+                assert re.search(r",\s*s\d+,\s*0(\s+op_sel.*)?$", code), (name, fn, "not value x scalar + 0", code)
+                seen[key] = seen.get(key, 0) + 1
+    assert seen == allowed, (seen, allowed)
+
+
 def test_no_undefined_names_in_bench_and_package():
     """A module-level constant deleted by an edit shows up only when its line runs — on the GPU box (round 4: `N_XCD` vanished
     from bench.py with a neighbouring function and the roofline leg died there).  Static check: every name loaded anywhere in
