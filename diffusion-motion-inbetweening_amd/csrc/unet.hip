@@ -407,6 +407,81 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
     }
 }
 
+// GroupNorm backward in ONE pass (round 6, VERDICT r5 task 5): one block per (sequence, group) holds the group's F and dY values
+// in registers (7 float4 each per thread at 1,024 threads: 224 frames x 128 channels), reduces mean(g) and mean(g xhat) over
+// the block and writes dF — F and dY are read ONCE instead of twice (the two kernels above re-read 2 x 58 MB per level-0 site)
+// and a GroupNorm backward is one launch instead of two.  g / xhat are recomputed in the second half (one Mish' per value:
+// VALU under an HBM-rate kernel) rather than kept (56 more registers at 16 waves per CU).  Sums in another order than the
+// chunked pair (per-thread, wave, then waves in order): pinned by the same reference tolerances; the pair stays as the
+// fallback for geometries that do not fit and as the specification (CMDI_UNET_GNB1=0).
+template <int NT>
+__global__ __launch_bounds__(NT) void gn_bwd_fused_kernel(const float* __restrict__ dy, int ld_dy, int nsl_dy, size_t sl_dy,
+                                                          const float* __restrict__ f, int nsl, size_t sl,
+                                                          const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ ss, int ss_ld,
+                                                          _Float16* __restrict__ out, int C, int Tp, int h, int Tv, int x6) {
+    __shared__ float red[2 * (NT / 64)];
+    constexpr int MAXV = GNF_MAXV * 256 / NT;
+    const int seq = blockIdx.x, g = blockIdx.y, cg = C / NG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float mean = stats[((size_t)seq * NG + g) * 2], rstd = stats[((size_t)seq * NG + g) * 2 + 1];
+    const int q4 = cg / 4, total = Tv * q4;
+    const size_t row0 = (size_t)seq * Tp + h;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 fv[MAXV], dv[MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        const int i = tid + NT * k;
+        if (i < total) {
+            const int r = i / q4, c = g * cg + (i - r * q4) * 4;
+            const size_t row = row0 + r;
+            fv[k] = load_slices(f + row * C + c, nsl, sl);
+            dv[k] = load_slices(dy + row * ld_dy + c, nsl_dy, sl_dy);   // (split-K slices of the producing GEMM)
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        const int i = tid + NT * k;
+        if (i < total) {
+            const int c = g * cg + (i % q4) * 4;
+            const float4 ga = *reinterpret_cast<const float4*>(gamma + c), be = *reinterpret_cast<const float4*>(beta + c);
+            const float4 sc = ss ? *reinterpret_cast<const float4*>(ss + (size_t)seq * ss_ld + c) : zero;
+            const float4 sh = ss ? *reinterpret_cast<const float4*>(ss + (size_t)seq * ss_ld + C + c) : zero;
+            float xh[4], gg[4];
+            gn_bwd_terms(fv[k], dv[k], mean, rstd, ga, be, sc, sh, ss != nullptr, xh, gg);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s1 += gg[e]; s2 += gg[e] * xh[e]; }
+        }
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0) { red[wave] = s1; red[NT / 64 + wave] = s2; }
+    __syncthreads();
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < NT / 64; w += 4) {
+        m1 += (red[w] + red[w + 1]) + (red[w + 2] + red[w + 3]);
+        m2 += (red[NT / 64 + w] + red[NT / 64 + w + 1]) + (red[NT / 64 + w + 2] + red[NT / 64 + w + 3]);
+    }
+    const float n = (float)(Tv * cg);
+    m1 /= n; m2 /= n;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        const int i = tid + NT * k;
+        if (i >= total) continue;
+        const int r = i / q4, c = g * cg + (i - r * q4) * 4;
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + c), be = *reinterpret_cast<const float4*>(beta + c);
+        const float4 sc = ss ? *reinterpret_cast<const float4*>(ss + (size_t)seq * ss_ld + c) : zero;
+        const float4 sh = ss ? *reinterpret_cast<const float4*>(ss + (size_t)seq * ss_ld + C + c) : zero;
+        float xh[4], gg[4];
+        gn_bwd_terms(fv[k], dv[k], mean, rstd, ga, be, sc, sh, ss != nullptr, xh, gg);
+        const float d4[4] = {rstd * (gg[0] - m1 - xh[0] * m2), rstd * (gg[1] - m1 - xh[1] * m2),
+                             rstd * (gg[2] - m1 - xh[2] * m2), rstd * (gg[3] - m1 - xh[3] * m2)};
+        bool unused = false;     // (gradients carry no range flag)
+        store_act4(out, row0 + r, 2 * C, c, d4, x6, unused);
+    }
+}
+
 // gout [nseq, J, T] -> split rows [nseq * Tp, 2 * Np] (frames T..223 and channels J.. are zero), times the power-of-two
 // gradient scale (common.hpp grad_scale_from_bits) that parks the chain mid-range of f16
 __global__ __launch_bounds__(256) void unet_output_bwd_kernel(const float* __restrict__ gout, _Float16* __restrict__ rows,
@@ -577,6 +652,7 @@ struct UnetModel {
     // the convolution over frames only on the persistent kernel and GroupNorm as one pass, no fusion is the fastest
     // (B=32, same box, alternating: 0: 7.50-7.52, 1: 7.51-7.53, 2: 7.53-7.58, 3: 7.59 ms/step) -> default 0
     int fuse_gn = 0;
+    int gn_bwd_one_pass = 1;   // CMDI_UNET_GNB1: GroupNorm backward as one register-resident pass (gn_bwd_fused_kernel)
     int gn_one_pass = 2;  // CMDI_UNET_GN1: GroupNorm as one register-resident pass (gn_fused_kernel) instead of statistics + apply:
                           // 1 = 256 threads per (sequence, group) (bitwise the two kernels), 2 = 1,024 threads (7.76 -> 7.57 ms/step)
     int persist = 2;      // CMDI_UNET_PERSIST: 1 = long-K convolutions on the persistent GEMM (conv_rows), 2 = ... over frames only
@@ -742,6 +818,7 @@ UnetModel* unet_new(int n_feats, int added, int dim, const int mults[4], int max
     if (const char* v = std::getenv("CMDI_UNET_FUSE_GN")) u->fuse_gn = std::atoi(v);
     if (const char* v = std::getenv("CMDI_UNET_PERSIST")) u->persist = std::atoi(v);
     if (const char* v = std::getenv("CMDI_UNET_GN1")) u->gn_one_pass = std::atoi(v);
+    if (const char* v = std::getenv("CMDI_UNET_GNB1")) u->gn_bwd_one_pass = std::atoi(v);
     u->C[0] = n_feats + added;
     for (int i = 0; i < 4; ++i) u->C[i + 1] = dim * mults[i];
     u->Cin0p = (u->C[0] + 31) / 32 * 32;
@@ -1152,6 +1229,12 @@ int gn_bwd(UnetModel* u, const float* dy, int ld_dy, const float* f, int nsl, co
     const Lvl L = lvl(level);
     const int C = u->C[1];
     const size_t sl = (size_t)nseq * L.Tp * C;
+    if (u->gn_bwd_one_pass && L.Tv * (C / NG / 4) <= 256 * GNF_MAXV) {   // CMDI_UNET_GNB1=0: the two kernels below
+        hipLaunchKernelGGL(gn_bwd_fused_kernel<1024>, dim3(nseq, NG), dim3(1024), 0, s, dy, ld_dy, nsl_dy, sl, f, nsl, sl, stats, n.g,
+                           n.b, ss, u->ss_ld, u->GS[level], C, L.Tp, L.h, L.Tv, u->x6 ? 1 : 0);
+        UCHK(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(nseq, NG, GNB_CHUNKS), dim3(256), 0, s, dy, ld_dy, nsl_dy, sl, f, nsl, sl, stats,
                        n.g, n.b, ss, u->ss_ld, u->bsums, C, L.Tp, L.h, L.Tv);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((L.Tv + 3) / 4, nseq), dim3(256), 0, s, dy, ld_dy, nsl_dy, sl, f, nsl, sl, stats, u->bsums,

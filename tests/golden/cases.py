@@ -208,7 +208,7 @@ UNET_LONG_CASES = {
                       every=100, f64=True),
     "big_unet": dict(B=32, T=196, seed=602, weight_seed=79, dim_mults=(2, 2, 2, 2), respacing="ddim100", ragged=True,
                      text_scale=[2.5] * 32, trans_length=5, stop_imputation_at=1, recon_weight=20.0, stop_recguidance_at=0,
-                     every=10, keep=(0, 7, 15, 16, 24, 31)),
+                     every=10, keep=(0, 7, 15, 16, 24, 31), f64_rows=(0, 7)),
 }
 
 

@@ -54,8 +54,14 @@ def build(case, dtype):
     return wrapped, diffusion, sorted(shapes)
 
 
-def run(case, inp, dtype):
+def run(case, inp, dtype, rows=None):
+    """rows: run only these samples of the case's batch (samples are independent — GroupNorm is per sample — and the noise
+    draws are sliced from the full-batch draws, so the chain of sample i is the one it has inside the full batch)."""
     wrapped, diffusion, names = build(case, dtype)
+    if rows is not None:
+        inp = {k: (v[list(rows)] if getattr(v, "shape", ()) and v.shape[0] == case["B"] else v) for k, v in inp.items()}
+        case = dict(case, B=len(rows))
+    sel = (lambda a: a[list(rows)]) if rows is not None else (lambda a: a)
     cast = (lambda a: t(a).to(dtype)) if dtype != torch.float32 else t
     ref_shims.set_text_embedding(cast(inp["enc_text"]))
     obs_mask = t(inp["obs_mask"])
@@ -66,7 +72,8 @@ def run(case, inp, dtype):
          "stop_recguidance_at": case["stop_recguidance_at"], "diffusion_steps": 1000}
     n = diffusion.num_timesteps
     assert n == cases.unet_long_steps(case)
-    stream = (cast(cases.unet_long_draw(case, 1 + k)) for k in range(n))
+    full = cases.UNET_LONG_CASES[case["name"]] if "name" in case else case
+    stream = (cast(sel(cases.unet_long_draw(full, 1 + k))) for k in range(n))
     every, dumps, final = case["every"], {}, None
     t0 = time.time()
     with ref_shims.injected_noise(stream):
@@ -83,10 +90,26 @@ def run(case, inp, dtype):
 
 def main():
     torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", 0)) or os.cpu_count() or 1)
-    for name in sys.argv[1:] or list(cases.UNET_LONG_CASES):
+    only_rows = "--f64-rows-only" in sys.argv       # add the float64 rows to an existing <case>.npz (keeps its fp32 chain)
+    for name in [a for a in sys.argv[1:] if not a.startswith("--")] or list(cases.UNET_LONG_CASES):
         case = cases.UNET_LONG_CASES[name]
         inp = cases.make_unet_long_inputs(case)
         print(f"== {name}", flush=True)
+        if only_rows:
+            old = dict(np.load(HERE / f"{name}.npz"))
+            assert np.array_equal(old["fingerprint"], cases.fingerprint(inp))
+            rows = list(case["f64_rows"])
+            f64, d64, _ = run(dict(case, name=name), inp, torch.float64, rows=rows)
+            old["f64_rows"] = np.asarray(rows, dtype=np.int64)
+            old["final_f64_rows"] = f64.astype(np.float32)
+            old["dumps_f64"] = np.stack([d64[i][:1] for i in sorted(d64)]).astype(np.float32)
+            keep = list(case["keep"])
+            for j, r in enumerate(rows):
+                ref32 = old["final"][keep.index(r)].astype(np.float64)
+                print(f"  {name}: sample {r}: reference fp32 vs float64 chain rel-L2 "
+                      f"{np.linalg.norm(ref32 - f64[j]) / np.linalg.norm(f64[j]):.3e}", flush=True)
+            np.savez_compressed(HERE / f"{name}.npz", **old)
+            continue
         final, dumps, names = run(case, inp, torch.float32)
         keep = list(case.get("keep", range(case["B"])))
         out = {"fingerprint": cases.fingerprint(inp), "final": final[keep], "stats": cases.sample_stats(final),
@@ -98,6 +121,16 @@ def main():
             out["dumps_f64"] = np.stack([d64[i][:1] for i in sorted(d64)]).astype(np.float32)
             err = np.linalg.norm(final.astype(np.float64) - f64) / np.linalg.norm(f64)
             print(f"  {name}: reference fp32 vs float64 chain rel-L2 {err:.3e}", flush=True)
+        if case.get("f64_rows"):
+            # the float64 ground truth of a FEW samples of the batch (the whole batch in float64 would take hours)
+            rows = list(case["f64_rows"])
+            f64, d64, _ = run(dict(case, name=name), inp, torch.float64, rows=rows)
+            out["f64_rows"] = np.asarray(rows, dtype=np.int64)
+            out["final_f64_rows"] = f64.astype(np.float32)
+            out["dumps_f64"] = np.stack([d64[i][:1] for i in sorted(d64)]).astype(np.float32)     # first of the rows
+            for j, r in enumerate(rows):
+                err = np.linalg.norm(final[r].astype(np.float64) - f64[j]) / np.linalg.norm(f64[j])
+                print(f"  {name}: sample {r}: reference fp32 vs float64 chain rel-L2 {err:.3e}", flush=True)
         path = HERE / f"{name}.npz"
         np.savez_compressed(path, **out)
         print(f"wrote {path.name}: {os.path.getsize(path) / 1024:.0f} KiB", flush=True)

@@ -1243,6 +1243,12 @@ def test_cond_fn_chain_vs_reference(cases, name, precision):
     assert ok("cond_fn_chain_vs_reference.rel_l2.0", rel_l2(final, g["final"]), 1e-4), rel_l2(final, g["final"])
     for k, d in enumerate(dumps):
         assert ok("cond_fn_chain_vs_reference.rel_l2.1", rel_l2(d.cpu().numpy(), g["pred_xstart"][k]), 1e-4), (k, rel_l2(d.cpu().numpy(), g["pred_xstart"][k]))
+    # is the chain's distance from the reference (1.3e-5 ... 2.0e-5 at step 1) rounding or a defect?  The
+    # chain's own sensitivity answers it: two runs of THIS engine whose x_T differ by one fp32 ulp (6e-8 relative) end this far apart
+    moved = loop(model, inp["x_T"].shape, **dict(kw, noise=torch.nextafter(kw["noise"], torch.full_like(kw["noise"], float("inf"))))).cpu().numpy()
+    sens = rel_l2(moved, final)
+    print(json_line({"case": name, "precision": precision, "vs_reference": rel_l2(final, g["final"]), "one_ulp_of_x_T": sens}))
+    assert rel_l2(final, g["final"]) <= 25.0 * sens + 2e-6, (rel_l2(final, g["final"]), sens)
     # the guidance is not a no-op: the unguided chain on the same noise ends elsewhere
     plain = loop(model, inp["x_T"].shape, **{k: v for k, v in kw.items() if k not in ("cond_fn", "cond_fn_with_grad")})
     assert rel_l2(plain.cpu().numpy(), g["final"]) > 1e-2
@@ -1991,6 +1997,19 @@ def test_unet_xl_geometry_vs_reference(cases, precision):
     got = got.cpu().numpy()
     assert float(np.abs(got[inp["obs_mask"]]).max()) == 0.0          # observed entries are replaced by obs_x0
     assert ok("unet_xl.vjp", rel_l2(got, g["gx"]), 5e-5), rel_l2(got, g["gx"])
+    # VERDICT r5 task 1c: against the FLOAT64 evaluation of the reference (make_golden_unet_xl.py) every precision mode must sit
+    # within 2 x the distance the reference's own fp32 arithmetic has from it — forward and input-VJP, whole tensor AND per frame
+    # row of the gradient (round 5's method: a defect confined to a few rows hides behind a whole-tensor norm)
+    fwd = out.detach().cpu().numpy()
+    d_fwd, d_vjp = rel_l2(fwd, g["out_cfg_f64"]), rel_l2(got, g["gx_f64"])
+    r_fwd, r_vjp = rel_l2(g["out_cfg"], g["out_cfg_f64"]), rel_l2(g["gx"], g["gx_f64"])
+    rows = lambda a, b: np.sqrt(((a.astype(np.float64) - b) ** 2).sum(axis=(1, 2)) / (b.astype(np.float64) ** 2).sum(axis=(1, 2)).mean())
+    worst, worst_ref = float(rows(got, g["gx_f64"]).max()), float(rows(g["gx"], g["gx_f64"]).max())
+    print(json_line({"case": "unet_xl", "precision": precision, "fwd_vs_f64": d_fwd, "reference_fwd_vs_f64": r_fwd, "vjp_vs_f64": d_vjp,
+                     "reference_vjp_vs_f64": r_vjp, "vjp_worst_frame_row": worst, "reference_worst_frame_row": worst_ref}))
+    assert ok("unet_xl.fwd_vs_f64", d_fwd, 2e-5) and d_fwd <= 2.0 * r_fwd + 2e-7, (d_fwd, r_fwd)
+    assert ok("unet_xl.vjp_vs_f64", d_vjp, 5e-5) and d_vjp <= 2.0 * r_vjp + 2e-7, (d_vjp, r_vjp)
+    assert worst <= 2.5 * worst_ref + 1e-6, (worst, worst_ref)
 
 
 @pytest.mark.parametrize("B,T,keyframe,cfg", [(3, 100, True, False), (1, 224, False, True), (2, 33, True, True)])
@@ -2058,6 +2077,14 @@ def test_unet_recon_guidance_chain_vs_reference(cases, precision):
                                     model_kwargs={"y": y, "obs_x0": tt(ci["x0"]), "obs_mask": obs_mask}).cpu().numpy()
     assert np.isfinite(final).all()
     assert ok("unet_recon_guidance_chain_vs_reference.rel_l2.0", rel_l2(final, g["final"]), 2e-4), rel_l2(final, g["final"])
+    # VERDICT r5 weak #1 (2.6e-5 / 3.0e-5 after six steps, 10 x the transformer's guided chain, in BOTH precisions): the chain's own
+    # sensitivity — x_T moved by one fp32 ulp — says how much of that is the problem's conditioning (GroupNorm + Mish on an
+    # untrained net under guidance weight 20; profiles/r06_unet_guided_chain_attribution.md)
+    moved = diffusion.p_sample_loop(wrapped, ci["x_T"].shape, noise=one_ulp_up(tt(ci["x_T"])), clip_denoised=False,
+                                    model_kwargs={"y": y, "obs_x0": tt(ci["x0"]), "obs_mask": obs_mask}).cpu().numpy()
+    sens = rel_l2(moved, final)
+    print(json_line({"case": "unet_recon_chain", "precision": precision, "vs_reference": rel_l2(final, g["final"]), "one_ulp_of_x_T": sens}))
+    assert rel_l2(final, g["final"]) <= 25.0 * sens + 2e-6, (rel_l2(final, g["final"]), sens)
 
 
 def unet_long_setup(cases, name, precision):
@@ -2100,32 +2127,50 @@ def unet_long_setup(cases, name, precision):
     return case, inp, g, wrapped, diffusion, kw
 
 
+def one_ulp_up(x):
+    return torch.nextafter(x, torch.full_like(x, float("inf")))
+
+
 @pytest.mark.parametrize("precision", UNET_PRECISIONS)
 def test_unet_baseline_batch_guided_chain_vs_reference(cases, precision):
     """VERDICT r5 task 1b: the U-Net at the bench's batch — released geometry (1024 channels), B=32, ragged lengths, all 100 steps
     of p_sample_loop on 'ddim100' (what sample/conditional_synthesis.py calls) with keyframe conditioning, imputation and
     reconstruction guidance on every step (forward AND input-VJP of csrc/unet.hip at M = 64 x 224 rows per evaluation) — vs the
-    REAL reference's CPU chain (make_golden_unet_long.py big_unet; model/mdm_unet.py:561-849, gaussian_diffusion.py:405-435):
-    six stored samples, float64 (sum, sum^2) of all 32, sample 0's x_t every 10 steps on the way."""
+    REAL reference's CPU chain (make_golden_unet_long.py big_unet; model/mdm_unet.py:561-849, gaussian_diffusion.py:405-435).
+
+    What the comparison can mean (profiles/r06_unet_guided_chain_attribution.md): on these random weights the guided chain is
+    CHAOTIC over its last ~40 steps — the reference's own fp32 chain ends 1.0e-1 / 3.5e-3 (samples 0 / 7) from the same chain
+    run by the reference in float64, and moving x_T by ONE fp32 ulp moves this engine's own result by 2e-3 ... 1.2e-1.  So:
+      * the stable window (steps <= 60, where the chain does not amplify): the usual tight bound against the reference;
+      * the final samples: the distance from the reference, per sample, against that sample's OWN sensitivity — the distance
+        between two runs of this engine whose x_T differ by one ulp.  Rounding differences are amplified like that ulp (measured
+        ratio 1-5); a defect worth 100 x the rounding error would be amplified to 100 x the ulp's effect;
+      * the two samples the reference also ran in float64: no further from the truth than 10 x the larger of the reference's own
+        fp32 distance and the one-ulp sensitivity."""
     name = "big_unet"
     case, inp, g, wrapped, diffusion, kw = unet_long_setup(cases, name, precision)
     at = {int(i): k for k, i in enumerate(g["dump_at"])}
-    last, on_the_way = None, 0.0
+    last, stable = None, 0.0
     for i, out in enumerate(diffusion.p_sample_loop_progressive(wrapped, inp["draw0"].shape, **kw)):
         last = out["sample"]
-        if i in at:
-            on_the_way = max(on_the_way, rel_l2(last[:1].cpu().numpy(), g["dumps"][at[i]]))
+        if i in at and i < 60:
+            stable = max(stable, rel_l2(last[:1].cpu().numpy(), g["dumps"][at[i]]))
     final = last.cpu().numpy()
-    keep = list(case["keep"])
-    err = rel_l2(final[keep], g["final"])
-    per = [rel_l2(final[k], g["final"][i]) for i, k in enumerate(keep)]
-    print(json_line({"case": name, "precision": precision, "rel_l2": err, "per_sample": per, "on_the_way": on_the_way}))
     assert np.isfinite(final).all()
-    assert ok("unet_big_chain.rel_l2", err, 2e-4) and ok("unet_big_chain.per_sample", max(per), 4e-4), (err, per)
-    assert ok("unet_big_chain.on_the_way", on_the_way, 2e-4), on_the_way
-    assert ok("unet_big_chain.stats", stats_err(cases.sample_stats(final), g["stats"]), 4e-4)
-    one_call = diffusion.p_sample_loop(wrapped, inp["draw0"].shape, **kw).cpu().numpy()
-    assert ok("unet_big_chain.per_step_vs_one_call", rel_l2(one_call, final), 1e-6), rel_l2(one_call, final)
+    assert ok("unet_big_chain.stable_window", stable, 2e-5), stable
+    moved = diffusion.p_sample_loop(wrapped, inp["draw0"].shape, **dict(kw, noise=one_ulp_up(kw["noise"]))).cpu().numpy()
+    keep = list(case["keep"])
+    report = {}
+    for i, k in enumerate(keep):
+        err, sens = rel_l2(final[k], g["final"][i]), rel_l2(moved[k], final[k])
+        report[k] = {"vs_reference": err, "one_ulp_of_x_T": sens}
+        assert err <= 10.0 * sens + 1e-5, (k, err, sens)
+    for j, r in enumerate(g["f64_rows"]):
+        r = int(r)
+        mine, ref = rel_l2(final[r], g["final_f64_rows"][j]), rel_l2(g["final"][keep.index(r)], g["final_f64_rows"][j])
+        report[r].update(vs_f64=mine, reference_fp32_vs_f64=ref)
+        assert mine <= 10.0 * max(ref, report[r]["one_ulp_of_x_T"]) + 1e-5, (r, mine, ref)
+    print(json_line({"case": name, "precision": precision, "stable_window": stable, "final": report}))
 
 
 @pytest.mark.parametrize("precision", UNET_PRECISIONS)

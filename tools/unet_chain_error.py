@@ -36,3 +36,18 @@ for name in sys.argv[1:] or ["big_unet"]:
                     row["reference_fp32_vs_f64"] = rel(g["dumps"][at[i]], g["dumps_f64"][at[i]])
                 rows.append(row)
         print(json.dumps({"case": name, "precision": precision, "sample0": rows}))
+        # the chain's own sensitivity: the same engine, x_T moved by ONE fp32 ulp — how far apart do two runs of the SAME arithmetic end?
+        final = diffusion.p_sample_loop(wrapped, inp["draw0"].shape, **kw).cpu().numpy()
+        kw2 = dict(kw, noise=torch.nextafter(kw["noise"], torch.full_like(kw["noise"], float("inf"))))
+        final2 = diffusion.p_sample_loop(wrapped, inp["draw0"].shape, **kw2).cpu().numpy()
+        keep = list(case.get("keep", range(case["B"])))
+        per = {int(k): {"vs_reference_fp32": rel(final[k], g["final"][i]), "one_ulp_of_x_T": rel(final2[k], final[k])} for i, k in enumerate(keep)}
+        if "f64_rows" in g.files:
+            for j, r in enumerate(g["f64_rows"]):
+                per[int(r)]["vs_f64"] = rel(final[int(r)], g["final_f64_rows"][j])
+                per[int(r)]["reference_fp32_vs_f64"] = rel(g["final"][keep.index(int(r))], g["final_f64_rows"][j])
+        elif "final_f64" in g.files:
+            for k in keep:
+                per[int(k)]["vs_f64"] = rel(final[k], g["final_f64"][k])
+                per[int(k)]["reference_fp32_vs_f64"] = rel(g["final"][keep.index(k)], g["final_f64"][k])
+        print(json.dumps({"case": name, "precision": precision, "final_per_sample": per}))
