@@ -82,13 +82,19 @@ __device__ __forceinline__ h8 tr_pair(const char* p0, const char* p1) {
 // [Vᵀ·Pᵀ of the previous stage, K·Qᵀ, softmax] inside a barrier interval where the leading group runs [K·Qᵀ, softmax,
 // Vᵀ·Pᵀ]: one group's softmax falls under the other's products.  The ring then keeps the previous stage alive, so the
 // look-ahead is NS - 2 stages instead of NS - 1.  STAG = 1: waves NW/2.. lag; STAG = 2: odd waves lag.
-template <bool STASH, int NW = NWAVE, int NS = NSTG, int STAG = 0>
+// PERSIST (round 6): gridDim.x blocks walk the n_items (sequence, head) pairs — block x takes the contiguous range
+// [n_items x / gridDim.x, n_items (x + 1) / gridDim.x) — instead of one block per pair.  At B >= 128 a CU is handed 8-32 pairs
+// one after the other; as separate blocks each pays its dispatch and runs its load burst (Q + the first K/V stages) with nothing
+// else on the CU, and its store tail likewise.  Inside one block the next pair's requests are issued right behind the
+// epilogue's LDS read-back (one barrier: the ring is every wave's staging area), so they travel under the previous pair's
+// output stores; a wave runs the same instruction sequence per pair: the same bits.
+template <bool STASH, int NW = NWAVE, int NS = NSTG, int STAG = 0, bool PERSIST = false>
 __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const _Float16* __restrict__ qkv,
                                                               float* __restrict__ out,
                                                               _Float16* __restrict__ out_s,
                                                               int* __restrict__ range_flag,
                                                               float* __restrict__ row_stats, int S,
-                                                              int H, float scale, int dbg_arg, long head_rows) {
+                                                              int H, float scale, int dbg_arg, long head_rows, int n_items) {
 #ifdef CMDI_PROBES
     const int dbg = dbg_arg;   // bench-only ablations / cycle stamps (probes build only, see gemm_h3.hpp)
 #else
@@ -97,10 +103,13 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const _Float16
     extern __shared__ __attribute__((aligned(16))) char lds[];  // [2][K tile | V tile]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int bh = blockIdx.x, b = bh / H, h = bh % H;
-    const int d_model = H * DH;
     long long t0 = 0, t1 = 0, t2 = 0;
     if (dbg & 16) t0 = __builtin_readcyclecounter();
+    const int item0 = PERSIST ? (int)((long)n_items * blockIdx.x / gridDim.x) : (int)blockIdx.x;
+    const int item1 = PERSIST ? (int)((long)n_items * (blockIdx.x + 1) / gridDim.x) : (int)blockIdx.x + 1;
+    for (int bh = item0; bh < item1; ++bh) {
+    const int b = bh / H, h = bh % H;
+    const int d_model = H * DH;
     // token-major qkv: row = token, 6 d halves, q | k | v column blocks.  head_rows > 0: HEAD-major (written so by the
     // in_proj epilogue, gemm_params.hpp cs_head_major): operand w of head h is its own [head_rows][256-half] matrix, so
     // the K / V of a (sequence, head) are one contiguous 100-KB stream each instead of 512-B pieces 6 KiB apart
@@ -368,6 +377,12 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const _Float16
             }
         }
     }
+    if constexpr (PERSIST) {
+        // the next pair's first stages go into the ring every wave has just used as its output staging area
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    }   // (sequence, head) pairs of this block
     if constexpr (!STASH) {
         if ((dbg & 16) && row_stats && tid == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -377,31 +392,31 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_h3_kernel(const _Float16
     }
 }
 
-template <int NW, int NS, int STAG = 0>
+template <int NW, int NS, int STAG = 0, bool PERSIST = false>
 static hipError_t launch_attention_h3_cfg(const _Float16* qkv_split, float* out, _Float16* out_split, int* range_flag,
                                           float* row_stats, int n_seq, int S, int H, int dbg, long head_rows,
-                                          hipStream_t stream) {
-    dim3 grid(n_seq * H, (S + 32 * NW - 1) / (32 * NW));
+                                          hipStream_t stream, int blocks = 0) {
+    dim3 grid(PERSIST ? blocks : n_seq * H, (S + 32 * NW - 1) / (32 * NW));
     const float scale = 1.0f / sqrtf((float)DH);
     constexpr size_t lds_ring = (size_t)NS * STAGE, lds_epi = (size_t)NW * 32 * 528;   // K/V ring | output rows (epilogue)
     constexpr size_t lds = lds_ring > lds_epi ? lds_ring : lds_epi;
     static PerDevice<bool> attr_done_dev;
     bool& attr_done = attr_done_dev.get();
     if (!attr_done) {
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_h3_kernel<true, NW, NS, STAG>),
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_h3_kernel<true, NW, NS, STAG, PERSIST>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_h3_kernel<false, NW, NS, STAG>),
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_h3_kernel<false, NW, NS, STAG, PERSIST>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e1 != hipSuccess) return e1;
         if (e2 != hipSuccess) return e2;
         attr_done = true;
     }
     if (row_stats && !(dbg & 16))
-        hipLaunchKernelGGL((attention_h3_kernel<true, NW, NS, STAG>), grid, dim3(64 * NW), lds, stream, qkv_split,
-                           out, out_split, range_flag, row_stats, S, H, scale, dbg, head_rows);
+        hipLaunchKernelGGL((attention_h3_kernel<true, NW, NS, STAG, PERSIST>), grid, dim3(64 * NW), lds, stream, qkv_split,
+                           out, out_split, range_flag, row_stats, S, H, scale, dbg, head_rows, n_seq * H);
     else
-        hipLaunchKernelGGL((attention_h3_kernel<false, NW, NS, STAG>), grid, dim3(64 * NW), lds, stream, qkv_split,
-                           out, out_split, range_flag, row_stats, S, H, scale, dbg, head_rows);
+        hipLaunchKernelGGL((attention_h3_kernel<false, NW, NS, STAG, PERSIST>), grid, dim3(64 * NW), lds, stream, qkv_split,
+                           out, out_split, range_flag, row_stats, S, H, scale, dbg, head_rows, n_seq * H);
     return hipGetLastError();
 }
 
@@ -446,6 +461,16 @@ hipError_t launch_attention_h3(const _Float16* qkv_split, float* out, _Float16* 
     if (stag == 2)
         return launch_attention_h3_cfg<NWAVE, NSTG, 2>(qkv_split, out, out_split, range_flag, row_stats, n_seq, S, H, dbg, head_rows, stream);
 #endif
+    // many pairs per CU (B >= 64 with CFG): one persistent block per CU walks its share — built and measured in round 6
+    // (profiles/r06_attention_persistent.txt): at C4 (2,048 pairs) the kernel takes 296 us against 280 us for one block per pair
+    // (the hardware hands a CU its next block as fast as the loop does, and the loop costs a barrier, 16 spilled row pointers per
+    // pair and the serialisation of one pair's store tail with the next pair's Q loads), the step 14.38 vs 14.36 ms.  Off by
+    // default; CMDI_ATTN_PERSIST=1 selects it (bitwise the default: test_attention_persistent_schedule_is_bitwise_identical).
+    static const int persist_env = std::getenv("CMDI_ATTN_PERSIST") ? std::atoi(std::getenv("CMDI_ATTN_PERSIST")) : 0;
+    const int cus_p = device_cu_count();
+    if (persist_env && S > 128 && S <= 256 && (long)n_seq * H >= 2L * cus_p && !(dbg & 16))
+        return launch_attention_h3_cfg<NWAVE, NSTG, kAttnStagDefault, true>(qkv_split, out, out_split, range_flag, row_stats, n_seq, S, H, dbg,
+                                                                        head_rows, stream, cus_p);
     return launch_attention_h3_cfg<NWAVE, NSTG, kAttnStagDefault>(qkv_split, out, out_split, range_flag, row_stats, n_seq, S, H, dbg, head_rows, stream);
 }
 

@@ -256,6 +256,28 @@ def test_attention_split_schedule_is_bitwise_identical(tmp_path):
         assert np.array_equal(outs["0"][key], outs[None][key]), key
 
 
+def test_attention_persistent_schedule_is_bitwise_identical(tmp_path):
+    """Round 6: with at least two (sequence, head) pairs per CU the attention core runs as ONE persistent block per CU that walks
+    its share of the pairs (attention_h3.hip PERSIST: the next pair's first requests travel under the previous pair's output
+    stores) instead of one block per pair.  A wave runs the same instruction sequence per pair in both: forced off and on
+    must give the same bits — pairs split unevenly over the blocks (532 on 256), S = 197 and S = 150; the batches below the
+    threshold take the one-block-per-pair kernel either way."""
+    import os
+    import subprocess
+    import sys
+    helper = str(__import__("pathlib").Path(__file__).resolve().parent / "helpers" / "attn_split_probe.py")
+    outs = {}
+    for mode in ("0", "1"):
+        path = tmp_path / f"persist{mode}.npz"
+        env = dict(os.environ, CMDI_ATTN_PERSIST=mode)
+        r = subprocess.run([sys.executable, helper, str(path)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[mode] = np.load(path)
+    for key in ("small", "big", "many", "many_short"):
+        assert np.isfinite(outs["1"][key]).all()
+        assert np.array_equal(outs["0"][key], outs["1"][key]), key
+
+
 # ---- bf16x6: exact three-plane bf16 operands, six MFMA products (fp32-class, no operand truncation) -----------------
 def test_pack_x6_is_exact():
     """W = p0 + p1 + p2 EXACTLY for every finite binary32 (24 significant bits = three bf16 mantissas), over the whole
