@@ -666,6 +666,10 @@ def main():
                    "step_frac_of_pipe_peak": flop_step / (e2 / K) / 1e12 / (F16_MFMA_PEAK_TFLOPS / 6.0 if prec == "bf16x6" else FP32_MFMA_PEAK_TFLOPS),
                    "max_abs_diff_vs_default": float((x2 - x_default).abs().max()),
                    "rel_l2_vs_default": float((x2 - x_default).norm() / x_default.norm())}
+            if is_unet and cfg["edit"]:
+                # the guided U-Net chain on random weights amplifies rounding by ~10 x per 10 steps (one fp32 ulp of x_T moves the
+                # result by 1e-3 ... 1e-1: profiles/r06_unet_guided_chain_attribution.md) — the two legs' samples say that, not parity
+                leg["vs_default_note"] = "chaotic chain on random weights: not a parity figure (see tests: one-ulp sensitivity)"
             if not args.no_roofline and not is_unet:
                 timed2 = timed_launches(eng2, loop2)
                 pmc2 = pmc_counters(args.config, prec, B, timed=timed2) if (want_pmc and prec == "f32") else {}

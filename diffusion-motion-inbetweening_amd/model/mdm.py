@@ -273,6 +273,16 @@ class MDM(nn.Module):
         if self._engine is not None:
             self._engine.check_range()
 
+    def range_certificate(self, **assumptions) -> dict:
+        """Weight-only bounds on every tensor the default precision carries as split f16 (utils/range_certificate.py): whether
+        ANY input inside the stated assumptions (x_bound, text_l2_bound, n_frames) can reach the f16 range guard, and by how many
+        bits not.  trans_enc only; host-side, no device work."""
+        if self.arch != 'trans_enc':
+            raise NotImplementedError("range_certificate covers arch='trans_enc' (see utils/range_certificate.py for why)")
+        from ..utils.range_certificate import trans_enc_range_certificate
+        sd = {k: v for k, v in self.state_dict().items() if not k.startswith('clip_model.')}
+        return trans_enc_range_certificate(sd, **assumptions)
+
     def range_fallback(self) -> bool:
         """After a RangeError of the default (f16x3) engine: switch this module to bf16x6 for good and report whether a
         retry makes sense (False if the caller pinned a precision or the fallback is already active)."""

@@ -596,3 +596,77 @@ def test_bare_bench_command_line_with_gpus_2_launches_its_own_ranks():
         line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
         assert line["world"] == 2 and line["ranks_summed"] == 2 and line["n_gpus"] == 2, line
         assert line["global_batch"] == batch and line["shards"] == [[0, batch // 2], [batch // 2, batch]], line
+
+
+def test_range_certificate_bounds_every_split_tensor_of_the_oracle_forward(monkeypatch):
+    """utils/range_certificate.py: weight-only bounds on the tensors the f16x3 engine carries as split f16.  (1) For seeded
+    weights and inputs at the edge of the assumptions (|x| = x_bound everywhere with random signs, one-hot outliers, a CLIP
+    feature on the 2-norm bound, several timesteps) every intermediate of the oracle's forward — observed through its own
+    _linear / _layernorm calls — stays below the certificate's bound for that tensor.  (2) Weights scaled until activations
+    CAN leave the f16 range are not certified.  (3) The bound does not depend on the data: LayerNorm outputs obey it for
+    adversarial pre-norm rows of any scale."""
+    import oracle.mdm_oracle as mo
+    from oracle import weights
+    rc = sub("utils.range_certificate")
+    sd = weights.make_state_dict(17, text=True)
+    T, X, E = 60, 16.0, 32.0
+    cert = rc.trans_enc_range_certificate(sd, x_bound=X, text_l2_bound=E, n_frames=T)
+    assert cert["certified"] and cert["headroom_bits"] > 1.0, cert["tensors"]
+    seen = {}
+    real_linear, real_ln = mo._linear, mo._layernorm
+
+    def note(name, a):
+        seen[name] = max(seen.get(name, 0.0), float(np.abs(a).max()))
+
+    def spy_linear(x, w, b=None):
+        y = real_linear(x, w, b)
+        shape = tuple(np.asarray(w).shape)
+        d = sd["input_process.poseEmbedding.weight"].shape[0]
+        if shape == (3 * d, d):
+            note("qkv", y)
+            note("attention", y[..., 2 * d:])          # the attention output is a convex combination of these rows
+        elif shape == (sd["seqTransEncoder.layers.0.linear1.weight"].shape[0], d):
+            note("ffn_hidden", mo._gelu(y))
+        return y
+
+    def spy_ln(x, g, b):
+        out = real_ln(x, g, b)
+        key = "pre_norm1" if spy_ln.calls % 2 == 0 else "pre_norm2"
+        note(key, x)
+        note("norm1" if spy_ln.calls % 2 == 0 else "norm2", out[0])
+        spy_ln.calls += 1
+        return out
+    spy_ln.calls = 0
+    monkeypatch.setattr(mo, "_linear", spy_linear)
+    monkeypatch.setattr(mo, "_layernorm", spy_ln)
+    m = mo.MDMOracle(sd)
+    rng = np.random.default_rng(5)
+    B = 4
+    xs = [np.where(rng.random((B, 263, 1, T)) < 0.5, -X, X).astype(np.float32),
+          (rng.standard_normal((B, 263, 1, T)) * 3).clip(-X, X).astype(np.float32)]
+    spike = np.zeros((B, 263, 1, T), np.float32)
+    spike[:, rng.integers(0, 263, 8), 0, :] = X
+    xs.append(spike)
+    for x in xs:
+        enc = rng.standard_normal((B, 512))
+        enc = (enc / np.linalg.norm(enc, axis=1, keepdims=True) * E).astype(np.float32)
+        for uncond in (False, True):
+            tok = m._tokens(x, np.array([0, 1, 500, 999]), enc, uncond)
+            note("tokens", tok)
+            m.forward(x, np.array([0, 1, 500, 999]), enc, uncond=uncond)
+    assert set(seen) == set(cert["tensors"]) - {"frames"}, (sorted(seen), sorted(cert["tensors"]))
+    print({k: (round(v, 2), round(cert["tensors"][k], 2)) for k, v in seen.items()})
+    for name, value in seen.items():
+        assert value <= cert["tensors"][name], (name, value, cert["tensors"][name])
+        assert value >= cert["tensors"][name] / 400.0, (name, value, cert["tensors"][name])   # a bound, not a blank cheque
+    # (2) a checkpoint that can overflow is not certified: the FFN's first GEMM scaled 3000 x
+    big = dict(sd)
+    for l in range(8):
+        big[f"seqTransEncoder.layers.{l}.linear1.weight"] = sd[f"seqTransEncoder.layers.{l}.linear1.weight"] * np.float32(3000.0)
+    bad = rc.trans_enc_range_certificate(big, x_bound=X, text_l2_bound=E, n_frames=T)
+    assert not bad["certified"] and bad["headroom_bits"] < 0 and bad["max_bound"] > 65504.0
+    # (3) the LayerNorm lemma behind it: |xhat_i| <= sqrt(d - 1), ||xhat||_2 <= sqrt(d) for rows of any scale / any outlier
+    d = 512
+    rows = np.concatenate([rng.standard_normal((64, d)) * 10.0 ** rng.integers(-6, 7, (64, 1)), np.eye(d)[:8] * 1e6], axis=0)
+    xhat = (rows - rows.mean(1, keepdims=True)) / np.sqrt(rows.var(1, keepdims=True) + 1e-5)
+    assert np.abs(xhat).max() <= np.sqrt(d - 1) + 1e-9 and np.linalg.norm(xhat, axis=1).max() <= np.sqrt(d) + 1e-9
