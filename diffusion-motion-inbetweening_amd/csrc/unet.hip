@@ -655,6 +655,7 @@ struct UnetModel {
     int gn_bwd_one_pass = 1;   // CMDI_UNET_GNB1: GroupNorm backward as one register-resident pass (gn_bwd_fused_kernel)
     int gn_one_pass = 2;  // CMDI_UNET_GN1: GroupNorm as one register-resident pass (gn_fused_kernel) instead of statistics + apply:
                           // 1 = 256 threads per (sequence, group) (bitwise the two kernels), 2 = 1,024 threads (7.76 -> 7.57 ms/step)
+    int persist_bwd = 1;  // CMDI_UNET_PERSIST_BWD=0: the gradient GEMMs stay on the tiled kernel (round 6 A/B)
     int persist = 2;      // CMDI_UNET_PERSIST: 1 = long-K convolutions on the persistent GEMM (conv_rows), 2 = ... over frames only
     int m_fast = 0;      // CMDI_UNET_MFAST: tile order of the convolution GEMMs (gemm_params.hpp)
     int big_tile = 0;    // CMDI_UNET_TILE: gemm_h3 tile id for the long-K convolutions that are not split
@@ -817,6 +818,7 @@ UnetModel* unet_new(int n_feats, int added, int dim, const int mults[4], int max
     // both GroupNorm schedules (separate kernels / fused epilogue) are complete and parity-tested
     if (const char* v = std::getenv("CMDI_UNET_FUSE_GN")) u->fuse_gn = std::atoi(v);
     if (const char* v = std::getenv("CMDI_UNET_PERSIST")) u->persist = std::atoi(v);
+    if (const char* v = std::getenv("CMDI_UNET_PERSIST_BWD")) u->persist_bwd = std::atoi(v);
     if (const char* v = std::getenv("CMDI_UNET_GN1")) u->gn_one_pass = std::atoi(v);
     if (const char* v = std::getenv("CMDI_UNET_GNB1")) u->gn_bwd_one_pass = std::atoi(v);
     u->C[0] = n_feats + added;
@@ -1219,6 +1221,18 @@ int grad_gemm(UnetModel* u, const _Float16* a, int a_ld, const _Float16* w, int 
     if (resid) { kind = H3_RESID; p.R = resid; p.r_ld = r_ld; p.C = out_f; p.Cs = out_s; }
     else if (out_s) { kind = H3_PLAIN_SPLIT; p.Cs = out_s; p.aux = out_f; }
     else { kind = H3_PLAIN; p.C = out_f; }
+    // round 6: the long-K gradient GEMMs with a plain fp32 output (the k=5 convolutions' input gradients) take the forward's
+    // route — persistent kernel, frames only — under the same size rule (conv_rows): same bits as the tiled kernel
+    if (!tile && kind == H3_PLAIN && u->persist && u->persist_bwd && p.ksplit <= 1 && p.K >= 1536 && N % 256 == 0 && ldc == N &&
+        (long)((M + 127) / 128) * (N / 256) >= 224 && gemm_h3p_supports(kind, p)) {
+        tile = 50;
+        if (u->persist >= 2 && a_mul <= 1 && !c_mul && M % lo.Tp == 0) {
+            H3Params q = p;
+            q.rc_tv = lo.Tv;
+            q.M = M / lo.Tp * lo.Tv;
+            if (gemm_h3p_supports(kind, q)) p = q;
+        }
+    }
     UCHK(launch_gemm_h3(kind, p, tile, s));
     return 0;
 }

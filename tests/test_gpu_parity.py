@@ -1937,6 +1937,44 @@ def test_unet_groupnorm_one_pass_is_the_two_kernel_groupnorm(cases, monkeypatch)
     assert ok("unet_groupnorm_one_pass.rel_l2", rel_l2(outs["2"], g["out_cfg"]), 2e-5)
 
 
+def test_unet_gradient_gemms_on_the_persistent_kernel_are_bitwise_the_tiled_route(cases, monkeypatch):
+    """Round 6: at the bench's batch the long-K gradient GEMMs of the U-Net's input-VJP (the k=5 convolutions' input gradients
+    at levels 0 and 1: M = 64 x Tp rows, K = 5,120) take the forward's route — persistent kernel over frames only.  Same
+    products in the same order: the input gradient of the released geometry at B=32 must equal the tiled route's
+    (CMDI_UNET_PERSIST_BWD=0) bit for bit, and the forward output with it."""
+    mu = sub("utils.model_util")
+    case = cases.UNET_XL_CASE
+    B, T = 32, 196
+    rng = np.random.default_rng(4242)
+    shape = (B, 263, 1, T)
+    x, obs, gout = (rng.standard_normal(shape).astype(np.float32) for _ in range(3))
+    m = rng.random(shape) < 0.2
+    enc = rng.standard_normal((B, 512)).astype(np.float32)
+    t = rng.integers(0, 1000, B)
+    sc = np.full(B, 2.5, np.float32)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CMDI_UNET_PERSIST_BWD", mode)
+        args = SimpleNamespace(dataset="humanml", arch="unet", keyframe_conditioned=True, dim_mults=case["dim_mults"], cond_mask_prob=0.1)
+        model, _ = mu.create_model_and_diffusion(args, None)
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        mu.load_model_wo_clip(model, weights.to_torch(weights.fill_like(shapes, case["weight_seed"])) |
+                              {k: v for k, v in model.state_dict().items() if k.endswith(".pe")})
+        model = model.to(DEV).eval()
+        wrapped = sub("model.cfg_sampler").ClassifierFreeSampleModel(model)
+        z = tt(x).requires_grad_(True)
+        with torch.enable_grad():
+            out = wrapped(z, tt(t), y={"text_embed": tt(enc), "text_scale": tt(sc)}, obs_x0=tt(obs), obs_mask=tt(m))
+            gx, = torch.autograd.grad((out * tt(gout)).sum(), z)
+        res[mode] = (out.detach().cpu().numpy(), gx.cpu().numpy())
+        model.invalidate_engine()
+        del model, wrapped
+        torch.cuda.empty_cache()
+    assert np.isfinite(res["1"][1]).all() and float(np.abs(res["1"][1]).max()) > 0.0
+    assert np.array_equal(res["0"][0], res["1"][0])
+    assert np.array_equal(res["0"][1], res["1"][1]), float(np.abs(res["0"][1] - res["1"][1]).max())
+
+
 @pytest.mark.parametrize("scale,expect", [(4000.0, "f16x3"), (60000.0, "bf16x6"), (60000.0, "pinned")])
 def test_unet_real_scale_activations_and_range_probe(cases, scale, expect, monkeypatch):
     """MDM_UNET's range story.  The reference's U-Net is plain fp32 at any activation scale (model/mdm_unet.py:561-849); the
