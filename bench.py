@@ -680,7 +680,8 @@ def main():
     # hipGraph replay vs eager launches of the same K steps (VERDICT r3 task 6; SURVEY 8d asks config 4 for step latency with
     # and without hipGraph, through ddim_sample_loop AND p_sample_loop on the 'ddim100' respacing).  The engine replays the
     # schedule it runs eagerly: pipeline parts on their own streams, one graph per (part, kind).
-    if rank == 0 and world == 1 and not is_unet and not args.no_graph_leg and args.precision is None:
+    # (round 6: the U-Net configs too — its embedding kernel reads the step's timestep from the chain's device table)
+    if rank == 0 and world == 1 and not args.no_graph_leg and args.precision is None:
         legs = {}
         kinds = ("ddim", "ddpm") if args.config == "c4" else (cfg["sampler"],)
         model.native_precision = main_prec     # (pinned: with None, engine() would hand back the f32 engine of the leg above)

@@ -282,7 +282,7 @@ int mdm_forward(cmdi_engine* e, const float* x, const int64_t* t_dev, int64_t t_
     const int n_seq = e->cfg ? 2 * B : B;
     if (e->unet) {   // MDM_UNET.forward (model/mdm_unet.py:766-849)
         HIPCHK(launch_unet_emb(e->uemb, e->time_table, e->have_text ? e->text_term : nullptr, t_dev, t_scalar,
-                               n_seq, B, d, e->n_time_rows, s));
+                               n_seq, B, d, e->n_time_rows, s, tables ? e->tmap_dev : nullptr, tables ? e->cursor_dev : nullptr));
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         int mnk[3] = {0, 0, 0};
         if (e->profile) {   // bench: HIP events around one level-0 convolution GEMM per evaluation

@@ -539,8 +539,9 @@ int cmdi_sample_loop(cmdi_handle e, int32_t sampler, int32_t first_step, int32_t
         return fail(CMDI_E_INVALID, "need n_steps > first_step >= last_step >= 0");
     if (!d_x) return fail(CMDI_E_INVALID, "null tensor");
     // graph replay: of the pipelined schedule where the batch is cut into parts (each part's steps on its own stream),
-    // else of the single-stream step
-    if (e->use_graph && !d_noise_stream && !e->profile && !e->unet && !(e->pipelines && n_parts(e) > 1))
+    // else of the single-stream step (round 6: MDM_UNET too — its embedding kernel reads the timestep from the chain's device
+    // table like token0_kernel; ~300 launches per evaluation, ~900 per guided step)
+    if (e->use_graph && !d_noise_stream && !e->profile && (e->unet || !(e->pipelines && n_parts(e) > 1)))
         return sample_loop_graph(e, sampler, first_step, last_step, eta, d_x, seed, first_sample,
                                  static_cast<hipStream_t>(stream));
     if (e->pipelines && !e->profile && !e->unet)

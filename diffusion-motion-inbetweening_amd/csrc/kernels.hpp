@@ -141,7 +141,8 @@ int unet_backward(UnetModel* u, const float* gout, const uint8_t* mask, const un
 int unet_range_flag(UnetModel* u, int* flag, hipStream_t s);
 int unet_range_clear(UnetModel* u, hipStream_t s);
 hipError_t launch_unet_emb(float* emb, const float* time_table, const float* text_term, const int64_t* t_dev,
-                           int64_t t_scalar, int n_seq, int n_per_pass, int d, int n_time_rows, hipStream_t stream);
+                           int64_t t_scalar, int n_seq, int n_per_pass, int d, int n_time_rows, hipStream_t stream,
+                           const int64_t* tmap_dev = nullptr, const int* cursor = nullptr);
 
 // ---- clip_text.hip: CLIP ViT-B/32 text tower (the step before the loop) ---------------------------------------
 struct ClipText;

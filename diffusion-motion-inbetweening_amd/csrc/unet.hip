@@ -118,9 +118,11 @@ __global__ void mish_kernel(const float* __restrict__ x, float* __restrict__ y, 
 // emb[seq][:] = time_table[t] + text_term[seq]   (MDM_UNET.forward_core: embed_timestep + embed_text(mask_cond))
 __global__ void unet_emb_kernel(float* __restrict__ emb, const float* __restrict__ time_table,
                                 const float* __restrict__ text_term, const int64_t* __restrict__ t_dev,
-                                int64_t t_scalar, int n_per_pass, int d, int n_time_rows) {
+                                int64_t t_scalar, int n_per_pass, int d, int n_time_rows,
+                                const int64_t* __restrict__ tmap_dev, const int* __restrict__ cursor) {
     const int seq = blockIdx.x;
-    int64_t t = t_dev ? t_dev[seq % n_per_pass] : t_scalar;
+    // cursor != null (hipGraph replay, round 6): the step's timestep comes from the chain's device table, as in token0_kernel
+    int64_t t = cursor ? tmap_dev[*cursor] : (t_dev ? t_dev[seq % n_per_pass] : t_scalar);
     t = t < 0 ? 0 : (t >= n_time_rows ? n_time_rows - 1 : t);
     for (int n = threadIdx.x; n < d; n += blockDim.x) {
         float e = time_table[(size_t)t * d + n];
@@ -1494,9 +1496,10 @@ int unet_range_clear(UnetModel* u, hipStream_t s) {
 }
 
 hipError_t launch_unet_emb(float* emb, const float* time_table, const float* text_term, const int64_t* t_dev,
-                           int64_t t_scalar, int n_seq, int n_per_pass, int d, int n_time_rows, hipStream_t stream) {
+                           int64_t t_scalar, int n_seq, int n_per_pass, int d, int n_time_rows, hipStream_t stream,
+                           const int64_t* tmap_dev, const int* cursor) {
     hipLaunchKernelGGL(unet_emb_kernel, dim3(n_seq), dim3(256), 0, stream, emb, time_table, text_term, t_dev, t_scalar,
-                       n_per_pass, d, n_time_rows);
+                       n_per_pass, d, n_time_rows, tmap_dev, cursor);
     return hipGetLastError();
 }
 
