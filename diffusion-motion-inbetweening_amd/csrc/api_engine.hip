@@ -147,7 +147,7 @@ int cmdi_create(const cmdi_model_desc* desc, cmdi_handle* out) {
     e->h3_tile_ffn1 = env_probe("CMDI_H3_TILE_FFN1", env_probe("CMDI_H3_TILE", 0));
     e->h3_tile_ffn2 = env_probe("CMDI_H3_TILE_FFN2", env_probe("CMDI_H3_TILE", 0));
     e->h3w_min_m = env_int("CMDI_H3W_MIN_M", 8192);
-    e->h3w = env_int("CMDI_H3W", 0);    // (round 6, in progress: the weight-stationary kernel is opt-in until it beats the tiled one at every shape it is routed to)
+    e->h3w = env_int("CMDI_H3W", 0);    // (round 6: the weight-stationary kernel wins no shape of C2 — opt-in; profiles/r06_h3w_stall_table.md)
     e->ln_fuse = env_probe("CMDI_LN_FUSE", 0) && desc->d_model == 512;
     e->io_h3 = e->precision == CMDI_PREC_F16X3 && !e->ln_fuse && env_probe("CMDI_IO_H3", 1);
     e->ln_fold = e->io_h3 && desc->d_model == 512 && env_int("CMDI_LN_FOLD", 1);
