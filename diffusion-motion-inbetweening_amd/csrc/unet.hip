@@ -313,6 +313,28 @@ __global__ __launch_bounds__(NT) void gn_fused_kernel(const float* __restrict__ 
     if (overflow && range_flag) atomicOr(range_flag, 1);
 }
 
+// out = resid + (slice 0 + slice 1 + ...) over the frame rows of every sequence: the residual epilogue of a gradient GEMM that ran
+// as split-K (round 6: the identity-residual blocks' d x = d out + conv1^T(dF1) at the coarse levels / small batches, where an
+// unsplit launch is a handful of blocks walking 160 K steps).  fp32 rows (ld ldc) and / or split rows (ld cs_ld, halves); halo
+// rows are not touched (the convolution rule of the GEMM epilogue it replaces).  In place on resid is fine (one thread per element).
+__global__ __launch_bounds__(256) void sum_slices_resid_kernel(const float* __restrict__ part, int nsl, size_t sl,
+                                                               const float* resid, int r_ld, float* out_f, int ldc,
+                                                               _Float16* __restrict__ out_s, int cs_ld, int N, int Tp, int h, int Tv,
+                                                               long n_frames) {
+    const int q4 = N >> 2;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_frames * q4) return;
+    const long fr = i / q4;
+    const int c = (int)(i - fr * q4) * 4;
+    const size_t row = (size_t)(fr / Tv) * Tp + h + (size_t)(fr % Tv);
+    const float4 v = load_slices(part + row * N + c, nsl, sl);
+    const float4 r = *reinterpret_cast<const float4*>(resid + row * r_ld + c);
+    const float y[4] = {v.x + r.x, v.y + r.y, v.z + r.z, v.w + r.w};
+    if (out_f) *reinterpret_cast<float4*>(out_f + row * ldc + c) = make_float4(y[0], y[1], y[2], y[3]);
+    bool overflow = false;
+    if (out_s) store_act4(out_s, row, cs_ld, c, y, 0, overflow);
+}
+
 // ---- input-VJP pieces (reconstruction guidance through the U-Net): everything is linear in the output gradient ----
 __device__ __forceinline__ float mish_grad(float z) { return mish_grad_f(z); }
 
@@ -812,8 +834,8 @@ UnetModel* unet_new(int n_feats, int added, int dim, const int mults[4], int max
     u->J = n_feats; u->added = added; u->dim = dim; u->max_seq = max_seq; u->text = text; u->want_grad = want_grad;
     u->attention = attention; u->x6 = x6;
     if (attention && x6) { u->err = "MDM_UNET with LinearAttention sites is built for the f16x3 precision only"; return u; }
+    if (const char* v = std::getenv("CMDI_UNET_KSPLIT")) u->ksplit_ok = std::atoi(v);   // 0 off, 1 default, 2 the round-2 rule
 #ifdef CMDI_PROBES   // tuning knobs: probes build only
-    if (const char* v = std::getenv("CMDI_UNET_KSPLIT")) u->ksplit_ok = std::atoi(v);
     if (const char* v = std::getenv("CMDI_UNET_TILE")) u->big_tile = std::atoi(v);
     if (const char* v = std::getenv("CMDI_UNET_MFAST")) u->m_fast = std::atoi(v);
 #endif
@@ -1032,6 +1054,17 @@ int x6_rows(UnetModel* u, const _Float16* a, int a_ld, const void* wx, const flo
     return 0;
 }
 
+// split-K slices of a long-K GEMM whose 128 x 128 tiles do not fill the chip: one round of the 512 block slots, slices of at
+// least 10 K steps, and nsl * M rows inside the 8,192-row slice buffers (F1 / F2 / GT and the stashes).  Round 6: 8 / 16
+// slices for <= 64 / <= 32 tiles (B <= 10: the coarse levels were one block per CU walking 40 K steps); CMDI_UNET_KSPLIT=2
+// keeps the round-2 rule (4 slices for <= 128 tiles, else 2).  The GroupNorm kernels add the slices in order.
+int pick_ksplit(const UnetModel* u, long tiles, int M, int K) {
+    int ks = tiles <= 128 ? 4 : 2;
+    if (u->ksplit_ok != 2) ks = tiles <= 32 ? 16 : tiles <= 64 ? 8 : ks;
+    while (ks > 1 && ((long)ks * M > 8192 || K / 32 / ks < 10)) ks >>= 1;
+    return ks;
+}
+
 // conv as GEMM over rows; `a` points at row 0 of the input frame buffer (column block already applied)
 int conv_rows(UnetModel* u, const Conv& c, const _Float16* ws, const _Float16* a, int a_ld, int m_rows, int level_out,
               int taps, int pad, int a_mul, int c_mul, int c_add, float* out_f, _Float16* out_s, int cs_ld,
@@ -1061,7 +1094,7 @@ int conv_rows(UnetModel* u, const Conv& c, const _Float16* ws, const _Float16* a
         // and the GroupNorm kernels add the slices in order (deterministic; atomics were measured slower)
         const long tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
         if (nsl_out && u->ksplit_ok && tiles <= 256 && p.K >= 2048) {
-            p.ksplit = tiles <= 128 ? 4 : 2;
+            p.ksplit = pick_ksplit(u, tiles, p.M, p.K);
             p.slice_stride = (long)p.M * p.N;
             tile = 8;
         }
@@ -1210,7 +1243,7 @@ int grad_gemm(UnetModel* u, const _Float16* a, int a_ld, const _Float16* w, int 
         const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
         *nsl_out = 1;
         if (!resid && !out_s && u->ksplit_ok && tiles <= 256 && p.K >= 2048 && ldc == N) {
-            p.ksplit = tiles <= 128 ? 4 : 2;
+            p.ksplit = pick_ksplit(u, tiles, M, p.K);
             p.slice_stride = (long)M * N;
             tile = 8;
             *nsl_out = p.ksplit;
@@ -1277,6 +1310,20 @@ int res_block_bwd(UnetModel* u, const ResBlock& r, const RBStash& st, const floa
     // h1 = Mish(GN1(conv1(x)) * (1 + scale) + shift)
     if (gn_bwd(u, u->GT[level], C, st.F1, st.n1, st.st1, r.n1, ss, nseq, level, s, nt)) return -1;
     if (!r.res.wb) {   // identity residual: d x = conv1^T(dF1) + d out
+        // round 6: where the tiles do not fill the chip the GEMM runs as split-K into the (now free) d h1 buffer and a small kernel
+        // adds the slices and the residual — the unsplit residual epilogue was 16-160 blocks walking all 160 K steps (~100 us)
+        const long tiles = (long)((rows + 127) / 128) * ((Ni + 127) / 128);
+        if (!u->x6 && u->ksplit_ok == 1 && Ni == C && tiles <= 256 && pick_ksplit(u, tiles, rows, 5 * C) > 1) {
+            int ns1 = 1;
+            if (grad_gemm(u, u->GS[level], 2 * C, r.c1.wb, rows, Ni, C, 5, 2, 1, 0, 0, level, u->GT[level], Ni, nullptr, 0, nullptr, 0, s,
+                          &ns1))
+                return -1;
+            const long n_frames = (long)nseq * L.Tv;
+            hipLaunchKernelGGL(sum_slices_resid_kernel, dim3((unsigned)((n_frames * (Ni / 4) + 255) / 256)), dim3(256), 0, s, u->GT[level],
+                               ns1, (size_t)rows * Ni, dy, ld_dy, out_f, Ni, out_s, 2 * Ni, Ni, L.Tp, L.h, L.Tv, n_frames);
+            UCHK(hipGetLastError());
+            return 0;
+        }
         return grad_gemm(u, u->GS[level], 2 * C, r.c1.wb, rows, Ni, C, 5, 2, 1, 0, 0, level, out_f, Ni, out_s, 2 * Ni, dy,
                          ld_dy, s);
     }
