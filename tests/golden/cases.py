@@ -281,6 +281,11 @@ BIG_CASES = {
                          eta=0.0, seed=514, ragged=True, every=10, keep=(0, 63, 64, 127, 128, 255)),
     "c4_ddpm_long": dict(kind="chain", text=True, cfg=True, weight_seed=46, B=256, T=196, respacing="ddim100", sampler="ddpm",
                          seed=515, ragged=True, every=10, keep=(0, 63, 64, 127, 128, 255)),
+    # (round 6) BASELINE config 5, one rank's share END TO END: B=128 x 196 frames (1024 / 8 GPUs), text CFG, ragged lengths, ALL
+    # 1000 ancestral steps through the reference on CPU (~70 min).  The other ranks run the same kernels on other samples
+    # (Philox keyed by the global sample index; shard invariance is bitwise, test_full_size_batch_independence_and_sharding).
+    "c5_rank_long": dict(kind="chain", text=True, cfg=True, weight_seed=47, B=128, T=196, respacing=None, sampler="ddpm",
+                         seed=516, ragged=True, every=100, keep=(0, 31, 32, 63, 64, 127)),
     # (VERDICT r3 task 5b) BASELINE config 2 itself, END TO END: B=32 x 196 frames, text CFG, ragged lengths, ALL 1000
     # ancestral steps through the reference on CPU (~15 min), so that the two-pipeline / two-stream one-call schedule is
     # compared with reference values over the whole chain, not its first 20 steps.  Sample 0's x_t every 100 steps.
