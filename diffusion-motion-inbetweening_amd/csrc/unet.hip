@@ -335,6 +335,34 @@ __global__ __launch_bounds__(256) void sum_slices_resid_kernel(const float* __re
     if (out_s) store_act4(out_s, row, cs_ld, c, y, 0, overflow);
 }
 
+// The epilogue of ANY long-K GEMM that ran as split-K into the scratch slices (part[slice][m][n], GEMM rows, no row mapping): adds
+// the slices in order (+ the residual), maps GEMM row m to its output row (m * c_mul + c_add for the transposed convolutions)
+// and writes frames only — the convolution rule of gemm_h3's epilogues — as fp32 rows and / or split rows.
+__global__ __launch_bounds__(256) void sum_slices_kernel(const float* __restrict__ part, int nsl, size_t sl, int M, int N, int c_mul,
+                                                         int c_add, int tp, int t_lo, int t_hi, const float* resid, int r_ld,
+                                                         float* out_f, int ldc, _Float16* __restrict__ out_s, int cs_ld,
+                                                         int* __restrict__ range_flag) {
+    const int q4 = N >> 2;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)M * q4) return;
+    const int m = (int)(i / q4), c = (int)(i - (long)m * q4) * 4;
+    const size_t mo = c_mul ? (size_t)m * c_mul + c_add : (size_t)m;
+    if (tp) {
+        const int pos = (int)(mo % tp);
+        if (pos < t_lo || pos >= t_hi) return;
+    }
+    const float4 v = load_slices(part + (size_t)m * N + c, nsl, sl);
+    float y[4] = {v.x, v.y, v.z, v.w};
+    if (resid) {
+        const float4 r = *reinterpret_cast<const float4*>(resid + mo * r_ld + c);
+        y[0] += r.x; y[1] += r.y; y[2] += r.z; y[3] += r.w;
+    }
+    if (out_f) *reinterpret_cast<float4*>(out_f + mo * ldc + c) = make_float4(y[0], y[1], y[2], y[3]);
+    bool overflow = false;
+    if (out_s) store_act4(out_s, mo, cs_ld, c, y, 0, overflow);
+    if (overflow && range_flag) atomicOr(range_flag, 1);
+}
+
 // ---- input-VJP pieces (reconstruction guidance through the U-Net): everything is linear in the output gradient ----
 __device__ __forceinline__ float mish_grad(float z) { return mish_grad_f(z); }
 
@@ -692,6 +720,7 @@ struct UnetModel {
     bool want_grad = false, stash_valid = false;
     RBStash st_down[4][2], st_mid[2], st_up[3][2], st_fin;   // st_fin: F1 / st1 only
     float *GA[4] = {}, *GC[4] = {}, *GT[4] = {}, *GB[4] = {}, *gIn0 = nullptr, *bsums = nullptr;
+    float* KS = nullptr;    // split-K slices of the GEMMs whose caller does not take slices (split_k_generic): 8,192 rows x Cw
     _Float16 *GS[4] = {}, *GU[4] = {}, *GBS[4] = {}, *gOutS = nullptr;
     int* range_flag = nullptr;
     std::string err;
@@ -834,7 +863,7 @@ UnetModel* unet_new(int n_feats, int added, int dim, const int mults[4], int max
     u->J = n_feats; u->added = added; u->dim = dim; u->max_seq = max_seq; u->text = text; u->want_grad = want_grad;
     u->attention = attention; u->x6 = x6;
     if (attention && x6) { u->err = "MDM_UNET with LinearAttention sites is built for the f16x3 precision only"; return u; }
-    if (const char* v = std::getenv("CMDI_UNET_KSPLIT")) u->ksplit_ok = std::atoi(v);   // 0 off, 1 default, 2 the round-2 rule
+    if (const char* v = std::getenv("CMDI_UNET_KSPLIT")) u->ksplit_ok = std::atoi(v);   // 0 off, 1 default, 2 the round-2 rule, 3 = 1 without split_k_generic
 #ifdef CMDI_PROBES   // tuning knobs: probes build only
     if (const char* v = std::getenv("CMDI_UNET_TILE")) u->big_tile = std::atoi(v);
     if (const char* v = std::getenv("CMDI_UNET_MFAST")) u->m_fast = std::atoi(v);
@@ -904,6 +933,7 @@ UnetModel* unet_new(int n_feats, int added, int dim, const int mults[4], int max
                       alloc_rows(u, &u->AGN[l], rows, Cw);
         }
     }
+    rc |= alloc_rows(u, &u->KS, 8192, Cw);
     rc |= alloc_rows(u, &u->in0S, ns * 256, 2 * (size_t)u->Cin0p);
     rc |= alloc_rows(u, &u->S0skip, ns * 256, 2 * (size_t)Cw);
     rc |= alloc_rows(u, &u->outF, ns * 256, (size_t)u->Np);
@@ -1065,6 +1095,34 @@ int pick_ksplit(const UnetModel* u, long tiles, int M, int K) {
     return ks;
 }
 
+// Round 6: a long-K GEMM whose caller does NOT take split-K slices (outputs with a residual, split rows, a strided or
+// transposed row map: the down / up-sampling convolutions, the gradient GEMMs of the blocks with a residual convolution) and
+// whose tiles do not fill the chip runs as a PLAIN split-K GEMM into the scratch slices + sum_slices_kernel, which is the
+// epilogue it replaces.  1 = launched, 0 = not applicable (the caller launches as before), -1 = error.
+int split_k_generic(UnetModel* u, int kind, const H3Params& p0, hipStream_t s) {
+    if (u->ksplit_ok != 1 || !u->KS || p0.ksplit > 1 || u->x6) return 0;
+    if (kind != H3_PLAIN && kind != H3_PLAIN_SPLIT && kind != H3_RESID) return 0;
+    if (p0.K < 2048 || p0.N % 4 != 0 || p0.rc_tv) return 0;
+    const long tiles = (long)((p0.M + 127) / 128) * ((p0.N + 127) / 128);
+    if (tiles > 256) return 0;
+    const int Cw = u->C[1];
+    const int ks = pick_ksplit(u, tiles, (int)(((long)p0.M * p0.N + Cw - 1) / Cw), p0.K);
+    if (ks <= 1) return 0;
+    H3Params q = p0;
+    q.C = u->KS; q.Cs = nullptr; q.aux = nullptr; q.R = nullptr; q.ldc = q.N; q.cs_ld = 0; q.r_ld = 0; q.range_flag = nullptr;
+    q.c_row_mul = 0; q.c_row_add = 0; q.tp = 0; q.t_lo = 0; q.t_hi = 0;      // slices in GEMM rows; the sum kernel maps them
+    q.ksplit = ks; q.slice_stride = (long)q.M * q.N;
+    UCHK(launch_gemm_h3(H3_PLAIN, q, 8, s));
+    float* out_f = kind == H3_PLAIN_SPLIT ? p0.aux : p0.C;
+    const float* resid = kind == H3_RESID ? p0.R : nullptr;
+    const long n4 = (long)p0.M * (p0.N / 4);
+    hipLaunchKernelGGL(sum_slices_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, u->KS, ks, (size_t)q.slice_stride, p0.M,
+                       p0.N, p0.c_row_mul, p0.c_row_add, p0.tp, p0.t_lo, p0.t_hi, resid, p0.r_ld ? p0.r_ld : p0.ldc, out_f, p0.ldc,
+                       kind == H3_PLAIN ? nullptr : p0.Cs, p0.cs_ld ? p0.cs_ld : 2 * p0.N, p0.range_flag);
+    UCHK(hipGetLastError());
+    return 1;
+}
+
 // conv as GEMM over rows; `a` points at row 0 of the input frame buffer (column block already applied)
 int conv_rows(UnetModel* u, const Conv& c, const _Float16* ws, const _Float16* a, int a_ld, int m_rows, int level_out,
               int taps, int pad, int a_mul, int c_mul, int c_add, float* out_f, _Float16* out_s, int cs_ld,
@@ -1115,6 +1173,10 @@ int conv_rows(UnetModel* u, const Conv& c, const _Float16* ws, const _Float16* a
             q.M = m_rows / lo.Tp * lo.Tv;
             if (gemm_h3p_supports(kind, q)) p = q;
         }
+    }
+    if (!tile && p.ksplit <= 1) {
+        const int r = split_k_generic(u, kind, p, s);
+        if (r) return r < 0 ? -1 : 0;
     }
     UCHK(launch_gemm_h3(kind, p, tile, s));
     return 0;
@@ -1268,6 +1330,10 @@ int grad_gemm(UnetModel* u, const _Float16* a, int a_ld, const _Float16* w, int 
             if (gemm_h3p_supports(kind, q)) p = q;
         }
     }
+    if (!tile && p.ksplit <= 1) {
+        const int r = split_k_generic(u, kind, p, s);
+        if (r) return r < 0 ? -1 : 0;
+    }
     UCHK(launch_gemm_h3(kind, p, tile, s));
     return 0;
 }
@@ -1313,7 +1379,7 @@ int res_block_bwd(UnetModel* u, const ResBlock& r, const RBStash& st, const floa
         // round 6: where the tiles do not fill the chip the GEMM runs as split-K into the (now free) d h1 buffer and a small kernel
         // adds the slices and the residual — the unsplit residual epilogue was 16-160 blocks walking all 160 K steps (~100 us)
         const long tiles = (long)((rows + 127) / 128) * ((Ni + 127) / 128);
-        if (!u->x6 && u->ksplit_ok == 1 && Ni == C && tiles <= 256 && pick_ksplit(u, tiles, rows, 5 * C) > 1) {
+        if (!u->x6 && (u->ksplit_ok == 1 || u->ksplit_ok == 3) && Ni == C && tiles <= 256 && pick_ksplit(u, tiles, rows, 5 * C) > 1) {
             int ns1 = 1;
             if (grad_gemm(u, u->GS[level], 2 * C, r.c1.wb, rows, Ni, C, 5, 2, 1, 0, 0, level, u->GT[level], Ni, nullptr, 0, nullptr, 0, s,
                           &ns1))
