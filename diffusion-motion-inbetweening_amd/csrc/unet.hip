@@ -1091,6 +1091,8 @@ int x6_rows(UnetModel* u, const _Float16* a, int a_ld, const void* wx, const flo
 int pick_ksplit(const UnetModel* u, long tiles, int M, int K) {
     int ks = tiles <= 128 ? 4 : 2;
     if (u->ksplit_ok != 2) ks = tiles <= 32 ? 16 : tiles <= 64 ? 8 : ks;
+    // (slice counts that fill the 512 slots exactly — 3, 5, 6, 12 — were measured: no gain over the powers of two,
+    // profiles/r06_unet_ksplit_ab4.txt)
     while (ks > 1 && ((long)ks * M > 8192 || K / 32 / ks < 10)) ks >>= 1;
     return ks;
 }
