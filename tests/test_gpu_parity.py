@@ -2046,6 +2046,53 @@ def test_unet_gradient_gemms_on_the_persistent_kernel_are_bitwise_the_tiled_rout
     assert np.array_equal(res["0"][1], res["1"][1]), float(np.abs(res["0"][1] - res["1"][1]).max())
 
 
+@pytest.mark.parametrize("B", [1, 2, 10])
+def test_unet_split_k_schedules_agree(cases, monkeypatch, B):
+    """Round 6: at small batches the long-K GEMMs of MDM_UNET run as split-K — more slices where the tiles do not fill the chip,
+    and (split_k_generic) also the GEMMs whose epilogue adds a residual, writes split rows or maps rows (down / up-sampling
+    convolutions, the residual blocks' gradient GEMMs) through scratch slices + sum_slices_kernel.  The three schedules
+    (CMDI_UNET_KSPLIT = 2: the round-2 rule, 3: without the generic path, 1: default) differ in summation order only: forward
+    output and input gradient of the released geometry agree to the rounding level of one evaluation (1e-5 / 2e-5 stated; measured
+    2.4e-6 / 4.8e-6), and the default stays within the
+    usual bound of the float64-checked oracle."""
+    from oracle.unet_oracle import UnetOracle
+    mu = sub("utils.model_util")
+    case = cases.UNET_XL_CASE
+    T = 196
+    rng = np.random.default_rng(777 + B)
+    shape = (B, 263, 1, T)
+    x, obs, gout = (rng.standard_normal(shape).astype(np.float32) for _ in range(3))
+    m = rng.random(shape) < 0.2
+    enc = rng.standard_normal((B, 512)).astype(np.float32)
+    t = rng.integers(0, 1000, B)
+    sc = np.full(B, 2.5, np.float32)
+    res, sd_np = {}, None
+    for mode in ("2", "3", "1"):
+        monkeypatch.setenv("CMDI_UNET_KSPLIT", mode)
+        args = SimpleNamespace(dataset="humanml", arch="unet", keyframe_conditioned=True, dim_mults=case["dim_mults"], cond_mask_prob=0.1)
+        model, _ = mu.create_model_and_diffusion(args, None)
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        mu.load_model_wo_clip(model, weights.to_torch(weights.fill_like(shapes, case["weight_seed"])) |
+                              {k: v for k, v in model.state_dict().items() if k.endswith(".pe")})
+        model = model.to(DEV).eval()
+        sd_np = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+        wrapped = sub("model.cfg_sampler").ClassifierFreeSampleModel(model)
+        z = tt(x).requires_grad_(True)
+        with torch.enable_grad():
+            out = wrapped(z, tt(t), y={"text_embed": tt(enc), "text_scale": tt(sc)}, obs_x0=tt(obs), obs_mask=tt(m))
+            gx, = torch.autograd.grad((out * tt(gout)).sum(), z)
+        res[mode] = (out.detach().cpu().numpy(), gx.cpu().numpy())
+        model.invalidate_engine()
+        del model, wrapped
+        torch.cuda.empty_cache()
+    for mode in ("2", "3"):
+        assert ok("unet_split_k_schedules.forward", rel_l2(res["1"][0], res[mode][0]), 1e-5), (mode, rel_l2(res["1"][0], res[mode][0]))
+        assert ok("unet_split_k_schedules.vjp", rel_l2(res["1"][1], res[mode][1]), 2e-5), (mode, rel_l2(res["1"][1], res[mode][1]))
+    if B <= 2:
+        want, _, _ = UnetOracle(sd_np).forward_cfg(x, t, enc, sc, obs, m)
+        assert ok("unet_split_k_schedules.vs_oracle", rel_l2(res["1"][0], want), 2e-5), rel_l2(res["1"][0], want)
+
+
 @pytest.mark.parametrize("scale,expect", [(4000.0, "f16x3"), (60000.0, "bf16x6"), (60000.0, "pinned")])
 def test_unet_real_scale_activations_and_range_probe(cases, scale, expect, monkeypatch):
     """MDM_UNET's range story.  The reference's U-Net is plain fp32 at any activation scale (model/mdm_unet.py:561-849); the
