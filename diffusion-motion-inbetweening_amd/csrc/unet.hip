@@ -694,7 +694,7 @@ struct UnetModel {
     bool finalized = false;
     // workspace
     float *emb_h = nullptr, *cvec = nullptr, *cm = nullptr, *ss = nullptr, *stats = nullptr;
-    int ksplit_ok = 1;   // CMDI_UNET_KSPLIT=0: no split-K at the coarse levels
+    int ksplit_ok = 1;   // CMDI_UNET_SPLITK=0: no split-K at the coarse levels
     hipEvent_t probe_ev[2] = {nullptr, nullptr};   // bench: events around ONE convolution GEMM (downs.0.1, blocks.1)
     int probe_mnk[3] = {0, 0, 0};
     const char* probe_route = "";                  // kernel family that GEMM dispatched to (cmdi_profile_kernel)
@@ -863,7 +863,7 @@ UnetModel* unet_new(int n_feats, int added, int dim, const int mults[4], int max
     u->J = n_feats; u->added = added; u->dim = dim; u->max_seq = max_seq; u->text = text; u->want_grad = want_grad;
     u->attention = attention; u->x6 = x6;
     if (attention && x6) { u->err = "MDM_UNET with LinearAttention sites is built for the f16x3 precision only"; return u; }
-    if (const char* v = std::getenv("CMDI_UNET_KSPLIT")) u->ksplit_ok = std::atoi(v);   // 0 off, 1 default, 2 the round-2 rule, 3 = 1 without split_k_generic
+    if (const char* v = std::getenv("CMDI_UNET_SPLITK")) u->ksplit_ok = std::atoi(v);   // 0 off, 1 default, 2 the round-2 rule, 3 = 1 without split_k_generic
 #ifdef CMDI_PROBES   // tuning knobs: probes build only
     if (const char* v = std::getenv("CMDI_UNET_TILE")) u->big_tile = std::atoi(v);
     if (const char* v = std::getenv("CMDI_UNET_MFAST")) u->m_fast = std::atoi(v);
@@ -1086,7 +1086,7 @@ int x6_rows(UnetModel* u, const _Float16* a, int a_ld, const void* wx, const flo
 
 // split-K slices of a long-K GEMM whose 128 x 128 tiles do not fill the chip: one round of the 512 block slots, slices of at
 // least 10 K steps, and nsl * M rows inside the 8,192-row slice buffers (F1 / F2 / GT and the stashes).  Round 6: 8 / 16
-// slices for <= 64 / <= 32 tiles (B <= 10: the coarse levels were one block per CU walking 40 K steps); CMDI_UNET_KSPLIT=2
+// slices for <= 64 / <= 32 tiles (B <= 10: the coarse levels were one block per CU walking 40 K steps); CMDI_UNET_SPLITK=2
 // keeps the round-2 rule (4 slices for <= 128 tiles, else 2).  The GroupNorm kernels add the slices in order.
 int pick_ksplit(const UnetModel* u, long tiles, int M, int K) {
     int ks = tiles <= 128 ? 4 : 2;

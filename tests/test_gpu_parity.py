@@ -2051,7 +2051,7 @@ def test_unet_split_k_schedules_agree(cases, monkeypatch, B):
     """Round 6: at small batches the long-K GEMMs of MDM_UNET run as split-K — more slices where the tiles do not fill the chip,
     and (split_k_generic) also the GEMMs whose epilogue adds a residual, writes split rows or maps rows (down / up-sampling
     convolutions, the residual blocks' gradient GEMMs) through scratch slices + sum_slices_kernel.  The three schedules
-    (CMDI_UNET_KSPLIT = 2: the round-2 rule, 3: without the generic path, 1: default) differ in summation order only: forward
+    (CMDI_UNET_SPLITK = 2: the round-2 rule, 3: without the generic path, 1: default) differ in summation order only: forward
     output and input gradient of the released geometry agree to the rounding level of one evaluation (1e-5 / 2e-5 stated; measured
     2.4e-6 / 4.8e-6), and the default stays within the
     usual bound of the float64-checked oracle."""
@@ -2068,7 +2068,7 @@ def test_unet_split_k_schedules_agree(cases, monkeypatch, B):
     sc = np.full(B, 2.5, np.float32)
     res, sd_np = {}, None
     for mode in ("2", "3", "1"):
-        monkeypatch.setenv("CMDI_UNET_KSPLIT", mode)
+        monkeypatch.setenv("CMDI_UNET_SPLITK", mode)
         args = SimpleNamespace(dataset="humanml", arch="unet", keyframe_conditioned=True, dim_mults=case["dim_mults"], cond_mask_prob=0.1)
         model, _ = mu.create_model_and_diffusion(args, None)
         shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
